@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference's host program over the C-ABI.
+
+Names follow the reference (safaad/aim host.c): a *device set* is what
+`struct dpu_set_t` was, `push` are the host->device scatters
+(host.c:246-268), `launch` is `dpu_launch(DPU_SYNCHRONOUS)` (host.c:289) and
+`pull` the gathers (host.c:316-326).  Pairs are split over the devices of a
+set in contiguous blocks exactly like host.c:191-209 splits them over DPUs.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import capi
+from .capi import (ALGO_BY_NAME, ALGO_NW, ALGO_SWG, ALGO_WFA, FLAG_BACKTRACE, FLAG_REDUCE, FLAG_SWG_W16,
+                   REQUEST_DTYPE, RESULT_DTYPE, Params)
+
+
+def round_up_8(x):
+    return ((x + 7) // 8) * 8
+
+
+def launcher_sizes(algo, read_length, error, mismatch=3, gap_o=4, gap_e=1, gap=4):
+    """(MAX_SCORE, READ_SIZE) as the reference launchers derive them."""
+    lib = capi.load()
+    ms, rs = C.c_int32(), C.c_int32()
+    a = ALGO_BY_NAME[algo] if isinstance(algo, str) else algo
+    capi.check(lib.aim_launcher_sizes(a, read_length, float(error), mismatch, gap_o, gap_e, gap, C.byref(ms), C.byref(rs)))
+    return ms.value, rs.value
+
+
+def make_params(algo, max_score, read_size, match=0, mismatch=3, gap_o=4, gap_e=1, gap=4, backtrace=False,
+                reduce=False, swg_w16=False):
+    a = ALGO_BY_NAME[algo] if isinstance(algo, str) else algo
+    flags = (FLAG_BACKTRACE if backtrace else 0) | (FLAG_REDUCE if reduce else 0) | (FLAG_SWG_W16 if swg_w16 else 0)
+    return Params(a, match, mismatch, gap_o, gap_e, gap, gap, max_score, read_size, flags)
+
+
+def params_for(algo, read_length, error, **kw):
+    """Params from launcher-style (-l, -e) arguments."""
+    cost = {k: kw[k] for k in ("mismatch", "gap_o", "gap_e", "gap") if k in kw}
+    ms, rs = launcher_sizes(algo, read_length, error, **cost)
+    return make_params(algo, ms, rs, **kw)
+
+
+def gen_pairs(seed, first_idx, n_pairs, length, error, read_size):
+    """Seeded synthetic pairs in the wire layout (requests, patterns[n][rs], texts[n][rs])."""
+    lib = capi.load()
+    req = np.zeros(n_pairs, dtype=REQUEST_DTYPE)
+    pat = np.zeros((n_pairs, read_size), dtype=np.uint8)
+    txt = np.zeros((n_pairs, read_size), dtype=np.uint8)
+    capi.check(lib.aim_gen_pairs(seed, first_idx, n_pairs, length, float(error), read_size, capi.ptr(req),
+                                 capi.ptr(pat), capi.ptr(txt)))
+    return req, pat, txt
+
+
+def pairs_to_text(req, pat, txt):
+    """Render pairs in the reference input format ('>'pattern / '<'text lines)."""
+    out = []
+    for i in range(len(req)):
+        out.append(b">" + pat[i, : req["pattern_len"][i]].tobytes() + b"\n")
+        out.append(b"<" + txt[i, : req["text_len"][i]].tobytes() + b"\n")
+    return b"".join(out)
+
+
+def parse_pairs(data, read_size, max_pairs=None, first_idx=0):
+    """get_reads (host.c:91-134): two lines per pair, first character dropped,
+    length = line length - 2 (a final line without newline loses its last base)."""
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+        terminated = True
+    else:
+        terminated = False
+    n = len(lines) // 2
+    if max_pairs is not None:
+        n = min(n, max_pairs)
+    req = np.zeros(n, dtype=REQUEST_DTYPE)
+    pat = np.zeros((n, read_size), dtype=np.uint8)
+    txt = np.zeros((n, read_size), dtype=np.uint8)
+    for i in range(n):
+        for arr, key, j in ((pat, "pattern_len", 2 * i), (txt, "text_len", 2 * i + 1)):
+            ln = lines[j]
+            full = len(ln) + (1 if (terminated or j < len(lines) - 1) else 0)   # getline length incl. '\n'
+            length = full - 2
+            if length > read_size:
+                raise ValueError("READ LENGTH less than length of the input reads")
+            seq = ln[1 : 1 + length]
+            arr[i, : len(seq)] = np.frombuffer(seq, dtype=np.uint8)
+            req[key][i] = length
+        req["idx"][i] = first_idx + i
+    return req, pat, txt
+
+
+def cigar_of(ops_row, begin_offset, end_offset):
+    lib = capi.load()
+    buf = C.create_string_buffer(int(4 * max(16, int(end_offset) - int(begin_offset)) + 32))
+    n = capi.check(lib.aim_cigar_format(capi.ptr(ops_row), int(begin_offset), int(end_offset), buf, len(buf)))
+    return buf.raw[:n]
+
+
+def format_output(results, ops, backtrace):
+    """Output file of the reference host (host.c:339-349): 'idx, score, \\n' [+ RLE CIGAR line]."""
+    out = []
+    for i in range(len(results)):
+        out.append(b"%d, %d, \n" % (int(results["idx"][i]), int(results["score"][i])))
+        if backtrace:
+            out.append(cigar_of(ops[i], results["begin_offset"][i], results["end_offset"][i]))
+    return b"".join(out)
+
+
+class DeviceSet:
+    """struct dpu_set_t counterpart: nr_devices GPUs, one stream each."""
+
+    def __init__(self, nr_devices=1, device_ids=None):
+        self.lib = capi.load()
+        self.handle = C.c_void_p()
+        ids = None
+        if device_ids is not None:
+            ids = (C.c_int * len(device_ids))(*device_ids)
+            nr_devices = len(device_ids)
+        capi.check(self.lib.aim_set_alloc(nr_devices, ids, C.byref(self.handle)))
+        self.nr_devices = nr_devices
+        self.params = None
+        self.max_pairs = 0
+
+    def close(self):
+        if self.handle:
+            self.lib.aim_set_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def configure(self, params, max_pairs_per_device):
+        capi.check(self.lib.aim_set_configure(self.handle, C.byref(params), max_pairs_per_device))
+        self.params = params
+        self.max_pairs = max_pairs_per_device
+
+    def push(self, device, req, pat, txt):
+        req = np.ascontiguousarray(req)
+        pat = np.ascontiguousarray(pat)
+        txt = np.ascontiguousarray(txt)
+        self._keep = getattr(self, "_keep", {})
+        self._keep[device] = (req, pat, txt)   # host buffers must outlive the async copies
+        capi.check(self.lib.aim_set_push(self.handle, device, len(req), capi.ptr(req), capi.ptr(pat), capi.ptr(txt)))
+        self._n = getattr(self, "_n", {})
+        self._n[device] = len(req)
+
+    def launch(self):
+        capi.check(self.lib.aim_set_launch(self.handle))
+
+    def pull(self, device, check=True):
+        n = self._n[device]
+        rs = self.params.read_size
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        ops = np.zeros((n, 2 * rs), dtype=np.uint8) if (self.params.flags & FLAG_BACKTRACE) else None
+        rc = self.lib.aim_set_pull(self.handle, device, capi.ptr(res), capi.ptr(ops))
+        if rc != capi.AIM_EALIGN or check:
+            capi.check(rc)
+        return res, ops
+
+    def timers(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        capi.check(self.lib.aim_set_timers(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def align(self, params, req, pat, txt, check=True):
+        """Whole batch over all devices of the set: contiguous blocks (host.c:191-209), results in input order."""
+        n = len(req)
+        per = max(1, math.ceil(n / self.nr_devices))
+        if self.params is None or bytes(self.params) != bytes(params) or per > self.max_pairs:
+            self.configure(params, per)
+        blocks = []
+        for d in range(self.nr_devices):
+            lo, hi = min(n, d * per), min(n, (d + 1) * per)
+            blocks.append((lo, hi))
+            self.push(d, req[lo:hi], pat[lo:hi], txt[lo:hi])
+        self.launch()
+        parts = [self.pull(d, check=check) for d in range(self.nr_devices)]
+        res = np.concatenate([p[0] for p in parts])
+        ops = np.concatenate([p[1] for p in parts]) if parts[0][1] is not None else None
+        return res, ops
+
+
+def align(params, req, pat, txt, nr_devices=1, check=True):
+    with DeviceSet(nr_devices) as s:
+        return s.align(params, req, pat, txt, check=check)

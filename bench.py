@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: aligned pairs/s (and GCUPS), WFA-adaptive score-only, l=100, e=1%, 4M synthetic pairs
+per MI355X (BASELINE.json configs[1]); one process per GPU, pairs sharded statically (weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (one aim_align_device launch) over the rank's HBM-resident batch.
+torch is used for device memory, the stream and torch.distributed only; the work is libaim_hip.so.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=1 << 22, help="pairs per GPU (BASELINE: 4M)")
+    ap.add_argument("--length", type=int, default=100)
+    ap.add_argument("--error", type=float, default=0.01)
+    ap.add_argument("--backtrace", action="store_true", help="also produce CIGAR ops (not the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-pairs", type=int, default=1 << 20, help="pairs re-checked against the CPU oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the alignment path has no CPU fallback", file=sys.stderr)
+        sys.exit(1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from aim_amd import capi, engine
+    lib = capi.load()
+
+    n = args.pairs
+    ms, rs = engine.launcher_sizes("wfa", args.length, args.error)
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=args.backtrace)
+    # static contiguous split: rank r owns global pairs [r*n, (r+1)*n)  (host.c:191-209)
+    req, pat, txt = engine.gen_pairs(42, rank * n, n, args.length, args.error, rs)
+    alg_bytes = int(req["pattern_len"].astype(np.int64).sum() + req["text_len"].astype(np.int64).sum() + 16 * n)
+    cells = int((req["pattern_len"].astype(np.int64) * req["text_len"].astype(np.int64)).sum())
+
+    def to_dev(a, pad=64):
+        t = torch.zeros(a.nbytes + pad, dtype=torch.uint8, device=dev)
+        t[: a.nbytes].copy_(torch.from_numpy(a.view(np.uint8).reshape(-1)))
+        return t
+
+    d_req, d_pat, d_txt = to_dev(req), to_dev(pat), to_dev(txt)
+    d_res = torch.zeros(n * capi.RESULT_DTYPE.itemsize + 64, dtype=torch.uint8, device=dev)
+    d_ops = torch.zeros(n * 2 * rs + 64, dtype=torch.uint8, device=dev) if args.backtrace else None
+    scratch_bytes = lib.aim_scratch_bytes(C.byref(params), n)
+    d_scratch = torch.zeros(max(scratch_bytes, 256), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        capi.check(lib.aim_align_device(C.byref(params), n, d_req.data_ptr(), d_pat.data_ptr(), d_txt.data_ptr(),
+                                        d_res.data_ptr(), d_ops.data_ptr() if d_ops is not None else None,
+                                        d_scratch.data_ptr(), d_scratch.numel(), stream.cuda_stream))
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    # final (idx, score) gather to every rank over RCCL/xGMI -- outside the timed region, reported separately
+    gather_ms = None
+    res_host = np.frombuffer(d_res[: n * capi.RESULT_DTYPE.itemsize].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+    if world > 1:
+        scores = torch.from_numpy(np.ascontiguousarray(res_host["score"])).to(dev)
+        out = torch.empty(world * n, dtype=scores.dtype, device=dev)
+        torch.cuda.synchronize(dev)
+        g0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, scores)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert bool((out[rank * n:(rank + 1) * n] == scores).all())
+
+    # correctness of what was timed: re-check a bounded prefix against the CPU oracle (checker only)
+    from oracle import oracle
+    nv = min(n, args.verify_pairs)
+    op = oracle.params("wfa", ms, rs, reduce=True, backtrace=False)
+    ores, _, worst = oracle.align_batch(op, req["pattern_len"][:nv], req["text_len"][:nv], pat[:nv], txt[:nv],
+                                        nthreads=os.cpu_count() or 1)
+    verified = bool(worst == 0 and np.array_equal(ores["score"], res_host["score"][:nv])
+                    and np.array_equal(res_host["idx"], req["idx"]))
+    if world > 1:
+        v = torch.tensor([1 if verified else 0], device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(int(v[0]))
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        passes, spent = 0, 0.0
+        while spent < 3.0 and passes < 64:
+            c0 = time.perf_counter()
+            oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=cores)
+            spent += time.perf_counter() - c0
+            passes += 1
+        cpu_baseline = {"value": passes * n / spent, "unit": "pairs/s", "cores": cores, "kind": "port",
+                        "sample": "%d passes over the same %d-pair batch, %d threads, %.1f s wall (oracle/aim_oracle.c)"
+                                  % (passes, n, cores, spent)}
+
+    if rank == 0:
+        total_pairs = world * n * args.steps
+        value = total_pairs / elapsed
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "aligned pairs/sec WFA-adaptive l=%d e=%g%%" % (args.length, args.error * 100),
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": "WFA-adaptive %s l=%d e=%g%% %d synthetic pairs per GPU (MAX_SCORE %d, READ_SIZE %d)"
+                                   % ("with CIGAR" if args.backtrace else "score-only", args.length, args.error * 100, n, ms, rs),
+                       "pairs_per_gpu": n, "parallelism": "pairs sharded statically, %d rank(s)" % world,
+                       "kernel": lib.aim_kernel_name(C.byref(params)).decode()},
+            "gcups": value * (cells / n) / 1e9,
+            "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_pair": alg_bytes / n},
+            "cpu_baseline": cpu_baseline,
+            "gather_ms": gather_ms,
+            "verified_vs_oracle": verified,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not verified:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+/*
+ * aim_hip.h -- C-ABI of the MI355X alignment engine (libaim_hip.so).
+ *
+ * This is the drop-in boundary for AIM's per-pair alignment path.  The
+ * reference host program (safaad/aim, e.g. WFA/DPU-WRAM/host/host.c) talks to
+ * the UPMEM SDK through nine calls and a byte-layout ABI in MRAM; every entry
+ * point below names the reference call site it replaces.  Plain C: pointers,
+ * sizes, POD structs; no C++ or torch types cross this boundary.
+ *
+ * All functions return AIM_OK (0) or a negative AIM_E* code; aim_last_error()
+ * returns a thread-local human readable message for the last failure.
+ * There is no CPU fallback: without a usable HIP device every compute entry
+ * point fails with AIM_ENODEV.
+ */
+#ifndef AIM_HIP_H
+#define AIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIM_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------- */
+#define AIM_OK 0
+#define AIM_EINVAL (-1)  /* bad argument / unsupported configuration          */
+#define AIM_ENODEV (-2)  /* no HIP device / HIP runtime failure                */
+#define AIM_ENOMEM (-3)  /* host or device allocation failed                  */
+#define AIM_ESTATE (-4)  /* call sequence violated (e.g. launch before push)  */
+#define AIM_EALIGN (-5)  /* at least one pair hit a reference abort condition;
+                            see aim_result_t.status                           */
+
+/* ---- algorithm selection (one per reference sub-project) ---------------- */
+#define AIM_ALGO_NW 0  /* NW/DPU-{WRAM,MRAM}   nw_compute      nw.c:109-153   */
+#define AIM_ALGO_SWG 1 /* SWG/DPU-{WRAM,MRAM}  swg_compute     swg.c:121-171  */
+#define AIM_ALGO_WFA 2 /* WFA/DPU-{WRAM,MRAM}  affine_wfa_compute wfa.c:342-379 */
+
+/* ---- flags: the reference's compile-time -D switches, now run time ------ */
+#define AIM_FLAG_BACKTRACE 0x1u /* -DBACKTRACE (run-*-pim-*.py -b)            */
+#define AIM_FLAG_REDUCE 0x2u    /* -DREDUCE = WFA-adaptive (run-wfa-*.py -r)  */
+#define AIM_FLAG_SWG_W16 0x4u   /* force int16 SWG cells (= SWG/DPU-MRAM,
+                                   SWG/DPU-MRAM/common/common.h:91); default is
+                                   the WRAM rule: int8 iff MAX_SCORE < 127
+                                   (SWG/DPU-WRAM/common/common.h:71-75)       */
+
+/* Replaces the -D macro set the launchers pass to make
+ * (WFA/DPU-WRAM/run-wfa-pim-wram.py:128-131; common.h:63-89). */
+typedef struct aim_params {
+    int32_t algo;      /* AIM_ALGO_*                                          */
+    int32_t match;     /* MATCH     (SWG only; NW/WFA ignore it like the ref) */
+    int32_t mismatch;  /* MISMATCH                                            */
+    int32_t gap_o;     /* GAP_O     (SWG, WFA)                                */
+    int32_t gap_e;     /* GAP_E     (SWG, WFA)                                */
+    int32_t gap_i;     /* GAP_I     (NW)                                      */
+    int32_t gap_d;     /* GAP_D     (NW)                                      */
+    int32_t max_score; /* MAX_SCORE (WFA: score cap; SWG: "+infinity" value)  */
+    int32_t read_size; /* READ_SIZE: row stride of patterns/texts, multiple of 8 */
+    uint32_t flags;    /* AIM_FLAG_*                                          */
+} aim_params_t;
+
+/* Per-pair descriptor: byte-compatible with the NW/SWG request_t
+ * (NW/DPU-WRAM/common/common.h:114-120).  The WFA variant of the reference
+ * uses int16 lengths (WFA/DPU-WRAM/common/common.h:172-177); a binding widens
+ * them when filling this struct. */
+typedef struct aim_request {
+    int32_t pattern_len;
+    int32_t text_len;
+    int32_t padding;
+    uint32_t idx; /* global pair index, echoed into the result */
+} aim_request_t;
+
+/* Per-pair result: byte-compatible with the NW/SWG result_t
+ * (NW/DPU-WRAM/common/common.h:122-130); the reference's unused `padding`
+ * word carries the per-pair status. */
+#define AIM_PAIR_OK 0
+#define AIM_PAIR_WFA_NO_LINK 1 /* wfa_backtracing.c:321-325: ref prints + exit(1) */
+#define AIM_PAIR_SWG_NO_OP 2   /* swg.c:99-104: ref prints + exit(1)             */
+#define AIM_PAIR_NOMEM 3       /* dpu_allocator_wram.c:19-23: ref prints + exit(1) */
+typedef struct aim_result {
+    int32_t max_operations; /* plen + tlen                                    */
+    int32_t begin_offset;   /* CIGAR ops live in ops[begin_offset,end_offset) */
+    int32_t end_offset;
+    int32_t score;
+    int32_t status; /* AIM_PAIR_* */
+    uint32_t idx;
+} aim_result_t;
+
+/* ---- library / device discovery ----------------------------------------- */
+int aim_abi_version(void);
+const char *aim_last_error(void);
+/* Number of usable gfx950 devices (0 and AIM_ENODEV when there is none). */
+int aim_device_count(int *count);
+
+/* ---- device set: replaces struct dpu_set_t and the nine SDK calls -------- */
+typedef struct aim_set aim_set_t;
+
+/* dpu_alloc(NR_DPUS, NULL, &set) + dpu_load(set, DPU_BINARY, NULL)
+ * (host.c:186-187).  device_ids may be NULL (= 0..nr_devices-1). */
+int aim_set_alloc(uint32_t nr_devices, const int *device_ids, aim_set_t **set);
+/* dpu_get_nr_dpus (host.c:188) */
+int aim_set_nr_devices(const aim_set_t *set, uint32_t *nr_devices);
+/* The compile-time configuration plus the MRAM plan of host.c:215-241
+ * (mram_heap_alloc of params/requests/results/patterns/texts/operations):
+ * sizes every device-side buffer for up to max_pairs_per_device pairs. */
+int aim_set_configure(aim_set_t *set, const aim_params_t *params, uint32_t max_pairs_per_device);
+/* The four host->device scatters of host.c:246-268 (DPUParams, requests,
+ * patterns, texts) for ONE device of the set.  patterns/texts are
+ * [n_pairs][read_size] byte rows.  Asynchronous when the host buffers come
+ * from aim_host_alloc; the copy is ordered before the next launch. */
+int aim_set_push(aim_set_t *set, uint32_t device, uint32_t n_pairs, const aim_request_t *requests,
+                 const char *patterns, const char *texts);
+/* dpu_launch(set, DPU_SYNCHRONOUS) (host.c:289): runs the alignment kernel on
+ * every device of the set and waits for all of them. */
+int aim_set_launch(aim_set_t *set);
+/* The device->host gathers of host.c:316-326: results[n_pairs] and, with
+ * AIM_FLAG_BACKTRACE, ops[n_pairs][2*read_size] (may be NULL otherwise). */
+int aim_set_pull(aim_set_t *set, uint32_t device, aim_result_t *results, char *ops);
+/* The three phase timers host.c prints ("CPU-DPU", "DPU Kernel", "DPU-CPU",
+ * host.c:270-272, 297-299, 328-330), in milliseconds, accumulated. */
+int aim_set_timers(const aim_set_t *set, float *h2d_ms, float *kernel_ms, float *d2h_ms);
+/* dpu_free (host.c:371) */
+int aim_set_free(aim_set_t *set);
+
+/* Pinned host staging for aim_set_push / aim_set_pull. */
+int aim_host_alloc(void **ptr, size_t bytes);
+int aim_host_free(void *ptr);
+
+/* ---- device-resident entry point ----------------------------------------
+ * One alignment launch over buffers that already live in HBM (same layouts as
+ * above).  Used by the benchmark and by callers that manage device memory
+ * themselves.  hip_stream is a hipStream_t (NULL = default stream); the call
+ * only enqueues work.  d_scratch must hold aim_scratch_bytes() bytes. */
+size_t aim_scratch_bytes(const aim_params_t *params, uint32_t n_pairs);
+int aim_align_device(const aim_params_t *params, uint32_t n_pairs, const aim_request_t *d_requests,
+                     const char *d_patterns, const char *d_texts, aim_result_t *d_results,
+                     char *d_ops, void *d_scratch, size_t scratch_bytes, void *hip_stream);
+/* Name of the kernel aim_align_device would launch for this configuration
+ * (matches the rocprofv3 kernel-trace name prefix). */
+const char *aim_kernel_name(const aim_params_t *params);
+
+/* ---- host-side helpers shared by the CLI and the Python binding ---------- */
+/* MAX_SCORE / READ_SIZE heuristics of the launchers (run-wfa-pim-wram.py:57-68,
+ * run-nw-pim-wram.py:50-57 [gap instead of gap_o+gap_e], run-swg-pim-wram.py:52-62). */
+int aim_launcher_sizes(int32_t algo, int32_t read_length, double error, int32_t mismatch, int32_t gap_o,
+                       int32_t gap_e, int32_t gap, int32_t *max_score, int32_t *read_size);
+/* edit_cigar_print (host.c:69-89): RLE of ops[begin,end) + '\n' into out;
+ * returns bytes written or AIM_EINVAL if cap is too small. */
+int aim_cigar_format(const char *ops, int32_t begin_offset, int32_t end_offset, char *out, int32_t cap);
+/* Seeded synthetic pairs (DESIGN.md "Synthetic data"): pattern = len uniform
+ * ACGT bases; text = pattern after ceil(len*error) sequential uniform
+ * substitute/insert/delete edits.  Pair i depends only on (seed, first_idx+i). */
+int aim_gen_pairs(uint64_t seed, uint64_t first_idx, uint32_t n_pairs, int32_t len, double error,
+                  int32_t read_size, aim_request_t *requests, char *patterns, char *texts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIM_HIP_H */

@@ -1,0 +1,50 @@
+import gzip
+import hashlib
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Native pieces built in-tree (no-op when up to date)."""
+    from aim_amd import build
+    build.build_all()
+    from oracle import oracle
+    oracle.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def sample_bytes():
+    with gzip.open(os.path.join(GOLDEN, "sample-l100-e1-40K.gz"), "rb") as f:
+        data = f.read()
+    digests = json.load(open(os.path.join(GOLDEN, "reference_digests.json")))
+    assert hashlib.md5(data).hexdigest() == digests["input_md5"]
+    return data
+
+
+@pytest.fixture(scope="session")
+def err_bytes():
+    with gzip.open(os.path.join(GOLDEN, "ERR240727-l100-e1-first2000.gz"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def ref_digests():
+    return json.load(open(os.path.join(GOLDEN, "reference_digests.json")))
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()

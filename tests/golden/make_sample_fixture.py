@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Copy the reference's own sample inputs (data files, not source) into tests/golden/.
+
+  sample-l100-e1-40K.gz        <- /root/reference/Datasets/sample-l100-e1-40K (20 000 pairs, whole file,
+                                  because the recorded reference digests are whole-file digests)
+  ERR240727-l100-e1-first2000.gz <- first 2 000 pairs of Datasets/ERR240727-l100-e1-30000Pairs (real reads,
+                                  contains 'N'; no reference digest exists for it, used for HIP-vs-oracle parity)
+
+reference_digests.json holds the md5 digests of the REFERENCE's output on the sample file as recorded in
+SURVEY.md section 8a / BASELINE.md section 2 (produced during the survey by running the reference sources).
+Only runs where /root/reference exists.
+"""
+import gzip, hashlib, json, os
+here = os.path.dirname(os.path.abspath(__file__))
+src = "/root/reference/Datasets/"
+raw = open(src + "sample-l100-e1-40K", "rb").read()
+with gzip.GzipFile(os.path.join(here, "sample-l100-e1-40K.gz"), "wb", compresslevel=9, mtime=0) as f:
+    f.write(raw)
+lines = open(src + "ERR240727-l100-e1-30000Pairs", "rb").read().split(b"\n")[:4000]
+with gzip.GzipFile(os.path.join(here, "ERR240727-l100-e1-first2000.gz"), "wb", compresslevel=9, mtime=0) as f:
+    f.write(b"\n".join(lines) + b"\n")
+digests = {
+    "_provenance": "md5 of the reference host program's output file on Datasets/sample-l100-e1-40K, "
+                   "n=20000, NR_DPUS=1, launcher flags for -l 100 -e 0.01 (MAX_SCORE=5 [NW: 4], READ_SIZE=112); "
+                   "recorded in SURVEY.md 8a and BASELINE.md 2",
+    "input_md5": hashlib.md5(raw).hexdigest(),
+    "wfa_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",
+    "wfa_reduce_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",
+    "swg_w8_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",
+    "swg_w16_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",
+    "nw_backtrace": "1bb055852cd6112bd40d47a54ff5d0b9",
+    "wfa_score_only": "e05231d4719412c109cda6c93e5a8cdb",
+    "score_histogram_wfa_swg": {"0": 1628, "3": 5001, "5": 13371},
+    "score_histogram_nw": {"0": 1628, "3": 5001, "4": 13371},
+}
+json.dump(digests, open(os.path.join(here, "reference_digests.json"), "w"), indent=1)
+print("ok", digests["input_md5"])

@@ -1,0 +1,280 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (aim_set_* via aim_amd.engine.DeviceSet),
+against the CPU oracle on the same inputs -- bit-exact scores, offsets and CIGAR ops -- and against the
+reference digests recorded for Datasets/sample-l100-e1-40K.  Run on the GPU box with `-m gpu`."""
+import collections
+import os
+
+import numpy as np
+import pytest
+
+from conftest import md5
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(built):
+    from aim_amd import capi
+    import ctypes as C
+    lib = capi.load()
+    n = C.c_int()
+    rc = lib.aim_device_count(C.byref(n))
+    assert rc == 0 and n.value >= 1, "no HIP device visible: %s" % lib.aim_last_error()
+    return lib
+
+
+def _oracle_params(oracle, params, algo):
+    from aim_amd import capi
+    bt = bool(params.flags & capi.FLAG_BACKTRACE)
+    red = bool(params.flags & capi.FLAG_REDUCE)
+    cellb = 2 if (params.flags & capi.FLAG_SWG_W16) else 0
+    return oracle.params(algo, params.max_score, params.read_size, match=params.match, mismatch=params.mismatch,
+                         gap_o=params.gap_o, gap_e=params.gap_e, gap=params.gap_i, backtrace=bt, reduce=red,
+                         swg_cell_bytes=cellb)
+
+
+def _compare(algo, params, req, pat, txt, threads=8, expect_status=None, env=None):
+    """Align on the GPU and with the oracle; require bit-identical results (and ops inside [begin,end))."""
+    from aim_amd import capi, engine
+    from oracle import oracle
+    res, ops = engine.align(params, req, pat, txt, check=False)
+    op = _oracle_params(oracle, params, algo)
+    ores, oops, worst = oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=threads)
+    assert np.array_equal(res["idx"], req["idx"])
+    for f in ("score", "max_operations", "end_offset", "status"):
+        bad = np.nonzero(res[f] != ores[f])[0]
+        assert bad.size == 0, "%s differs at pair %d: hip %d oracle %d (plen %d tlen %d)" % (
+            f, bad[0], res[f][bad[0]], ores[f][bad[0]], req["pattern_len"][bad[0]], req["text_len"][bad[0]])
+    if params.flags & capi.FLAG_BACKTRACE:
+        ok = res["status"] == 0
+        bad = np.nonzero((res["begin_offset"] != ores["begin_offset"]) & ok)[0]
+        assert bad.size == 0, "begin_offset differs at pair %d: hip %d oracle %d" % (
+            bad[0], res["begin_offset"][bad[0]], ores["begin_offset"][bad[0]])
+        for i in np.nonzero(ok)[0]:
+            b, e = int(res["begin_offset"][i]), int(res["end_offset"][i])
+            if not np.array_equal(ops[i, b:e], oops[i, b:e]):
+                raise AssertionError("ops differ at pair %d: hip %r oracle %r" % (
+                    i, ops[i, b:e].tobytes(), oops[i, b:e].tobytes()))
+    if expect_status is not None:
+        assert collections.Counter(int(s) for s in res["status"]) == expect_status
+    return res, ops, ores
+
+
+# ------------------------------------------------------------------ reference digests on the sample file
+SAMPLE_CASES = [
+    ("wfa_backtrace", "wfa", 5, dict(backtrace=True)),
+    ("wfa_reduce_backtrace", "wfa", 5, dict(backtrace=True, reduce=True)),
+    ("wfa_score_only", "wfa", 5, dict(reduce=True)),
+    ("nw_backtrace", "nw", 4, dict(backtrace=True)),
+    ("swg_w8_backtrace", "swg", 5, dict(backtrace=True)),
+    ("swg_w16_backtrace", "swg", 5, dict(backtrace=True, swg_w16=True)),
+]
+
+
+@pytest.mark.parametrize("key,algo,ms,kw", SAMPLE_CASES)
+def test_sample_file_matches_reference_digest(gpu, sample_bytes, ref_digests, key, algo, ms, kw):
+    from aim_amd import engine
+    req, pat, txt = engine.parse_pairs(sample_bytes, 112)
+    params = engine.make_params(algo, ms, 112, **kw)
+    res, ops = engine.align(params, req, pat, txt)
+    out = engine.format_output(res, ops, kw.get("backtrace", False))
+    assert md5(out) == ref_digests[key]
+
+
+def test_sample_file_wave_kernel_too(gpu, sample_bytes, ref_digests, monkeypatch):
+    """The general one-pair-per-wavefront WFA kernel must give the same file (fast path disabled)."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_FORCE_WAVE", "1")
+    req, pat, txt = engine.parse_pairs(sample_bytes, 112)
+    for key, kw in (("wfa_reduce_backtrace", dict(backtrace=True, reduce=True)), ("wfa_score_only", dict(reduce=True))):
+        params = engine.make_params("wfa", 5, 112, **kw)
+        res, ops = engine.align(params, req, pat, txt)
+        assert md5(engine.format_output(res, ops, kw.get("backtrace", False))) == ref_digests[key]
+
+
+def test_real_reads_with_N(gpu, err_bytes):
+    from aim_amd import engine
+    req, pat, txt = engine.parse_pairs(err_bytes, 112)
+    assert len(req) == 2000
+    for algo, ms, kw in (("wfa", 5, dict(backtrace=True, reduce=True)), ("wfa", 5, dict()), ("nw", 4, dict(backtrace=True)),
+                         ("swg", 5, dict(backtrace=True))):
+        _compare(algo, engine.make_params(algo, ms, 112, **kw), req, pat, txt)
+
+
+# ------------------------------------------------------------------ synthetic strata
+@pytest.mark.parametrize("err", [0.01, 0.02, 0.05, 0.10])
+@pytest.mark.parametrize("algo,kw", [("wfa", dict()), ("wfa", dict(backtrace=True)), ("wfa", dict(backtrace=True, reduce=True)),
+                                     ("nw", dict(backtrace=True)), ("swg", dict(backtrace=True)),
+                                     ("swg", dict(backtrace=True, swg_w16=True)), ("swg", dict())])
+def test_synthetic_l100(gpu, algo, kw, err):
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes(algo, 100, err)
+    req, pat, txt = engine.gen_pairs(1234 + int(err * 100), 0, 3000, 100, err, rs)
+    strata = collections.Counter(np.sign(req["pattern_len"] - req["text_len"]).tolist())
+    assert len(strata) == 3   # plen > tlen (flat-index aliasing N1/S1), plen < tlen, plen == tlen all present
+    _compare(algo, engine.make_params(algo, ms, rs, **kw), req, pat, txt)
+
+
+@pytest.mark.parametrize("force_wave", ["0", "1"])
+def test_wfa_custom_penalties_and_overflow(gpu, force_wave, monkeypatch):
+    """Non-default costs; MAX_SCORE deliberately too small so that the score cap (W3) triggers."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_FORCE_WAVE", force_wave)
+    for (x, o, e), err, ms_override in (((4, 6, 2), 0.05, None), ((2, 3, 1), 0.05, None), ((5, 4, 2), 0.03, None),
+                                        ((3, 4, 1), 0.05, 7), ((1, 1, 1), 0.04, None)):
+        ms, rs = engine.launcher_sizes("wfa", 100, err, mismatch=x, gap_o=o, gap_e=e)
+        if ms_override is not None:
+            ms = ms_override
+        req, pat, txt = engine.gen_pairs(99, 0, 1500, 100, err, rs)
+        for kw in (dict(), dict(backtrace=True, reduce=True)):
+            p = engine.make_params("wfa", ms, rs, mismatch=x, gap_o=o, gap_e=e, **kw)
+            res, _, _ = _compare("wfa", p, req, pat, txt)
+            if ms_override is not None:
+                assert (res["score"] == ms + 1).any()
+
+
+def test_wfa_adaptive_l1000_e5_backtrace(gpu):
+    """BASELINE config 3 shape (MAX_SCORE 250, READ_SIZE 1064): reduce fires (width >= 10)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("wfa", 1000, 0.05)
+    assert (ms, rs) == (250, 1064)
+    req, pat, txt = engine.gen_pairs(7, 0, 600, 1000, 0.05, rs)
+    r1, _, _ = _compare("wfa", engine.make_params("wfa", ms, rs, backtrace=True, reduce=True), req, pat, txt)
+    r2, _, _ = _compare("wfa", engine.make_params("wfa", ms, rs, backtrace=True), req, pat, txt)
+    _compare("wfa", engine.make_params("wfa", ms, rs, reduce=True), req, pat, txt)
+    assert r1["score"].mean() > 100
+
+
+def test_nw_swg_l250(gpu):
+    from aim_amd import engine
+    for algo in ("nw", "swg"):
+        ms, rs = engine.launcher_sizes(algo, 250, 0.05)
+        req, pat, txt = engine.gen_pairs(5, 0, 400, 250, 0.05, rs)
+        _compare(algo, engine.make_params(algo, ms, rs, backtrace=True), req, pat, txt)
+
+
+def test_swg_int8_wrap(gpu):
+    """l=150 e=3%: MAX_SCORE 23 < 127 -> int8 cells whose boundary values (4+v) wrap past 127 (S3)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("swg", 150, 0.03)
+    assert ms < 127
+    req, pat, txt = engine.gen_pairs(11, 0, 500, 150, 0.03, rs)
+    _compare("swg", engine.make_params("swg", ms, rs), req, pat, txt)
+    _compare("swg", engine.make_params("swg", ms, rs, backtrace=True), req, pat, txt)
+
+
+# ------------------------------------------------------------------ edge cases
+def _mk(pairs, rs):
+    from aim_amd import capi
+    n = len(pairs)
+    req = np.zeros(n, dtype=capi.REQUEST_DTYPE)
+    pat = np.zeros((n, rs), dtype=np.uint8)
+    txt = np.zeros((n, rs), dtype=np.uint8)
+    for i, (p, t) in enumerate(pairs):
+        pat[i, : len(p)] = np.frombuffer(p, dtype=np.uint8)
+        txt[i, : len(t)] = np.frombuffer(t, dtype=np.uint8)
+        req[i] = (len(p), len(t), 0, 1000 + i)
+    return req, pat, txt
+
+
+EDGE_PAIRS = [
+    (b"", b""), (b"A", b"A"), (b"A", b"C"), (b"", b"ACGT"), (b"ACGT", b""), (b"ACGTACGT", b"ACGTACGT"),
+    (b"ACGTACGTAC", b"ACGTTCGTAC"), (b"AAAAAAAAAA", b"AAAAAAAAAAAA"), (b"AAAAAAAAAAAA", b"AAAAAAAAAA"),
+    (b"ACGTNNNNACGT", b"ACGTNNNACGT"), (b"acgtacgt", b"ACGTACGT"), (b"GATTACA" * 16, b"GATTACA" * 16),
+    (b"GATTACA" * 16, b"GATTACA" * 8 + b"T" + b"GATTACA" * 8), (b"A" * 112, b"A" * 112), (b"A" * 112, b"C" * 112),
+    (b"ACGT" * 28, b"TGCA" * 28), (b"A" * 100, b"A" * 50),
+]
+
+
+@pytest.mark.parametrize("algo,ms,kw", [("wfa", 5, dict()), ("wfa", 5, dict(backtrace=True, reduce=True)),
+                                        ("wfa", 40, dict(backtrace=True)), ("nw", 4, dict(backtrace=True)),
+                                        ("swg", 5, dict(backtrace=True)), ("swg", 200, dict(backtrace=True)),
+                                        ("nw", 4, dict())])
+def test_edge_cases(gpu, algo, ms, kw):
+    from aim_amd import engine
+    req, pat, txt = _mk(EDGE_PAIRS, 112)
+    _compare(algo, engine.make_params(algo, ms, 112, **kw), req, pat, txt, threads=1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_ragged_batch_sizes(gpu, n):
+    from aim_amd import engine
+    req, pat, txt = engine.gen_pairs(3, 17, n, 100, 0.02, 112)
+    for algo, ms, kw in (("wfa", 10, dict()), ("wfa", 10, dict(backtrace=True)), ("nw", 8, dict(backtrace=True))):
+        _compare(algo, engine.make_params(algo, ms, 112, **kw), req, pat, txt, threads=1)
+
+
+def test_empty_batch_and_errors(gpu):
+    from aim_amd import capi, engine
+    req, pat, txt = engine.gen_pairs(3, 0, 0, 100, 0.02, 112)
+    with engine.DeviceSet(1) as s:
+        s.configure(engine.make_params("wfa", 5, 112), 16)
+        s.push(0, req, pat, txt)
+        s.launch()
+        res, ops = s.pull(0)
+        assert len(res) == 0
+        with pytest.raises(capi.AimError):
+            s.configure(engine.make_params("wfa", 5, 110), 16)     # read_size not a multiple of 8
+        with pytest.raises(capi.AimError):
+            s.configure(engine.make_params("wfa", 5, 112, mismatch=0), 16)
+        r2, p2, t2 = engine.gen_pairs(3, 0, 8, 100, 0.02, 112)
+        r2["pattern_len"][3] = 113                                  # longer than READ_SIZE (host.c:119-123)
+        s.configure(engine.make_params("wfa", 5, 112), 16)
+        with pytest.raises(capi.AimError):
+            s.push(0, r2, p2, t2)
+
+
+# ------------------------------------------------------------------ full BASELINE size (cfg2) + properties
+def test_cfg2_full_size_4M_pairs(gpu):
+    """WFA score-only l=100 e=1% on 4M synthetic pairs: bit-exact against the oracle over the whole batch,
+    plus the size-independent properties (score alphabet, identical pairs score 0, order/idx preserved)."""
+    from aim_amd import engine
+    from oracle import oracle
+    n = 1 << 22
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.01)
+    req, pat, txt = engine.gen_pairs(42, 0, n, 100, 0.01, rs)
+    params = engine.make_params("wfa", ms, rs, reduce=True)
+    res, _ = engine.align(params, req, pat, txt)
+    assert np.array_equal(res["idx"], np.arange(n, dtype=np.uint32))
+    assert set(np.unique(res["score"]).tolist()) <= {0, 3, 5, 6}
+    same = (req["pattern_len"] == req["text_len"]) & (pat == txt).all(axis=1)
+    assert (res["score"][same] == 0).all() and same.sum() > 0
+    op = oracle.params("wfa", ms, rs, reduce=True)
+    ores, _, worst = oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=os.cpu_count() or 8)
+    assert worst == 0
+    assert np.array_equal(res["score"], ores["score"])
+    # checksum of checksums: order-sensitive digest of (idx, score)
+    assert md5(res["score"].tobytes()) == md5(ores["score"].tobytes())
+
+
+def test_multi_device_split_matches_single(gpu):
+    """Static contiguous split over the devices of a set (host.c:191-209) returns the same results in input order.
+    With one physical GPU the set is built from the same device twice."""
+    from aim_amd import engine
+    req, pat, txt = engine.gen_pairs(8, 0, 5001, 100, 0.02, 112)
+    params = engine.make_params("wfa", 10, 112, backtrace=True)
+    a_res, a_ops = engine.align(params, req, pat, txt)
+    with engine.DeviceSet(device_ids=[0, 0, 0]) as s:
+        b_res, b_ops = s.align(params, req, pat, txt)
+    assert np.array_equal(a_res, b_res)
+    for i in range(len(req)):
+        b, e = int(a_res["begin_offset"][i]), int(a_res["end_offset"][i])
+        assert np.array_equal(a_ops[i, b:e], b_ops[i, b:e])
+
+
+def test_host_cli_end_to_end(gpu, sample_bytes, ref_digests, tmp_path):
+    """The C host program keeps the reference CLI/output: whole-file digests through `python -m aim_amd.launch`."""
+    import subprocess
+    import sys
+    inp = tmp_path / "sample"
+    inp.write_bytes(sample_bytes)
+    for algo, flags, key in (("wfa", ["-b", "-r"], "wfa_reduce_backtrace"), ("wfa", ["-r"], "wfa_score_only"),
+                             ("nw", ["-b"], "nw_backtrace"), ("swg", ["-b"], "swg_w8_backtrace")):
+        out = tmp_path / ("out_" + key)
+        r = subprocess.run([sys.executable, "-m", "aim_amd.launch", algo, "-i", str(inp), "-o", str(out), "-l", "100",
+                            "-e", "0.01", "-n", "20000", "-d", "4"] + flags, capture_output=True, text=True,
+                           cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(__file__))))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert md5(out.read_bytes()) == ref_digests[key]
+        for line in ("Allocated 4 DPU(s)", "NumReads per dpu = 5000", "DPU Kernel:", "CPU-DPU:", "DPU-CPU:"):
+            assert line in r.stdout

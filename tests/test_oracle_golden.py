@@ -1,0 +1,77 @@
+"""The CPU oracle against everything the reference left us for this path: the recorded output
+digests and score histograms on Datasets/sample-l100-e1-40K (SURVEY.md 8a / BASELINE.md 2)."""
+import collections
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, md5
+
+
+def _run(oracle_mod, engine, data, algo, max_score, backtrace, reduce=False, swg_cell_bytes=0, threads=4):
+    req, pat, txt = engine.parse_pairs(data, 112)
+    p = oracle_mod.params(algo, max_score, 112, backtrace=backtrace, reduce=reduce, swg_cell_bytes=swg_cell_bytes)
+    res, ops, worst = oracle_mod.align_batch(p, req["pattern_len"], req["text_len"], pat, txt, nthreads=threads)
+    assert worst == 0
+    return res, ops
+
+
+CASES = [
+    ("wfa_backtrace", "wfa", 5, True, False, 0),
+    ("wfa_reduce_backtrace", "wfa", 5, True, True, 0),
+    ("wfa_score_only", "wfa", 5, False, True, 0),
+    ("nw_backtrace", "nw", 4, True, False, 0),
+    ("swg_w8_backtrace", "swg", 5, True, False, 1),
+    ("swg_w16_backtrace", "swg", 5, True, False, 2),
+]
+
+
+@pytest.mark.parametrize("key,algo,ms,bt,red,cellb", CASES)
+def test_oracle_reproduces_reference_digest(built, sample_bytes, ref_digests, key, algo, ms, bt, red, cellb):
+    from aim_amd import engine
+    from oracle import oracle
+    res, ops = _run(oracle, engine, sample_bytes, algo, ms, bt, red, cellb)
+    assert len(res) == 20000
+    out = oracle.format_output(res, ops, bt)
+    assert md5(out) == ref_digests[key]
+
+
+def test_oracle_score_histograms(built, sample_bytes, ref_digests):
+    from aim_amd import engine
+    from oracle import oracle
+    for algo, ms, key in (("wfa", 5, "score_histogram_wfa_swg"), ("swg", 5, "score_histogram_wfa_swg"),
+                          ("nw", 4, "score_histogram_nw")):
+        res, _ = _run(oracle, engine, sample_bytes, algo, ms, False)
+        hist = collections.Counter(int(s) for s in res["score"])
+        assert {str(k): v for k, v in hist.items()} == ref_digests[key]
+
+
+def test_oracle_cli_file_digest(built, sample_bytes, ref_digests, tmp_path):
+    """Whole-program check incl. the restated parser / partition rule / writer (host.c:91-134,191,331-352)."""
+    inp = tmp_path / "sample"
+    inp.write_bytes(sample_bytes)
+    cli = os.path.join(ROOT, "oracle", "oracle_cli")
+    for algo, flags, key in (("wfa", ["-b", "-r"], "wfa_reduce_backtrace"), ("nw", ["-b"], "nw_backtrace"),
+                             ("wfa", ["-r"], "wfa_score_only")):
+        out = tmp_path / ("out_" + key)
+        subprocess.check_call([cli, algo, "-i", str(inp), "-o", str(out), "-n", "20000", "-l", "100", "-e", "0.01",
+                               "-d", "4", "-t", "4"] + flags)
+        assert md5(out.read_bytes()) == ref_digests[key]
+    # H3: n is not a cap -- n=100, NR_DPUS=4 -> ROUND_UP_8(25)*4 = 128 pairs
+    out = tmp_path / "out_n100"
+    subprocess.check_call([cli, "wfa", "-i", str(inp), "-o", str(out), "-n", "100", "-l", "100", "-e", "0.01", "-d", "4"])
+    assert out.read_bytes().count(b"\n") == 128
+    # H4: n <= NR_DPUS exits 1
+    assert subprocess.call([cli, "wfa", "-i", str(inp), "-o", str(out), "-n", "4", "-l", "100", "-e", "0.01", "-d", "4"],
+                           stdout=subprocess.DEVNULL) == 1
+
+
+def test_wfa_wram_equals_mram_style_variants(built, sample_bytes):
+    """REDUCE is inert at l=100 (width < 10) and score-only scores equal the backtrace run's scores."""
+    from aim_amd import engine
+    from oracle import oracle
+    a, _ = _run(oracle, engine, sample_bytes, "wfa", 5, True, False)
+    b, _ = _run(oracle, engine, sample_bytes, "wfa", 5, False, True)
+    assert np.array_equal(a["score"], b["score"])
