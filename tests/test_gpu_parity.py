@@ -181,7 +181,7 @@ EDGE_PAIRS = [
     (b"", b""), (b"A", b"A"), (b"A", b"C"), (b"", b"ACGT"), (b"ACGT", b""), (b"ACGTACGT", b"ACGTACGT"),
     (b"ACGTACGTAC", b"ACGTTCGTAC"), (b"AAAAAAAAAA", b"AAAAAAAAAAAA"), (b"AAAAAAAAAAAA", b"AAAAAAAAAA"),
     (b"ACGTNNNNACGT", b"ACGTNNNACGT"), (b"acgtacgt", b"ACGTACGT"), (b"GATTACA" * 16, b"GATTACA" * 16),
-    (b"GATTACA" * 16, b"GATTACA" * 8 + b"T" + b"GATTACA" * 8), (b"A" * 112, b"A" * 112), (b"A" * 112, b"C" * 112),
+    (b"GATTACA" * 15, b"GATTACA" * 7 + b"T" + b"GATTACA" * 8), (b"A" * 112, b"A" * 112), (b"A" * 112, b"C" * 112),
     (b"ACGT" * 28, b"TGCA" * 28), (b"A" * 100, b"A" * 50),
 ]
 
