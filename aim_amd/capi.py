@@ -45,6 +45,7 @@ SYMBOLS = {
     "aim_set_launch": (C.c_int, [_VP]),
     "aim_set_pull": (C.c_int, [_VP, _U32, _VP, _VP]),
     "aim_set_timers": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "aim_set_fallback_pairs": (C.c_int, [_VP, _U32, C.POINTER(_U32)]),
     "aim_set_free": (C.c_int, [_VP]),
     "aim_host_alloc": (C.c_int, [C.POINTER(_VP), C.c_size_t]),
     "aim_host_free": (C.c_int, [_VP]),

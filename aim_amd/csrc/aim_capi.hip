@@ -56,6 +56,10 @@ struct Plan {
     uint32_t pool_cap, meta_cap;
     bool seq_lds;
     size_t scratch_total;
+    size_t todo_bytes;      // K_WFA_LANE: to-do region in front of the fallback kernel's scratch
+    uint32_t fb_grid;       // K_WFA_LANE: grid / LDS of the fallback (general) kernel
+    size_t fb_lds;
+    bool no_lane;
 };
 
 uint64_t scratch_budget_bytes()
@@ -94,18 +98,26 @@ bool force_wave_kernel()
     return e && e[0] == '1';
 }
 
-int make_plan(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
+int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
 {
-    int rc = validate_params(p);
-    if (rc) return rc;
-    memset(pl, 0, sizeof *pl);
+    int rc = AIM_OK;
     const uint64_t budget = scratch_budget_bytes();
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     if (p.algo == AIM_ALGO_WFA) {
-        if (!force_wave_kernel() && aim::wfa_lane_supported(p)) {
+        if (!force_wave_kernel() && !pl->no_lane && aim::wfa_lane_supported(p)) {
+            // fast path + the general kernel in to-do mode behind it (its plan goes into *pl first)
+            Plan fb;
+            memset(&fb, 0, sizeof fb);
+            fb.no_lane = true;
+            rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), &fb);
+            if (rc) return rc;
+            *pl = fb;
             pl->kid = K_WFA_LANE;
+            pl->fb_grid = fb.grid;
+            pl->fb_lds = fb.lds;
             aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
-            pl->scratch_total = 256;
+            pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
+            pl->scratch_total = pl->todo_bytes + fb.scratch_total;
             return AIM_OK;
         }
         pl->kid = K_WFA_WAVE;
@@ -150,6 +162,14 @@ int make_plan(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
                : fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
 }
 
+int make_plan(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
+{
+    int rc = validate_params(p);
+    if (rc) return rc;
+    memset(pl, 0, sizeof *pl);
+    return make_plan_inner(p, n_pairs, pl);
+}
+
 template <bool BT, bool RED>
 void launch_wfa_wave(const Plan &pl, const aim::KArgs &ka, hipStream_t s)
 {
@@ -185,6 +205,7 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
     ka.scratch_per_wave = pl.scratch_per_wg;
     ka.pool_cap = pl.pool_cap;
     ka.meta_cap = pl.meta_cap;
+    ka.todo = nullptr;
     switch (pl.kid) {
     case K_WFA_WAVE:
         if (bt && red) launch_wfa_wave<true, true>(pl, ka, stream);
@@ -192,9 +213,21 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         else if (red) launch_wfa_wave<false, true>(pl, ka, stream);
         else launch_wfa_wave<false, false>(pl, ka, stream);
         break;
-    case K_WFA_LANE:
+    case K_WFA_LANE: {
+        // [to-do region | general kernel scratch]: count zeroed per launch, lane kernel, then the drain
+        HIP_TRY(hipMemsetAsync(d_scratch, 0, 64, stream));
         aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
+        HIP_TRY(hipGetLastError());
+        aim::KArgs kb = ka;
+        kb.todo = reinterpret_cast<const uint32_t *>(d_scratch);
+        kb.scratch = (char *)d_scratch + pl.todo_bytes;
+        Plan fb = pl;
+        fb.grid = pl.fb_grid;
+        fb.lds = pl.fb_lds;
+        if (red) launch_wfa_wave<false, true>(fb, kb, stream);
+        else launch_wfa_wave<false, false>(fb, kb, stream);
         break;
+    }
     case K_DP_LANE:
         aim::dp_lane_launch(p, pl.grid, pl.lds, pl.seq_lds, ka, stream);
         break;
@@ -414,6 +447,21 @@ int aim_set_timers(const aim_set_t *set, float *h2d_ms, float *kernel_ms, float 
     if (h2d_ms) *h2d_ms = set->h2d_ms;
     if (kernel_ms) *kernel_ms = set->kernel_ms;
     if (d2h_ms) *d2h_ms = set->d2h_ms;
+    return AIM_OK;
+}
+
+int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback)
+{
+    if (!set || device >= set->devs.size() || !n_fallback) return fail(AIM_EINVAL, "bad arguments");
+    aim_device_ctx &d = set->devs[device];
+    if (!d.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
+    *n_fallback = 0;
+    Plan pl;
+    int rc = make_plan(set->params, set->max_pairs, &pl);
+    if (rc) return rc;
+    if (pl.kid != K_WFA_LANE || d.n_pairs == 0) return AIM_OK;
+    HIP_TRY(hipSetDevice(d.dev));
+    HIP_TRY(hipMemcpy(n_fallback, d.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return AIM_OK;
 }
 

@@ -24,6 +24,7 @@ struct KArgs {
     uint64_t scratch_per_wave;  // bytes
     uint32_t pool_cap;    // int16 entries per wave (WFA)
     uint32_t meta_cap;    // WfMeta entries per wave (WFA)
+    const uint32_t *todo; // nullptr: units are pairs 0..n_pairs-1; else {count @0, pair ids @16..} written by wfa_lane
 };
 
 // XCD-aware work distribution: workgroups are dealt round-robin over the 8 XCDs

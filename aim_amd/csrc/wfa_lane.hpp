@@ -1,16 +1,325 @@
-// wfa_lane.hpp -- short-read WFA fast path (one pair per lane).  Placeholder until the
-// kernel lands: nothing is routed here yet.
+// wfa_lane.hpp -- short-read WFA / WFA-adaptive fast path: ONE PAIR PER LANE, 64 pairs per wavefront,
+// everything after staging in registers.
+//
+// Same results as affine_wfa_compute (WFA/DPU-WRAM/dpu/wfa.c:342-379) for configurations whose
+// wavefront structure is known at compile time: penalties (X, O, E) and a score cap MAXS are template
+// parameters, so which scores have a wavefront, their [lo, hi] ranges and which of them carry I/D
+// components (affine_wfa_compute_next, wfa.c:268-340) are constants; only the offsets are data.
+// WFA-adaptive's reduction (wfa.c:69-140) needs a wavefront of >= 10 diagonals, which these shapes
+// never reach (checked at compile time), so -DREDUCE is inert exactly as in the reference.
+//
+// Data path per wavefront of 64 pairs:
+//   HBM --(LDS-DMA, 1 KiB per wave-instruction, no VGPRs; the next group's DMA is issued as soon as the
+//   image is consumed and flies under the compute)--> linear LDS image --> each lane reads ITS row with
+//   ds_read_b128 at compile-time offsets (row = odd number of 16-B slots: conflict-free), validates the
+//   alphabet and packs 2 bits/base with v_dot4: pattern and text become RS/16 dwords each in VGPRs.
+//   affine_wfa_extend (wfa.c:186-208) becomes bit-parallel: for diagonal k, D_k = P xor (T shifted by k
+//   bases) is a mismatch bit-vector; extending from pattern position v is "first set bit at or after v",
+//   clamped to min(plen, tlen - k).  No loop, no divergence, no memory access.
+// Pairs containing anything but A/C/G/T (the reference compares raw bytes, host.c:126-127) cannot be
+// packed; they are appended to a to-do list that the general kernel (wfa_wave.hpp) drains right after.
 #pragma once
 
 #include "aim_device.hpp"
 
 namespace aim {
 
-inline bool wfa_lane_supported(const aim_params_t &) { return false; }
-inline void wfa_lane_plan(const aim_params_t &, uint32_t, uint32_t *grid, uint32_t *block, size_t *lds)
+constexpr int kLaneNull = -16384;   // AFFINE_WAVEFRONT_OFFSET_NULL (common.h:100)
+
+// Compile-time wavefront structure (affine_wfa_compute_next bounds logic, wfa.c:272-335, without
+// reduction; klo/khi == lo/hi).
+template <int X, int O, int E, int MAXS>
+struct WfShape {
+    bool present[MAXS + 1];
+    bool hasI[MAXS + 1];
+    bool hasD[MAXS + 1];
+    int lo[MAXS + 1];
+    int hi[MAXS + 1];
+    int kmin, kmax, maxw;
+    constexpr WfShape() : present{}, hasI{}, hasD{}, lo{}, hi{}, kmin(0), kmax(0), maxw(1)
+    {
+        present[0] = true;
+        for (int s = 1; s <= MAXS; ++s) {
+            const int ss = s - X, so = s - O - E, se = s - E;
+            const bool m_sub_null = ss < 0 || !present[ss];
+            const bool m_o_null = so < 0 || !present[so];
+            const bool i_e_null = se < 0 || !present[se] || !hasI[se];
+            const bool d_e_null = se < 0 || !present[se] || !hasD[se];
+            const bool i_out_null = m_o_null && i_e_null;
+            const bool d_out_null = m_o_null && d_e_null;
+            if (m_sub_null && i_out_null && d_out_null) continue;
+            const int sub_lo = m_sub_null ? 1 : lo[ss], sub_hi = m_sub_null ? -1 : hi[ss];
+            const int o_lo = m_o_null ? 1 : lo[so], o_hi = m_o_null ? -1 : hi[so];
+            const bool e_none = i_e_null && d_e_null;
+            const int e_lo = e_none ? 1 : lo[se], e_hi = e_none ? -1 : hi[se];
+            int l = sub_lo < o_lo ? sub_lo : o_lo;
+            l = (l < e_lo ? l : e_lo) - 1;
+            int h = sub_hi > o_hi ? sub_hi : o_hi;
+            h = (h > e_hi ? h : e_hi) + 1;
+            present[s] = true;
+            hasI[s] = !i_out_null;
+            hasD[s] = !d_out_null;
+            lo[s] = l;
+            hi[s] = h;
+            if (l < kmin) kmin = l;
+            if (h > kmax) kmax = h;
+            if (h - l + 1 > maxw) maxw = h - l + 1;
+        }
+    }
+};
+
+// first set flag at or after pattern position v in a 2-bit-per-base flag vector (flags on even bits)
+template <int NP>
+__device__ __forceinline__ int first_stop(const uint32_t (&m)[NP], int v)
 {
-    *grid = 8; *block = kWave; *lds = 0;
+    const int wi = v >> 4;
+    const uint32_t lowmask = ~0u << ((v & 15) * 2);
+    int res = NP * 16;
+#pragma unroll
+    for (int j = NP - 1; j >= 0; --j) {
+        uint32_t mj = m[j];
+        mj = (j == wi) ? (mj & lowmask) : mj;
+        mj = (j < wi) ? 0u : mj;
+        const int pos = j * 16 + (__builtin_ctz(mj | 0x80000000u) >> 1);
+        res = mj ? pos : res;
+    }
+    return res;
 }
-inline void wfa_lane_launch(const aim_params_t &, uint32_t, uint32_t, size_t, const KArgs &, hipStream_t) {}
+
+// One 64-pair group of one sequence array, HBM -> LDS, by LDS-DMA (global_load_lds_dwordx4): the group's
+// rows are contiguous in HBM ([64][RS] bytes), so NCH wave-instructions of 1 KiB copy them verbatim; no
+// VGPR is used and the copy stays in flight while the wave computes.  Lanes past the batch tail are masked.
+template <int RS, int NCH>
+__device__ __forceinline__ void dma_rows(uint32_t *lds_rows, const char *base, uint32_t pair0, uint32_t n_pairs, int lane)
+{
+    const char *g = base + (uint64_t)pair0 * RS;
+    const uint32_t rows = min((uint32_t)kWave, n_pairs - pair0);
+    const uint32_t n_chunks = (rows * RS + 15) / 16;   // arrays carry >= 16 B of tail slack (aim_hip.h)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const uint32_t c = i * kWave + lane;
+        if (c < n_chunks)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (uint64_t)c * 16),
+                                             (__attribute__((address_space(3))) void *)(lds_rows + i * kWave * 4), 16, 0, 0);
+    }
+}
+
+// Read this lane's row (16 B at a time, compile-time offsets; RS/16 odd => ds_read_b128 is conflict-free),
+// validate A/C/G/T over [0, len) and pack 2 bits/base: 16 bases -> one dword.
+template <int RS, int NP>
+__device__ __forceinline__ uint32_t pack_row(const uint32_t *lds_rows, int lane, int len, int min_len_wave, uint32_t (&out)[NP])
+{
+    uint32_t bad = 0;
+    const uint4 *row = reinterpret_cast<const uint4 *>(lds_rows + lane * (RS / 4));
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const uint4 q = row[j];
+        const uint32_t a[4] = {q.x, q.y, q.z, q.w};
+        uint32_t b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t t = (a[i] >> 1) & 0x03030303u;                    // 2-bit code per byte: A0 C1 T2 G3
+            const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);  // decode back: "ACTG"[code]
+            uint32_t diff = rec ^ a[i];
+            const int w = 4 * j + i;
+            if (4 * w + 4 > min_len_wave) {   // wave-uniform: only tail dwords need the per-lane length mask
+                const int rem = len - 4 * w;
+                const uint32_t mask = rem >= 4 ? ~0u : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+                diff &= mask;
+            }
+            bad |= diff;
+            b[i] = __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);       // c0 + 4 c1 + 16 c2 + 64 c3
+        }
+        out[j] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    }
+    return bad;
+}
+
+enum : uint32_t { LANE_TODO_COUNT = 0, LANE_TODO_LIST = 16 };   // dword offsets inside the to-do region
+
+template <int X, int O, int E, int MAXS, int RS>
+__global__ __launch_bounds__(64) void wfa_lane_kernel(KArgs a)
+{
+    constexpr WfShape<X, O, E, MAXS> SH{};
+    static_assert(SH.maxw < 10, "WFA-adaptive reduction could fire: shape not eligible for the static kernel");
+    static_assert(RS % 16 == 0 && (RS / 16) % 2 == 1, "row stride must be an odd number of 16-B slots");
+    constexpr int NCH = RS / 16;                // 1-KiB DMA pieces per array per group (64 rows * RS / 1024)
+    constexpr int NP = RS / 16;                 // packed dwords per sequence
+    constexpr int KW = SH.kmax - SH.kmin + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *rowsT = rowsP + kWave * (RS / 4);
+    const int lane = threadIdx.x;
+    const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
+    uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
+    const int ms_run = a.p.max_score;           // runtime MAX_SCORE <= MAXS
+
+    uint32_t grp;
+    bool have = xcd_unit(n_groups, 0, &grp);
+    aim_request_t rq_next;
+    rq_next.pattern_len = 0; rq_next.text_len = 0; rq_next.padding = 0; rq_next.idx = 0;
+    if (have) {
+        dma_rows<RS, NCH>(rowsP, a.patterns, grp * kWave, a.n_pairs, lane);
+        dma_rows<RS, NCH>(rowsT, a.texts, grp * kWave, a.n_pairs, lane);
+        if (grp * kWave + lane < a.n_pairs) rq_next = a.req[grp * kWave + lane];
+    }
+    for (uint32_t it = 0; have; ++it) {
+        const uint32_t pair = grp * kWave + lane;
+        const bool active = pair < a.n_pairs;
+        __builtin_amdgcn_s_waitcnt(0);          // this group's DMA has landed (and rq_next arrived)
+        __syncthreads();
+        const aim_request_t rq = rq_next;
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const int minlen = active ? min(plen, tlen) : 0x7fffffff;
+        const int min_len_wave = __builtin_amdgcn_readfirstlane(wave_min_i32(minlen));
+        uint32_t P[NP], T[NP];
+        uint32_t bad = pack_row<RS, NP>(rowsP, lane, plen, min_len_wave, P);
+        bad |= pack_row<RS, NP>(rowsT, lane, tlen, min_len_wave, T);
+
+        // the LDS image is consumed: start the next group's DMA into the same buffer, under the compute
+        uint32_t ngrp = 0;
+        const bool nhave = xcd_unit(n_groups, it + 1, &ngrp);
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): every ds_read of this group has returned
+        __syncthreads();
+        if (nhave) {
+            dma_rows<RS, NCH>(rowsP, a.patterns, ngrp * kWave, a.n_pairs, lane);
+            dma_rows<RS, NCH>(rowsT, a.texts, ngrp * kWave, a.n_pairs, lane);
+            if (ngrp * kWave + lane < a.n_pairs) rq_next = a.req[ngrp * kWave + lane];
+        }
+
+        // ---- mismatch bit-vectors per diagonal: bit pair v of dk[k] != 0  <=>  P[v] != T[v + k] ----
+        uint32_t dk[KW][NP];
+#pragma unroll
+        for (int kk = 0; kk < KW; ++kk) {
+            const int k = SH.kmin + kk;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                uint32_t ts;
+                if (k == 0) ts = T[j];
+                else if (k > 0) ts = __builtin_amdgcn_alignbit(j + 1 < NP ? T[j + 1] : 0u, T[j], 2 * k);
+                else ts = __builtin_amdgcn_alignbit(T[j], j > 0 ? T[j - 1] : 0u, 32 + 2 * k);
+                dk[kk][j] = P[j] ^ ts;
+            }
+        }
+        const int ak = tlen - plen;   // alignment_k
+
+        // ---- affine_wfa_compute, statically unrolled over scores and diagonals -----------------
+        int Mv[MAXS + 1][KW], Iv[MAXS + 1][KW], Dv[MAXS + 1][KW];
+        int score = MAXS + 1;
+        bool done = false;
+#pragma unroll
+        for (int s = 0; s <= MAXS; ++s) {
+            if (!SH.present[s]) continue;
+            if (s > 0) {
+                const int ss = s - X, so = s - O - E, se = s - E;
+                const bool sub_ok = ss >= 0 && SH.present[ss];
+                const bool o_ok = so >= 0 && SH.present[so];
+                const bool ie_ok = se >= 0 && SH.present[se] && SH.hasI[se];
+                const bool de_ok = se >= 0 && SH.present[se] && SH.hasD[se];
+#pragma unroll
+                for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {   // affine_wfa_compute_offsets, wfa.c:231-266
+                    const int kk = k - SH.kmin;
+                    const int km1 = kk > 0 ? kk - 1 : 0, kp1 = kk + 1 < KW ? kk + 1 : KW - 1;   // clamped: only read when in range
+                    int ins = -10;
+                    if (SH.hasI[s]) {
+                        const int ins_g = (o_ok && SH.lo[so] <= k - 1 && k - 1 <= SH.hi[so]) ? Mv[so][km1] : kLaneNull;
+                        const int ins_i = (ie_ok && SH.lo[se] <= k - 1 && k - 1 <= SH.hi[se]) ? Iv[se][km1] : kLaneNull;
+                        ins = (ins_g == kLaneNull && ins_i == kLaneNull) ? kLaneNull : max(ins_g, ins_i) + 1;
+                        Iv[s][kk] = ins;
+                    }
+                    int del = -10;
+                    if (SH.hasD[s]) {
+                        const int del_g = (o_ok && SH.lo[so] <= k + 1 && k + 1 <= SH.hi[so]) ? Mv[so][kp1] : kLaneNull;
+                        const int del_d = (de_ok && SH.lo[se] <= k + 1 && k + 1 <= SH.hi[se]) ? Dv[se][kp1] : kLaneNull;
+                        del = max(del_g, del_d);
+                        Dv[s][kk] = del;
+                    }
+                    int sub = -10;
+                    if (sub_ok) sub = (SH.lo[ss] <= k && k <= SH.hi[ss]) ? Mv[ss][kk] + 1 : kLaneNull;
+                    Mv[s][kk] = max(del, max(sub, ins));
+                }
+            } else {
+                Mv[0][-SH.kmin] = 0;
+            }
+            // affine_wfa_extend (wfa.c:186-208), bit-parallel; then affine_wfa_end_reached (wfa.c:210-230)
+            int m_end = kLaneNull;
+            bool end_in_range = false;
+#pragma unroll
+            for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {
+                const int kk = k - SH.kmin;
+                int off = Mv[s][kk];
+                const int v = off - k;
+                const int limit = min(plen, tlen - k);
+                if (off >= 0 && v >= 0 && v < limit) {
+                    const int stop = min(first_stop<NP>(dk[kk], v), limit);
+                    off += stop - v;
+                }
+                Mv[s][kk] = off;
+                if (k == ak) { m_end = off; end_in_range = true; }
+            }
+            if (!done && end_in_range && m_end >= tlen) { done = true; score = s; }
+            if (__ballot(!done && active && bad == 0u) == 0ull) break;   // every pair of this wave has finished
+            if (s + 1 > ms_run) break;                              // runtime MAX_SCORE below the template cap
+        }
+        if (!done) score = ms_run + 1;                              // wfa.c:368-376
+
+        if (active) {
+            if (bad != 0u) {   // non-ACGT byte inside a sequence: hand the pair to the general kernel
+                const uint32_t slot = atomicAdd(&todo[LANE_TODO_COUNT], 1u);
+                todo[LANE_TODO_LIST + slot] = pair;
+            } else {
+                aim_result_t r;
+                r.max_operations = plen + tlen;        // edit_cigar_allocate, wfa.c:57-67
+                r.begin_offset = plen + tlen - 1;
+                r.end_offset = plen + tlen;
+                r.score = score;
+                r.status = AIM_PAIR_OK;
+                r.idx = rq.idx;
+                a.res[pair] = r;
+            }
+        }
+        have = nhave;
+        grp = ngrp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side planning / dispatch
+// ---------------------------------------------------------------------------------------------------
+constexpr uint32_t kLaneGrid = 256 * 11;   // 11 single-wave workgroups per CU (LDS: 2 x 64 rows x 112 B = 14 KiB each)
+
+inline bool wfa_lane_supported(const aim_params_t &p)
+{
+    if (p.algo != AIM_ALGO_WFA) return false;
+    if (p.flags & AIM_FLAG_BACKTRACE) return false;               // CIGAR path: general kernel
+    if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the reference's default penalties
+    if (p.max_score > 5) return false;
+    return p.read_size == 80 || p.read_size == 112;   // odd number of 16-B slots per row (conflict-free row reads)
+}
+
+inline size_t wfa_lane_todo_bytes(uint32_t n_pairs) { return ((size_t)(LANE_TODO_LIST + n_pairs) * 4 + 255) & ~(size_t)255; }
+
+inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
+{
+    const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
+    uint32_t g = kLaneGrid;
+    const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
+    if (g > need) g = need < 8u ? 8u : need;
+    *grid = g;
+    *block = kWave;
+    *lds = (size_t)2 * kWave * p.read_size;
+}
+
+inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    (void)block;
+#define AIM_LANE_LAUNCH(RS) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS>), dim3(grid), dim3(kWave), lds, s, ka)
+    switch (p.read_size) {
+    case 80: AIM_LANE_LAUNCH(80); break;
+    case 112: AIM_LANE_LAUNCH(112); break;
+    default: break;
+    }
+#undef AIM_LANE_LAUNCH
+}
 
 }  // namespace aim

@@ -96,12 +96,13 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
     const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e;
     const int MS = a.p.max_score;
 
+    // direct mode: every pair of the batch; indirect mode: the pairs the lane kernel could not pack
+    const uint32_t n_units = a.todo ? min(a.todo[0], a.n_pairs) : a.n_pairs;
+
     for (uint32_t it = 0;; ++it) {
         uint32_t pair;
-        if (!xcd_unit(a.n_pairs, it, &pair)) {
-            // per-XCD slices are equal sized except the last; once this block is past its slice it is done
-            break;
-        }
+        if (!xcd_unit(n_units, it, &pair)) break;   // past this block's slice: done
+        if (a.todo) pair = a.todo[16 + pair];
         const aim_request_t rq = a.req[pair];
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);

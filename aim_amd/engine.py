@@ -163,6 +163,11 @@ class DeviceSet:
             capi.check(rc)
         return res, ops
 
+    def fallback_pairs(self, device=0):
+        n = C.c_uint32()
+        capi.check(self.lib.aim_set_fallback_pairs(self.handle, device, C.byref(n)))
+        return n.value
+
     def timers(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         capi.check(self.lib.aim_set_timers(self.handle, C.byref(a), C.byref(b), C.byref(c)))

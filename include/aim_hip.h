@@ -121,6 +121,10 @@ int aim_set_pull(aim_set_t *set, uint32_t device, aim_result_t *results, char *o
 /* The three phase timers host.c prints ("CPU-DPU", "DPU Kernel", "DPU-CPU",
  * host.c:270-272, 297-299, 328-330), in milliseconds, accumulated. */
 int aim_set_timers(const aim_set_t *set, float *h2d_ms, float *kernel_ms, float *d2h_ms);
+/* How many pairs of the last launch on `device` left the short-read fast path
+ * (sequences with bytes other than A/C/G/T) and were aligned by the general
+ * kernel instead.  Diagnostic only; 0 when the configuration has no fast path. */
+int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback);
 /* dpu_free (host.c:371) */
 int aim_set_free(aim_set_t *set);
 
@@ -132,7 +136,9 @@ int aim_host_free(void *ptr);
  * One alignment launch over buffers that already live in HBM (same layouts as
  * above).  Used by the benchmark and by callers that manage device memory
  * themselves.  hip_stream is a hipStream_t (NULL = default stream); the call
- * only enqueues work.  d_scratch must hold aim_scratch_bytes() bytes. */
+ * only enqueues work.  d_scratch must hold aim_scratch_bytes() bytes.
+ * d_patterns / d_texts must be 16-byte aligned and carry >= 16 bytes of
+ * addressable slack after the last row (the kernels read whole 16-byte chunks). */
 size_t aim_scratch_bytes(const aim_params_t *params, uint32_t n_pairs);
 int aim_align_device(const aim_params_t *params, uint32_t n_pairs, const aim_request_t *d_requests,
                      const char *d_patterns, const char *d_texts, aim_result_t *d_results,

@@ -278,3 +278,30 @@ def test_host_cli_end_to_end(gpu, sample_bytes, ref_digests, tmp_path):
         assert md5(out.read_bytes()) == ref_digests[key]
         for line in ("Allocated 4 DPU(s)", "NumReads per dpu = 5000", "DPU Kernel:", "CPU-DPU:", "DPU-CPU:"):
             assert line in r.stdout
+
+
+def test_fast_path_is_taken_and_non_acgt_falls_back(gpu, sample_bytes, err_bytes):
+    """cfg2 runs on the one-pair-per-lane kernel; pairs with bytes outside ACGT (the reference compares raw
+    bytes) are drained by the general kernel -- and only those."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    params = engine.make_params("wfa", 5, 112, reduce=True)
+    assert capi.load().aim_kernel_name(C.byref(params)) == b"wfa_lane_kernel"
+    for data in (sample_bytes, err_bytes):
+        req, pat, txt = engine.parse_pairs(data, 112)
+        expect = 0
+        for i in range(len(req)):
+            s = pat[i, : req["pattern_len"][i]].tobytes() + txt[i, : req["text_len"][i]].tobytes()
+            expect += 1 if (set(s) - set(b"ACGT")) else 0
+        with engine.DeviceSet(1) as ds:
+            res, _ = ds.align(params, req, pat, txt)
+            assert ds.fallback_pairs(0) == expect
+        if data is err_bytes:
+            assert expect > 0
+    # lower-case / N / arbitrary bytes, mixed into an otherwise clean batch
+    req, pat, txt = engine.gen_pairs(77, 0, 1000, 100, 0.01, 112)
+    for i in range(0, 1000, 7):
+        pat[i, i % 100] = ord("N")
+    for i in range(3, 1000, 11):
+        txt[i, (3 * i) % 99] = ord("a")
+    _compare("wfa", params, req, pat, txt)
