@@ -25,6 +25,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def pmc_traffic(kernel, pairs):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    separate passes; profiles/rNN/*_pmc_summary.json) when it was taken on this kernel and batch size."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel", "").startswith(kernel) and d.get("pairs_per_launch") == pairs:
+            best = (d["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +167,8 @@ def main():
         total_pairs = world * n * args.steps
         value = total_pairs / elapsed
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        kname = lib.aim_kernel_name(C.byref(params)).decode()
+        traffic = pmc_traffic(kname, n) if not args.backtrace else None
         line = {
             "metric": "aligned pairs/sec WFA-adaptive l=%d e=%g%%" % (args.length, args.error * 100),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,12 +177,13 @@ def main():
             "config": {"workload": "WFA-adaptive %s l=%d e=%g%% %d synthetic pairs per GPU (MAX_SCORE %d, READ_SIZE %d)"
                                    % ("with CIGAR" if args.backtrace else "score-only", args.length, args.error * 100, n, ms, rs),
                        "pairs_per_gpu": n, "parallelism": "pairs sharded statically, %d rank(s)" % world,
-                       "kernel": lib.aim_kernel_name(C.byref(params)).decode()},
+                       "kernel": kname},
             "gcups": value * (cells / n) / 1e9,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_pair": alg_bytes / n},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic[1] if traffic else None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_pair": alg_bytes / n},
             "cpu_baseline": cpu_baseline,
             "gather_ms": gather_ms,
             "verified_vs_oracle": verified,
