@@ -73,14 +73,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from aim_amd import capi, engine
+    from aim_amd import capi, engine, shard
     lib = capi.load()
 
     n = args.pairs
     ms, rs = engine.launcher_sizes("wfa", args.length, args.error)
     params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=args.backtrace)
     # static contiguous split: rank r owns global pairs [r*n, (r+1)*n)  (host.c:191-209)
-    req, pat, txt = engine.gen_pairs(42, rank * n, n, args.length, args.error, rs)
+    req, pat, txt = engine.gen_pairs(42, shard.weak_first_index(n, rank), n, args.length, args.error, rs)
     alg_bytes = int(req["pattern_len"].astype(np.int64).sum() + req["text_len"].astype(np.int64).sum() + 16 * n)
     cells = int((req["pattern_len"].astype(np.int64) * req["text_len"].astype(np.int64)).sum())
 
@@ -129,10 +129,9 @@ def main():
     res_host = np.frombuffer(d_res[: n * capi.RESULT_DTYPE.itemsize].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
     if world > 1:
         scores = torch.from_numpy(np.ascontiguousarray(res_host["score"])).to(dev)
-        out = torch.empty(world * n, dtype=scores.dtype, device=dev)
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
-        dist.all_gather_into_tensor(out, scores)
+        out = shard.gather_scores(scores, dist)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert bool((out[rank * n:(rank + 1) * n] == scores).all())
