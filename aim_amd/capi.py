@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaim_hip.so")
+LIB_PATH = os.environ.get("AIM_LIB") or os.path.join(_HERE, "libaim_hip.so")   # AIM_LIB: A/B builds of the same ABI
 
 AIM_OK, AIM_EINVAL, AIM_ENODEV, AIM_ENOMEM, AIM_ESTATE, AIM_EALIGN = 0, -1, -2, -3, -4, -5
 ALGO_NW, ALGO_SWG, ALGO_WFA = 0, 1, 2

@@ -216,11 +216,13 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
     case K_WFA_LANE: {
         // [to-do region | general kernel scratch]: count zeroed per launch, lane kernel, then the drain
         HIP_TRY(hipMemsetAsync(d_scratch, 0, 64, stream));
+        ka.scratch_per_wave = pl.todo_bytes;   // (diagnostic builds park their stamps behind the to-do region)
         aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         aim::KArgs kb = ka;
         kb.todo = reinterpret_cast<const uint32_t *>(d_scratch);
         kb.scratch = (char *)d_scratch + pl.todo_bytes;
+        kb.scratch_per_wave = pl.scratch_per_wg;
         Plan fb = pl;
         fb.grid = pl.fb_grid;
         fb.lds = pl.fb_lds;

@@ -22,6 +22,28 @@
 
 #include "aim_device.hpp"
 
+// ---- build-time knobs (A/B tested on MI355X) ------------------------------------
+#ifndef AIM_LANE_MIN_WAVES
+#define AIM_LANE_MIN_WAVES 1      // __launch_bounds__ 2nd argument: minimum waves per SIMD (caps VGPRs)
+#endif
+#ifndef AIM_LANE_STAMPS
+#define AIM_LANE_STAMPS 0         // diagnostic build only: s_memtime per segment, summed per wave into scratch
+#endif
+#ifndef AIM_LANE_DMA_AUX
+#define AIM_LANE_DMA_AUX 2        // cache policy of the sequence DMA: 2 = nt (rows are read exactly once; +5 % measured), 0 = default
+#endif
+#ifndef AIM_LANE_WGS_PER_CU
+#define AIM_LANE_WGS_PER_CU 8     // persistent single-wave workgroups per CU = resident waves at this VGPR count
+                                  // (a grid larger than the residency runs in uneven rounds: 11/CU measured 15-20 % slower)
+#endif
+#if AIM_LANE_STAMPS
+#define AIM_STAMP(i) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        stamp_sum[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define AIM_STAMP(i) do { } while (0)
+#endif
+
 namespace aim {
 
 constexpr int kLaneNull = -16384;   // AFFINE_WAVEFRONT_OFFSET_NULL (common.h:100)
@@ -100,21 +122,27 @@ __device__ __forceinline__ void dma_rows(uint32_t *lds_rows, const char *base, u
         const uint32_t c = i * kWave + lane;
         if (c < n_chunks)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (uint64_t)c * 16),
-                                             (__attribute__((address_space(3))) void *)(lds_rows + i * kWave * 4), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(lds_rows + i * kWave * 4), 16, 0, AIM_LANE_DMA_AUX);
     }
 }
 
-// Read this lane's row (16 B at a time, compile-time offsets; RS/16 odd => ds_read_b128 is conflict-free),
-// validate A/C/G/T over [0, len) and pack 2 bits/base: 16 bases -> one dword.
+// Read this lane's row, 16 B at a time at compile-time offsets (RS/16 odd => ds_read_b128 is conflict-free).
 template <int RS, int NP>
-__device__ __forceinline__ uint32_t pack_row(const uint32_t *lds_rows, int lane, int len, int min_len_wave, uint32_t (&out)[NP])
+__device__ __forceinline__ void load_row(const uint32_t *lds_rows, int lane, uint4 (&raw)[NP])
 {
-    uint32_t bad = 0;
     const uint4 *row = reinterpret_cast<const uint4 *>(lds_rows + lane * (RS / 4));
 #pragma unroll
+    for (int j = 0; j < NP; ++j) raw[j] = row[j];
+}
+
+// Validate A/C/G/T over [0, len) and pack 2 bits/base: 16 bases -> one dword.
+template <int NP>
+__device__ __forceinline__ uint32_t pack_row(const uint4 (&raw)[NP], int len, int min_len_wave, uint32_t (&out)[NP])
+{
+    uint32_t bad = 0;
+#pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const uint4 q = row[j];
-        const uint32_t a[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t a[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
         uint32_t b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -137,8 +165,9 @@ __device__ __forceinline__ uint32_t pack_row(const uint32_t *lds_rows, int lane,
 
 enum : uint32_t { LANE_TODO_COUNT = 0, LANE_TODO_LIST = 16 };   // dword offsets inside the to-do region
 
+
 template <int X, int O, int E, int MAXS, int RS>
-__global__ __launch_bounds__(64) void wfa_lane_kernel(KArgs a)
+__global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs a)
 {
     constexpr WfShape<X, O, E, MAXS> SH{};
     static_assert(SH.maxw < 10, "WFA-adaptive reduction could fire: shape not eligible for the static kernel");
@@ -154,8 +183,10 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(KArgs a)
     uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
     const int ms_run = a.p.max_score;           // runtime MAX_SCORE <= MAXS
 
+    // static XCD slices (an atomic work ticket was measured 3.5x slower: one word serves ~88 tickets/us)
+    auto next_group = [&](uint32_t it_, uint32_t *g_) -> bool { return xcd_unit(n_groups, it_, g_); };
     uint32_t grp;
-    bool have = xcd_unit(n_groups, 0, &grp);
+    bool have = next_group(0, &grp);
     aim_request_t rq_next;
     rq_next.pattern_len = 0; rq_next.text_len = 0; rq_next.padding = 0; rq_next.idx = 0;
     if (have) {
@@ -163,30 +194,43 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(KArgs a)
         dma_rows<RS, NCH>(rowsT, a.texts, grp * kWave, a.n_pairs, lane);
         if (grp * kWave + lane < a.n_pairs) rq_next = a.req[grp * kWave + lane];
     }
+#if AIM_LANE_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
     for (uint32_t it = 0; have; ++it) {
         const uint32_t pair = grp * kWave + lane;
         const bool active = pair < a.n_pairs;
+        AIM_STAMP(0);                           // loop overhead / previous store
         __builtin_amdgcn_s_waitcnt(0);          // this group's DMA has landed (and rq_next arrived)
         __syncthreads();
+        AIM_STAMP(1);                           // wait for DMA
         const aim_request_t rq = rq_next;
         const int plen = rq.pattern_len, tlen = rq.text_len;
-        const int minlen = active ? min(plen, tlen) : 0x7fffffff;
-        const int min_len_wave = __builtin_amdgcn_readfirstlane(wave_min_i32(minlen));
-        uint32_t P[NP], T[NP];
-        uint32_t bad = pack_row<RS, NP>(rowsP, lane, plen, min_len_wave, P);
-        bad |= pack_row<RS, NP>(rowsT, lane, tlen, min_len_wave, T);
-
-        // the LDS image is consumed: start the next group's DMA into the same buffer, under the compute
+        // pull both rows into registers, then immediately start the next group's DMA into the same buffer:
+        // its HBM latency flies under the pack + compute below
+        uint4 rawP[NP], rawT[NP];
+        load_row<RS, NP>(rowsP, lane, rawP);
+        load_row<RS, NP>(rowsT, lane, rawT);
         uint32_t ngrp = 0;
-        const bool nhave = xcd_unit(n_groups, it + 1, &ngrp);
+        const bool nhave = next_group(it + 1, &ngrp);
         __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): every ds_read of this group has returned
         __syncthreads();
+        AIM_STAMP(2);                           // LDS row reads
         if (nhave) {
             dma_rows<RS, NCH>(rowsP, a.patterns, ngrp * kWave, a.n_pairs, lane);
             dma_rows<RS, NCH>(rowsT, a.texts, ngrp * kWave, a.n_pairs, lane);
             if (ngrp * kWave + lane < a.n_pairs) rq_next = a.req[ngrp * kWave + lane];
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the DMA issue ahead of the ALU work
+        AIM_STAMP(3);                           // DMA issue
+        const int minlen = active ? min(plen, tlen) : 0x7fffffff;
+        const int min_len_wave = __builtin_amdgcn_readfirstlane(wave_min_i32(minlen));
+        uint32_t P[NP], T[NP];
+        uint32_t bad = pack_row<NP>(rawP, plen, min_len_wave, P);
+        bad |= pack_row<NP>(rawT, tlen, min_len_wave, T);
 
+        AIM_STAMP(4);                           // pack + validate
         // ---- mismatch bit-vectors per diagonal: bit pair v of dk[k] != 0  <=>  P[v] != T[v + k] ----
         uint32_t dk[KW][NP];
 #pragma unroll
@@ -262,6 +306,7 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(KArgs a)
             if (s + 1 > ms_run) break;                              // runtime MAX_SCORE below the template cap
         }
         if (!done) score = ms_run + 1;                              // wfa.c:368-376
+        AIM_STAMP(5);                           // diagonals + WFA
 
         if (active) {
             if (bad != 0u) {   // non-ACGT byte inside a sequence: hand the pair to the general kernel
@@ -280,13 +325,20 @@ __global__ __launch_bounds__(64) void wfa_lane_kernel(KArgs a)
         }
         have = nhave;
         grp = ngrp;
+        AIM_STAMP(6);                           // result store issue
     }
+#if AIM_LANE_STAMPS
+    if (lane == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.scratch + a.scratch_per_wave) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 8; ++i) dbg[i] = stamp_sum[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
 // host-side planning / dispatch
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kLaneGrid = 256 * 11;   // 11 single-wave workgroups per CU (LDS: 2 x 64 rows x 112 B = 14 KiB each)
+constexpr uint32_t kLaneGrid = 256 * AIM_LANE_WGS_PER_CU;   // single-wave workgroups, LDS 2 x 64 rows x 112 B = 14 KiB each
 
 inline bool wfa_lane_supported(const aim_params_t &p)
 {

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Kernel-only timings of the non-headline configurations through the C-ABI set calls (aim_set_timers' kernel
+timer = AIM's "DPU Kernel").  One JSON line per configuration.  python tools/bench_configs.py [names...]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from aim_amd import capi, engine  # noqa: E402
+
+CONFIGS = {
+    "wfa_l100_e1_cigar": dict(algo="wfa", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True, reduce=True)),
+    "wfa_l100_e2_score": dict(algo="wfa", l=100, e=0.02, n=1 << 20, kw=dict(reduce=True)),
+    "wfa_l100_e5_cigar": dict(algo="wfa", l=100, e=0.05, n=1 << 19, kw=dict(backtrace=True, reduce=True)),
+    "wfa_l1000_e5_cigar": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(backtrace=True, reduce=True)),
+    "wfa_l1000_e5_score": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(reduce=True)),
+    "nw_l100_e1_cigar": dict(algo="nw", l=100, e=0.01, n=1 << 17, kw=dict(backtrace=True)),
+    "swg_l100_e1_cigar": dict(algo="swg", l=100, e=0.01, n=1 << 17, kw=dict(backtrace=True)),
+    "swg_l100_e1_score": dict(algo="swg", l=100, e=0.01, n=1 << 17, kw=dict()),
+}
+
+
+def run(name, cfg, reps=3):
+    ms, rs = engine.launcher_sizes(cfg["algo"], cfg["l"], cfg["e"])
+    params = engine.make_params(cfg["algo"], ms, rs, **cfg["kw"])
+    req, pat, txt = engine.gen_pairs(42, 0, cfg["n"], cfg["l"], cfg["e"], rs)
+    with engine.DeviceSet(1) as s:
+        s.configure(params, cfg["n"])
+        best = None
+        for _ in range(reps):
+            k0 = s.timers()[1]
+            s.push(0, req, pat, txt)
+            s.launch()
+            k = s.timers()[1] - k0
+            best = k if best is None else min(best, k)
+        res, ops = s.pull(0)
+    cells = float((req["pattern_len"].astype(np.int64) * req["text_len"]).sum())
+    alg = float(req["pattern_len"].sum() + req["text_len"].sum() + 16 * cfg["n"])
+    if ops is not None:
+        alg += float((res["end_offset"] - res["begin_offset"]).sum())
+    print(json.dumps({"config": name, "kernel": capi.load().aim_kernel_name(__import__("ctypes").byref(params)).decode(),
+                      "pairs": cfg["n"], "max_score": ms, "read_size": rs, "kernel_ms": best,
+                      "pairs_per_s": cfg["n"] / (best * 1e-3), "gcups": cells / (best * 1e-3) / 1e9,
+                      "algorithmic_GBps": alg / (best * 1e-3) / 1e9, "mean_score": float(res["score"].mean())}), flush=True)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CONFIGS)
+    for nm in names:
+        run(nm, CONFIGS[nm])
