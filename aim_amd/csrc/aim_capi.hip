@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "aim_hip.h"
@@ -20,6 +21,7 @@
 #include "wfa_wave.hpp"
 #include "wfa_lane.hpp"
 #include "dp_lane.hpp"
+#include "dp_wave.hpp"
 
 namespace {
 
@@ -45,7 +47,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3 };
 
 struct Plan {
     KernelId kid;
@@ -154,7 +156,17 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         pl->scratch_total = (size_t)(per * grid);
         return AIM_OK;
     }
-    // NW / SWG: one pair per lane, flat DP table in per-wave HBM scratch
+    // NW / SWG long reads: one pair per wavefront, row-scan, canonical table in per-wave HBM scratch
+    const bool force_dpw = getenv("AIM_FORCE_DPWAVE") && getenv("AIM_FORCE_DPWAVE")[0] == '1';
+    if (p.read_size > 320 || force_dpw) {
+        pl->kid = K_DP_WAVE;
+        pl->block = 64;
+        const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
+        return aim::dp_wave_plan(p, n_pairs, budget, cell8, &pl->grid, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total)
+                   ? AIM_OK
+                   : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
+    }
+    // NW / SWG short reads: one pair per lane, flat DP table in per-wave HBM scratch
     pl->kid = K_DP_LANE;
     return aim::dp_lane_plan(p, n_pairs, budget, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total,
                              &pl->seq_lds)
@@ -232,6 +244,9 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
     }
     case K_DP_LANE:
         aim::dp_lane_launch(p, pl.grid, pl.lds, pl.seq_lds, ka, stream);
+        break;
+    case K_DP_WAVE:
+        aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.lds, ka, stream);
         break;
     }
     HIP_TRY(hipGetLastError());
@@ -522,6 +537,7 @@ const char *aim_kernel_name(const aim_params_t *params)
     case K_WFA_WAVE: return "wfa_wave_kernel";
     case K_WFA_LANE: return "wfa_lane_kernel";
     case K_DP_LANE: return p_is_nw(params) ? "nw_lane_kernel" : "swg_lane_kernel";
+    case K_DP_WAVE: return "dp_wave_kernel";
     }
     return "";
 }

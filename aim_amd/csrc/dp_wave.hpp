@@ -1,0 +1,381 @@
+// dp_wave.hpp -- long-read NW / SWG: ONE PAIR PER WAVEFRONT, row by row, 64 lanes x K cells per step.
+//
+// Same results as nw_compute/nw_traceback (NW/DPU-WRAM/dpu/nw.c:67-153) and swg_compute/swg_traceback
+// (SWG/DPU-WRAM/dpu/swg.c:45-171) for reads whose table does not fit the one-pair-per-lane kernel
+// (dp_lane.hpp), e.g. BASELINE config 4: SWG, l = 10 000 (10^8 cells per pair).
+//
+// The reference's table is flat, indexed num_cols*h + v with num_cols = tlen+1 while v runs to plen.
+// Write W = tlen+1.  In row h the cells v < W ("regular") depend only on row h-1 and on their left
+// neighbour chain; the cells v >= W ("tail", only when plen > tlen) alias row h+1: cell (h, W) IS the
+// boundary cell of row h+1 and (h, v > W) occupy cells that row h+1 recomputes.  Hence:
+//   * regular cells of a row are computed by all lanes, K consecutive cells per lane per step; the
+//     vertical/diagonal inputs come from the previous row kept in LDS; the in-row gap chain
+//         D[v] = min(M[v-1]+o+e, D[v-1]+e)   (SWG)      R[v] = min(A[v], R[v-1]+g)   (NW)
+//     is a prefix-min: D[v] = v*e + min_{j<v} G[j] with G[j] = A[j]+o+e-(j+1)e (A = min(diag+cost, I)),
+//     evaluated with a per-lane sequential pass, one wave-level exclusive scan and a running carry.
+//     This equals the reference's cell-by-cell arithmetic exactly as long as no int16 store can wrap,
+//     which dp_wave_exact_ok() proves from (READ_SIZE, penalties, MAX_SCORE) before this path is taken.
+//   * tail cells are evaluated sequentially after the regular part of their row with the aliased inputs
+//     (left = boundary / current row, diag likewise), cell (h, W) becomes row h+1's boundary, and only
+//     the last row's tail survives in the final table -- exactly what the flat table ends up holding.
+//   * the final table (all three layers, int16) is kept in a per-wave HBM slab in canonical form
+//     (flat index f -> row f / W, column f % W, padded rows), and the traceback is the reference's
+//     value-comparison walk over flat indices.
+// Pairs outside these preconditions (plen > 2*tlen, possible int16 wrap, int8 cells) take a literal
+// single-lane path over a flat table in the same slab: correct for everything, slow, and rare.
+#pragma once
+
+#include "aim_device.hpp"
+
+namespace aim {
+
+constexpr int kDpK = 8;                      // cells per lane per step
+constexpr int kDpBlock = kWave * kDpK;       // 512 cells per step
+constexpr int kDpInf = 0x3fffffff;
+
+__device__ __forceinline__ int wave_excl_scan_min(int x, int lane, int *total)
+{
+    int v = x;   // inclusive Kogge-Stone prefix-min
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(v, off, kWave);
+        if (lane >= off) v = min(v, o);
+    }
+    *total = __shfl(v, kWave - 1, kWave);
+    const int e = __shfl_up(v, 1, kWave);
+    return lane == 0 ? kDpInf : e;
+}
+
+struct DpCell { int M, I, D; };
+
+// Host + device: can any int16 store of the row-scan path wrap?  
+__host__ __device__ inline bool dp_wave_exact_ok(const aim_params_t &p, bool swg_int8)
+{
+    if (swg_int8) return false;
+    const long rs = p.read_size;
+    if (p.algo == AIM_ALGO_NW) {
+        const long g = p.gap_i > p.gap_d ? p.gap_i : p.gap_d;
+        return (2 * rs + 4) * g + 2 * p.mismatch < 32000;
+    }
+    const long hi = 3L * p.gap_o + (2 * rs + 4) * p.gap_e + 2L * p.mismatch + (p.max_score > 0 ? p.max_score : 0);
+    const long lo = (long)p.match * rs;   // match <= 0
+    return hi < 32000 && lo > -32000 && p.max_score < 32000;
+}
+
+// ALGO: AIM_ALGO_NW or AIM_ALGO_SWG.  CELL8: SWG with int8 cells (literal path only).
+template <int ALGO, bool BT, bool CELL8>
+__global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SWG = (ALGO == AIM_ALGO_SWG);
+    const int lane = threadIdx.x;
+    const int rs = a.p.read_size;
+    const int rowcap = rs + 16;                       // int16 entries per LDS row buffer
+    unsigned char *ldsP = reinterpret_cast<unsigned char *>(smem);
+    int16_t *rowbuf = reinterpret_cast<int16_t *>(smem + ((rs + 15) & ~15));
+    int16_t *Mrow[2] = {rowbuf, rowbuf + rowcap};
+    int16_t *Irow[2] = {rowbuf + 2 * rowcap, rowbuf + 3 * rowcap};   // SWG only
+    int16_t *tailM = rowbuf + (SWG ? 4 : 2) * rowcap;                 // tail cells of the current row (<= rs)
+    // table slab: canonical rows of stride S, layers as planes
+    const int S = (rs + 16) & ~7;
+    const size_t plane = (size_t)S * (size_t)(rs + 3);
+    int16_t *tb = reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
+    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;
+    const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
+    const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
+    const bool exact_ok = dp_wave_exact_ok(a.p, CELL8);
+
+    for (uint32_t it = 0;; ++it) {
+        uint32_t pair;
+        if (!xcd_unit(a.n_pairs, it, &pair)) break;
+        const aim_request_t rq = a.req[pair];
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
+        const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
+        char *ops = BT ? a.ops + (uint64_t)pair * 2 * rs : nullptr;
+        const int W = tlen + 1;
+        int score = 0, status = AIM_PAIR_OK;
+        int begin_offset = plen + tlen - 1;
+        const int end_offset = plen + tlen;
+        __syncthreads();
+        if (BT && SWG) {   // memset(cigar->operations, 'M', 2*READ_SIZE), swg.c:261
+            uint32_t *o4 = reinterpret_cast<uint32_t *>(ops);
+            for (int w = lane; w < (rs >> 1); w += kWave) o4[w] = 0x4D4D4D4Du;
+        }
+        const bool literal = !exact_ok || plen > 2 * tlen;
+
+        if (literal) {
+            // ------------------------------------------------------------------ literal single-lane path
+            // The reference's loops verbatim over a flat table (plane-separated) in the slab.
+            typedef typename std::conditional<CELL8, int8_t, int16_t>::type cell_t;
+            if (lane == 0) {
+                if (!SWG) {
+                    int cell = 0;
+                    TM[0] = 0;
+                    for (int v = 1; v <= plen; ++v) { cell += GD; TM[v] = (int16_t)cell; }
+                    cell = 0;
+                    for (int h = 1; h <= tlen; ++h) { cell += GI; TM[(size_t)W * h] = (int16_t)cell; }
+                    int16_t sc = 0;
+                    for (int h = 1; h <= tlen; ++h) {
+                        const int tch = gT[h - 1];
+                        const size_t row = (size_t)W * h, prow = row - W;
+                        for (int v = 1; v <= plen; ++v) {
+                            const int16_t del = (int16_t)(TM[row + v - 1] + GD);
+                            const int16_t ins = (int16_t)(TM[prow + v] + GI);
+                            const int16_t mm = (int16_t)(TM[prow + v - 1] + ((gP[v - 1] == tch) ? 0 : MISMATCH));
+                            sc = TM[row + v] = min(mm, min(ins, del));
+                        }
+                    }
+                    score = sc;
+                } else {
+                    TD[0] = (cell_t)MAXS; TI[0] = (cell_t)MAXS; TM[0] = 0;
+                    for (int v = 1; v <= plen; ++v) { const cell_t d = (cell_t)(O + v * E); TD[v] = d; TI[v] = (cell_t)MAXS; TM[v] = d; }
+                    for (int h = 1; h <= tlen; ++h) {
+                        const cell_t i = (cell_t)(O + h * E);
+                        TD[(size_t)W * h] = (cell_t)MAXS; TI[(size_t)W * h] = i; TM[(size_t)W * h] = i;
+                    }
+                    for (int h = 1; h <= tlen; ++h) {
+                        const int tch = gT[h - 1];
+                        const size_t row = (size_t)W * h, prow = row - W;
+                        for (int v = 1; v <= plen; ++v) {
+                            const cell_t del = min((cell_t)((cell_t)TM[row + v - 1] + OE), (cell_t)((cell_t)TD[row + v - 1] + E));
+                            const cell_t ins = min((cell_t)((cell_t)TM[prow + v] + OE), (cell_t)((cell_t)TI[prow + v] + E));
+                            const cell_t mm = (cell_t)((cell_t)TM[prow + v - 1] + ((gP[v - 1] == tch) ? MATCH : MISMATCH));
+                            const cell_t m = min(mm, min(ins, del));
+                            TD[row + v] = del; TI[row + v] = ins; TM[row + v] = m;
+                            score = m;
+                        }
+                    }
+                }
+            }
+            score = __shfl(score, 0, kWave);
+            __syncthreads();
+        } else {
+            // ------------------------------------------------------------------ row-scan path
+            for (int i = lane; i < plen; i += kWave) ldsP[i] = gP[i];
+            const int Rr = min(plen, W - 1);          // regular columns 1..Rr
+            const bool has_tail = plen >= W;
+            // row 0 (and its table image) ; boundary column of the table
+            int cur = 0;
+            for (int v = lane; v <= Rr; v += kWave) {
+                int m0, i0;
+                if (SWG) { m0 = v ? O + v * E : 0; i0 = MAXS; }
+                else { m0 = v * GD; i0 = 0; }
+                Mrow[cur][v] = (int16_t)m0;
+                if (SWG) Irow[cur][v] = (int16_t)i0;
+                TM[7 + v] = (int16_t)m0;
+                if (SWG) { TI[7 + v] = (int16_t)i0; TD[7 + v] = (int16_t)(v ? m0 : MAXS); }
+            }
+            for (int h = 1 + lane; h <= tlen; h += kWave) {   // row-init boundary cells flat[W*h]
+                const size_t at = (size_t)h * S + 7;
+                if (SWG) { TM[at] = (int16_t)(O + h * E); TI[at] = (int16_t)(O + h * E); TD[at] = (int16_t)MAXS; }
+                else TM[at] = (int16_t)(h * GI);
+            }
+            __syncthreads();
+            DpCell B;                                  // boundary cell of the current row (flat[W*h])
+            DpCell lastTail = {0, 0, 0};
+            for (int h = 1; h <= tlen; ++h) {
+                const int nxt = cur ^ 1;
+                const int tch = gT[h - 1];
+                if (h == 1 || !has_tail) {
+                    if (SWG) { B.M = O + h * E; B.I = B.M; B.D = MAXS; }
+                    else { B.M = h * GI; B.I = B.D = 0; }
+                } else {
+                    B = lastTail;                      // cell (h-1, W) landed on flat[W*h]
+                }
+                if (lane == 0) { Mrow[nxt][0] = (int16_t)B.M; if (SWG) Irow[nxt][0] = (int16_t)B.I; }
+                int carry = SWG ? min(B.D, B.M + O) : B.M;     // G[0]
+                int lastD = B.D, lastM = B.M;                   // up-neighbour of the first tail cell: cell (h, W-1)
+                const size_t trow = (size_t)h * S + 7;
+                for (int base = 1; base <= Rr; base += kDpBlock) {
+                    const int v0 = base + lane * kDpK;
+                    int A[kDpK], Iv[kDpK], G[kDpK];
+                    int lane_min = kDpInf;
+#pragma unroll
+                    for (int t = 0; t < kDpK; ++t) {
+                        const int v = v0 + t;
+                        if (v <= Rr) {
+                            const int leftM = Mrow[cur][v], diagM = Mrow[cur][v - 1];
+                            const int pch = ldsP[v - 1];
+                            if (SWG) {
+                                const int ins = min(leftM + OE, (int)Irow[cur][v] + E);
+                                Iv[t] = ins;
+                                A[t] = min(diagM + ((pch == tch) ? MATCH : MISMATCH), ins);
+                                G[t] = A[t] + OE - (v + 1) * E;
+                            } else {
+                                Iv[t] = 0;
+                                A[t] = min(diagM + ((pch == tch) ? 0 : MISMATCH), leftM + GI);
+                                G[t] = A[t] - v * GD;
+                            }
+                        } else {
+                            A[t] = Iv[t] = 0;
+                            G[t] = kDpInf;
+                        }
+                        lane_min = min(lane_min, G[t]);
+                    }
+                    int total;
+                    int pre = min(carry, wave_excl_scan_min(lane_min, lane, &total));
+#pragma unroll
+                    for (int t = 0; t < kDpK; ++t) {
+                        const int v = v0 + t;
+                        if (v <= Rr) {
+                            const int d = pre + v * (SWG ? E : GD);
+                            const int m = min(A[t], d);
+                            Mrow[nxt][v] = (int16_t)m;
+                            TM[trow + v] = (int16_t)m;
+                            if (SWG) {
+                                Irow[nxt][v] = (int16_t)Iv[t];
+                                TI[trow + v] = (int16_t)Iv[t];
+                                TD[trow + v] = (int16_t)d;
+                            }
+                            if (v == Rr) { tailM[0] = (int16_t)m; tailM[1] = (int16_t)d; }
+                            pre = min(pre, G[t]);
+                        }
+                    }
+                    carry = min(carry, total);
+                }
+                __syncthreads();
+                if (has_tail) {
+                    // cells v = W .. plen, sequentially (wave-uniform), with the aliased inputs
+                    lastM = tailM[0];
+                    lastD = tailM[1];
+                    DpCell up = {lastM, 0, lastD};
+                    const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical row of flat[W*h + v], v >= W
+                    for (int v = W; v <= plen; ++v) {
+                        int leftM, leftI, diagM;
+                        if (v == W) { leftM = B.M; leftI = B.I; diagM = Mrow[cur][W - 1]; }
+                        else {
+                            leftM = Mrow[nxt][v - W];
+                            leftI = SWG ? (int)Irow[nxt][v - W] : 0;
+                            diagM = (v - 1 == W) ? B.M : (int)Mrow[nxt][v - 1 - W];
+                        }
+                        const int pch = ldsP[v - 1];
+                        DpCell c;
+                        if (SWG) {
+                            c.D = min(up.M + OE, up.D + E);
+                            c.I = min(leftM + OE, leftI + E);
+                            c.M = min(diagM + ((pch == tch) ? MATCH : MISMATCH), min(c.I, c.D));
+                        } else {
+                            c.I = c.D = 0;
+                            c.M = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(leftM + GI, up.M + GD));
+                        }
+                        if (v == W) lastTail = c;
+                        if ((h == tlen || v == W) && lane == 0) {
+                            TM[tdst + (v - W)] = (int16_t)c.M;
+                            if (SWG) { TI[tdst + (v - W)] = (int16_t)c.I; TD[tdst + (v - W)] = (int16_t)c.D; }
+                        }
+                        up = c;
+                    }
+                    if (h == tlen) score = up.M;
+                } else if (h == tlen) {
+                    score = plen >= 1 ? (int)Mrow[nxt][plen] : 0;
+                }
+                cur = nxt;
+                __syncthreads();
+            }
+            if (plen == 0 || tlen == 0) score = 0;
+        }
+
+        if (BT) {
+            // nw_traceback / swg_traceback over flat indices; canonical slab unless literal
+            auto addr = [&](int f) -> size_t {
+                if (literal) return (size_t)f;
+                const int r = f / W;
+                return (size_t)r * S + 7 + (f - r * W);
+            };
+            int sentinel = end_offset - 1;
+            int h = tlen, v = plen;
+            const int cap = 2 * rs;
+            auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
+            if (!SWG) {
+                while (h > 0 && v > 0) {
+                    const int at = W * h + v;
+                    const int c = TM[addr(at)];
+                    if (c == (int)TM[addr(at - 1)] + GD) { put('D'); --v; }
+                    else if (c == (int)TM[addr(at - W)] + GI) { put('I'); --h; }
+                    else { put((c == (int)TM[addr(at - W - 1)] + MISMATCH) ? 'X' : 'M'); --h; --v; }
+                }
+            } else {
+                enum { L_M, L_I, L_D };
+                int layer = L_M;
+                while (h > 0 && v > 0) {
+                    const int at = W * h + v;
+                    if (layer == L_D) {
+                        put('D');
+                        if ((int)TD[addr(at)] == (int)TM[addr(at - 1)] + OE) layer = L_M;
+                        --v;
+                    } else if (layer == L_I) {
+                        put('I');
+                        if ((int)TI[addr(at)] == (int)TM[addr(at - W)] + OE) layer = L_M;
+                        --h;
+                    } else {
+                        const int m = TM[addr(at)];
+                        if (m == (int)TD[addr(at)]) layer = L_D;
+                        else if (m == (int)TI[addr(at)]) layer = L_I;
+                        else if (m == (int)TM[addr(at - W - 1)] + MATCH) { put('M'); --h; --v; }
+                        else if (m == (int)TM[addr(at - W - 1)] + MISMATCH) { put('X'); --h; --v; }
+                        else { status = AIM_PAIR_SWG_NO_OP; break; }
+                    }
+                }
+            }
+            if (status == AIM_PAIR_OK) {
+                for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
+                if (h > 0) sentinel -= h;
+                for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
+                if (v > 0) sentinel -= v;
+            }
+            begin_offset = sentinel + 1;
+        }
+        if (lane == 0) {
+            aim_result_t r;
+            r.max_operations = plen + tlen;
+            r.begin_offset = begin_offset;
+            r.end_offset = end_offset;
+            r.score = score;
+            r.status = status;
+            r.idx = rq.idx;
+            a.res[pair] = r;
+        }
+    }
+}
+
+inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, bool cell8, uint32_t *grid, size_t *lds,
+                         uint64_t *scratch_per_wg, size_t *scratch_total)
+{
+    const uint64_t rs = (uint64_t)p.read_size;
+    const uint64_t S = (rs + 16) & ~7ull;
+    uint64_t per = 3 * S * (rs + 3) * 2;   // three int16 planes (NW uses the first)
+    per = (per + 255) & ~255ull;
+    uint32_t g = 256 * 4;
+    const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
+    if (g > need) g = need < 8u ? 8u : need;
+    while (g > 8 && per * g > budget) g -= 8;
+    if (per * g > budget) return false;
+    (void)cell8;
+    *grid = g;
+    const bool swg = p.algo == AIM_ALGO_SWG;
+    *lds = ((rs + 15) & ~15ull) + (size_t)((swg ? 4 : 2) * (rs + 16) + rs + 16) * 2;
+    *scratch_per_wg = per;
+    *scratch_total = (size_t)(per * g);
+    return *lds <= 160 * 1024;
+}
+
+inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+#define AIM_DPW(KERNEL)                                                                              \
+    do {                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWave), lds, s, ka);                             \
+    } while (0)
+    if (p.algo == AIM_ALGO_NW) {
+        if (bt) AIM_DPW((dp_wave_kernel<AIM_ALGO_NW, true, false>)); else AIM_DPW((dp_wave_kernel<AIM_ALGO_NW, false, false>));
+    } else if (cell8) {
+        if (bt) AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, true, true>)); else AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, false, true>));
+    } else {
+        if (bt) AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, true, false>)); else AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, false, false>));
+    }
+#undef AIM_DPW
+}
+
+}  // namespace aim

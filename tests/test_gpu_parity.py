@@ -305,3 +305,78 @@ def test_fast_path_is_taken_and_non_acgt_falls_back(gpu, sample_bytes, err_bytes
     for i in range(3, 1000, 11):
         txt[i, (3 * i) % 99] = ord("a")
     _compare("wfa", params, req, pat, txt)
+
+
+# ------------------------------------------------------------------ long-read NW/SWG kernel (dp_wave)
+@pytest.mark.parametrize("key,algo,ms,kw", [("nw_backtrace", "nw", 4, dict(backtrace=True)),
+                                            ("swg_w16_backtrace", "swg", 5, dict(backtrace=True, swg_w16=True)),
+                                            ("swg_w8_backtrace", "swg", 5, dict(backtrace=True))])
+def test_dp_wave_on_sample_file_digest(gpu, sample_bytes, ref_digests, monkeypatch, key, algo, ms, kw):
+    """The row-scan kernel (and, for int8 cells, its literal path) forced onto the reference's sample file."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    monkeypatch.setenv("AIM_FORCE_DPWAVE", "1")
+    req, pat, txt = engine.parse_pairs(sample_bytes, 112)
+    n = 20000 if "w8" not in key else 4000
+    params = engine.make_params(algo, ms, 112, **kw)
+    assert capi.load().aim_kernel_name(C.byref(params)) == b"dp_wave_kernel"
+    if n == 20000:
+        res, ops = engine.align(params, req, pat, txt)
+        assert md5(engine.format_output(res, ops, True)) == ref_digests[key]
+    else:
+        _compare(algo, params, req[:n], pat[:n], txt[:n])
+
+
+@pytest.mark.parametrize("algo,kw", [("nw", dict(backtrace=True)), ("swg", dict(backtrace=True, swg_w16=True)), ("swg", dict(swg_w16=True))])
+@pytest.mark.parametrize("err", [0.02, 0.10])
+def test_dp_wave_strata_l100(gpu, monkeypatch, algo, kw, err):
+    """plen > tlen (tail cells / boundary aliasing), plen < tlen and plen == tlen through the row-scan path."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_FORCE_DPWAVE", "1")
+    ms, rs = engine.launcher_sizes(algo, 100, err)
+    req, pat, txt = engine.gen_pairs(4321, 0, 2000, 100, err, rs)
+    assert (req["pattern_len"] > req["text_len"] + (2 if err > 0.05 else 0)).any()
+    _compare(algo, engine.make_params(algo, ms, rs, **kw), req, pat, txt)
+
+
+@pytest.mark.parametrize("algo", ["nw", "swg"])
+@pytest.mark.parametrize("l,err,n", [(600, 0.05, 300), (1000, 0.05, 200), (3000, 0.02, 24)])
+def test_dp_wave_long_reads(gpu, algo, l, err, n):
+    from aim_amd import capi, engine
+    import ctypes as C
+    ms, rs = engine.launcher_sizes(algo, l, err)
+    req, pat, txt = engine.gen_pairs(l, 0, n, l, err, rs)
+    params = engine.make_params(algo, ms, rs, backtrace=True)
+    assert capi.load().aim_kernel_name(C.byref(params)) == b"dp_wave_kernel"
+    _compare(algo, params, req, pat, txt)
+    _compare(algo, engine.make_params(algo, ms, rs), req, pat, txt)
+
+
+def test_cfg4_swg_l10000_e1(gpu):
+    """BASELINE config 4 shape: SWG, l = 10 000, e = 1 % (MAX_SCORE 500 -> int16 cells, READ_SIZE 10112)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("swg", 10000, 0.01)
+    assert (ms, rs) == (500, 10112)
+    req, pat, txt = engine.gen_pairs(10, 0, 8, 10000, 0.01, rs)
+    assert (req["pattern_len"] > req["text_len"]).any() and (req["pattern_len"] < req["text_len"]).any()
+    res, _, _ = _compare("swg", engine.make_params("swg", ms, rs, backtrace=True), req, pat, txt, threads=4)
+    assert (res["score"] > 100).all()
+
+
+def test_dp_wave_exotic_and_literal_paths(gpu, monkeypatch):
+    """plen > 2*tlen (tail would spill past the next row) and configurations where an int16 store could wrap
+    take the literal single-lane path; both must still equal the oracle."""
+    from aim_amd import engine
+    rng = np.random.default_rng(5)
+    pairs = []
+    for _ in range(40):
+        pl, tl = int(rng.integers(1, 330)), int(rng.integers(1, 120))
+        p = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=pl).tolist())
+        t = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=tl).tolist())
+        pairs.append((p, t))
+    pairs += [(b"", b""), (b"ACGT" * 80, b"A"), (b"A", b"ACGT" * 80), (b"ACGT" * 60, b"ACGT" * 20), (b"", b"ACGT"), (b"ACGT", b"")]
+    req, pat, txt = _mk(pairs, 336)
+    assert (req["pattern_len"] > 2 * req["text_len"]).any()
+    for algo, ms, kw in (("nw", 40, dict(backtrace=True)), ("swg", 200, dict(backtrace=True)), ("swg", 40, dict(backtrace=True)),
+                         ("nw", 40, dict(backtrace=True, gap=50))):
+        _compare(algo, engine.make_params(algo, ms, 336, **kw), req, pat, txt, threads=2)
