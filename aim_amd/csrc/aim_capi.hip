@@ -238,7 +238,9 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         Plan fb = pl;
         fb.grid = pl.fb_grid;
         fb.lds = pl.fb_lds;
-        if (red) launch_wfa_wave<false, true>(fb, kb, stream);
+        if (bt && red) launch_wfa_wave<true, true>(fb, kb, stream);
+        else if (bt) launch_wfa_wave<true, false>(fb, kb, stream);
+        else if (red) launch_wfa_wave<false, true>(fb, kb, stream);
         else launch_wfa_wave<false, false>(fb, kb, stream);
         break;
     }

@@ -166,7 +166,7 @@ __device__ __forceinline__ uint32_t pack_row(const uint4 (&raw)[NP], int len, in
 enum : uint32_t { LANE_TODO_COUNT = 0, LANE_TODO_LIST = 16 };   // dword offsets inside the to-do region
 
 
-template <int X, int O, int E, int MAXS, int RS>
+template <int X, int O, int E, int MAXS, int RS, bool BT>
 __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs a)
 {
     constexpr WfShape<X, O, E, MAXS> SH{};
@@ -308,17 +308,128 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         if (!done) score = ms_run + 1;                              // wfa.c:368-376
         AIM_STAMP(5);                           // diagonals + WFA
 
+        int begin_offset = plen + tlen - 1;     // edit_cigar_allocate, wfa.c:57-67
+        int status = AIM_PAIR_OK;
+        if (BT && active && bad == 0u) {
+            // memset(cigar->operations, 'M', 2*READ_SIZE) (wfa.c:465): full rows, constant data, no VGPR image.
+            // Match runs of the backtrace then only move begin_offset; edit ops are patched in as bytes.
+            char *ops = a.ops + (uint64_t)pair * (2 * RS);
+            uint4 *orow = reinterpret_cast<uint4 *>(ops);
+            const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+#pragma unroll
+            for (int j = 0; j < (2 * RS) / 16; ++j) orow[j] = mm;
+            if (done) {
+                // affine_wavefronts_backtrace (wfa_backtracing.c:210-351) over the register-resident history.
+                // The fetchers (wfa_backtracing.c:73-172) become static select chains; kNone marks "no such cell"
+                // (score < 0, wavefronts[s] == NULL, d_null / iwavefront == NULL, k outside [klo, khi]).
+                constexpr int kNone = (int)0x80000000;
+                auto getM = [&](int s_, int k_) {
+                    int r = kNone;
+#pragma unroll
+                    for (int s2 = 0; s2 <= MAXS; ++s2)
+                        if (SH.present[s2])
+#pragma unroll
+                            for (int k2 = SH.lo[s2]; k2 <= SH.hi[s2]; ++k2) r = (s_ == s2 && k_ == k2) ? Mv[s2][k2 - SH.kmin] : r;
+                    return r;
+                };
+                auto getI = [&](int s_, int k_) {
+                    int r = kNone;
+#pragma unroll
+                    for (int s2 = 0; s2 <= MAXS; ++s2)
+                        if (SH.present[s2] && SH.hasI[s2])
+#pragma unroll
+                            for (int k2 = SH.lo[s2]; k2 <= SH.hi[s2]; ++k2) r = (s_ == s2 && k_ == k2) ? Iv[s2][k2 - SH.kmin] : r;
+                    return r;
+                };
+                auto getD = [&](int s_, int k_) {
+                    int r = kNone;
+#pragma unroll
+                    for (int s2 = 0; s2 <= MAXS; ++s2)
+                        if (SH.present[s2] && SH.hasD[s2])
+#pragma unroll
+                            for (int k2 = SH.lo[s2]; k2 <= SH.hi[s2]; ++k2) r = (s_ == s2 && k_ == k2) ? Dv[s2][k2 - SH.kmin] : r;
+                    return r;
+                };
+                auto valid_loc = [&](int kk_, int off_) {
+                    const int v_ = off_ - kk_, h_ = off_;
+                    return v_ > 0 && v_ <= plen && h_ > 0 && h_ <= tlen;
+                };
+                auto put = [&](char ch) {
+                    if (begin_offset >= 0 && begin_offset < 2 * RS) ops[begin_offset] = ch;
+                    --begin_offset;
+                };
+                enum { BT_M = 0, BT_I = 1, BT_D = 2 };
+                int sc = score, k = ak;
+                int offset = getM(sc, k);
+                bool valid = valid_loc(k, offset);
+                int bt = BT_M;
+                int v = offset - k, h = offset;
+                while (v > 0 && h > 0 && sc > 0) {
+                    if (!valid) {
+                        valid = valid_loc(k, offset);
+                        if (valid) {   // add_trailing_gap, wfa_backtracing.c:48-69
+                            if (k < ak) for (int i = k; i < ak; ++i) put('I');
+                            else if (k > ak) for (int i = ak; i < k; ++i) put('D');
+                        }
+                    }
+                    const int s_o = sc - (O + E), s_e = sc - E, s_x = sc - X;
+                    int del_ext = kLaneNull, del_open = kLaneNull, ins_ext = kLaneNull, ins_open = kLaneNull, misms = kLaneNull;
+                    if (bt != BT_I) {
+                        const int a1 = getD(s_e, k + 1), a2 = getM(s_o, k + 1);
+                        if (a1 != kNone) del_ext = a1;
+                        if (a2 != kNone) del_open = a2;
+                    }
+                    if (bt != BT_D) {
+                        const int a1 = getI(s_e, k - 1), a2 = getM(s_o, k - 1);
+                        if (a1 != kNone) ins_ext = a1 + 1;
+                        if (a2 != kNone) ins_open = a2 + 1;
+                    }
+                    if (bt == BT_M) {
+                        const int a1 = getM(s_x, k);
+                        if (a1 != kNone) misms = a1 + 1;
+                    }
+                    const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
+                    if (bt == BT_M) {
+                        const int num_matches = offset - max_all;
+                        if (num_matches > 0) begin_offset -= num_matches;   // 'M' already in place
+                        offset = max_all;
+                        v = offset - k;
+                        h = offset;
+                        if (v <= 0 || h <= 0) break;
+                    }
+                    char op;
+                    if (max_all == del_ext) { op = 'D'; sc = s_e; ++k; bt = BT_D; }
+                    else if (max_all == del_open) { op = 'D'; sc = s_o; ++k; bt = BT_M; }
+                    else if (max_all == ins_ext) { op = 'I'; sc = s_e; --k; --offset; bt = BT_I; }
+                    else if (max_all == ins_open) { op = 'I'; sc = s_o; --k; --offset; bt = BT_M; }
+                    else if (max_all == misms) { op = 'X'; sc = s_x; --offset; }
+                    else { status = AIM_PAIR_WFA_NO_LINK; break; }
+                    if (valid) put(op);
+                    v = offset - k;
+                    h = offset;
+                }
+                if (status == AIM_PAIR_OK) {
+                    if (sc == 0) {
+                        if (offset > 0) begin_offset -= offset;
+                    } else {
+                        for (; v > 0; --v) put('D');
+                        for (; h > 0; --h) put('I');
+                    }
+                    ++begin_offset;
+                }
+            }
+        }
         if (active) {
             if (bad != 0u) {   // non-ACGT byte inside a sequence: hand the pair to the general kernel
                 const uint32_t slot = atomicAdd(&todo[LANE_TODO_COUNT], 1u);
                 todo[LANE_TODO_LIST + slot] = pair;
             } else {
                 aim_result_t r;
-                r.max_operations = plen + tlen;        // edit_cigar_allocate, wfa.c:57-67
-                r.begin_offset = plen + tlen - 1;
+                r.max_operations = plen + tlen;
+                r.begin_offset = begin_offset;
                 r.end_offset = plen + tlen;
                 r.score = score;
-                r.status = AIM_PAIR_OK;
+                r.status = status;
                 r.idx = rq.idx;
                 a.res[pair] = r;
             }
@@ -343,7 +454,6 @@ constexpr uint32_t kLaneGrid = 256 * AIM_LANE_WGS_PER_CU;   // single-wave workg
 inline bool wfa_lane_supported(const aim_params_t &p)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
-    if (p.flags & AIM_FLAG_BACKTRACE) return false;               // CIGAR path: general kernel
     if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the reference's default penalties
     if (p.max_score > 5) return false;
     return p.read_size == 80 || p.read_size == 112;   // odd number of 16-B slots per row (conflict-free row reads)
@@ -365,7 +475,12 @@ inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *gri
 inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
 {
     (void)block;
-#define AIM_LANE_LAUNCH(RS) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS>), dim3(grid), dim3(kWave), lds, s, ka)
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+#define AIM_LANE_LAUNCH(RS)                                                                                          \
+    do {                                                                                                             \
+        if (bt) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS, true>), dim3(grid), dim3(kWave), lds, s, ka);    \
+        else hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS, false>), dim3(grid), dim3(kWave), lds, s, ka);      \
+    } while (0)
     switch (p.read_size) {
     case 80: AIM_LANE_LAUNCH(80); break;
     case 112: AIM_LANE_LAUNCH(112); break;

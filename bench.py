@@ -162,6 +162,8 @@ def main():
                         "sample": "%d passes over the same %d-pair batch, %d threads, %.1f s wall (oracle/aim_oracle.c)"
                                   % (passes, n, cores, spent)}
 
+    if args.backtrace:   # algorithmic bytes with CIGAR include the ops actually produced
+        alg_bytes += int((res_host["end_offset"].astype(np.int64) - res_host["begin_offset"]).sum())
     if rank == 0:
         total_pairs = world * n * args.steps
         value = total_pairs / elapsed

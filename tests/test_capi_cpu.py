@@ -79,6 +79,7 @@ def test_scratch_planning_is_pure(built):
         assert a > 0 and a == lib.aim_scratch_bytes(C.byref(p), 1 << 20)
     assert lib.aim_scratch_bytes(C.byref(engine.make_params("wfa", 5, 110)), 16) == 0   # invalid read_size
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112))) == b"wfa_lane_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True))) == b"wfa_wave_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True))) == b"wfa_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True, mismatch=4))) == b"wfa_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112))) == b"wfa_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_lane_kernel"
