@@ -56,6 +56,7 @@ struct Plan {
     size_t lds;             // dynamic LDS bytes
     uint64_t scratch_per_wg;
     uint32_t pool_cap, meta_cap;
+    uint32_t ring_slots, slot_w;
     bool seq_lds;
     size_t scratch_total;
     size_t todo_bytes;      // K_WFA_LANE: to-do region in front of the fallback kernel's scratch
@@ -134,12 +135,30 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
             cap = std::min(full, (R + 2) * 3 * (2 * ms + 3));
         }
         pl->meta_cap = (uint32_t)(ms + 2);
-        uint32_t grid = 256 * 16;
+        // LDS ring for the live window of wavefronts: max(x, o+e)+1 slots of slot_w diagonals (M, I, D)
+        {
+            const uint32_t R = (uint32_t)std::max(p.mismatch, p.gap_o + p.gap_e);
+            uint32_t w = 16;
+            while (w < 2 * (uint32_t)ms + 3 && w < 128) w *= 2;   // 128: keeps 16 workgroups resident per CU at l = 1000 (measured +9 % over 256)
+            if (const char *e = getenv("AIM_WFA_SLOTW")) w = (uint32_t)std::max(16, atoi(e)) & ~15u;
+            while (w > 16 && (uint64_t)(R + 1) * 3 * w * 2 > 24 * 1024) w /= 2;
+            const bool ring_ok = (uint64_t)(R + 1) * 3 * w * 2 <= 24 * 1024 && !(getenv("AIM_WFA_NO_RING") && getenv("AIM_WFA_NO_RING")[0] == '1');
+            pl->ring_slots = ring_ok ? R + 1 : 0;
+            pl->slot_w = ring_ok ? w : 0;
+        }
+        const size_t seq_bytes = 2 * ((size_t)p.read_size + 8);
+        pl->seq_lds = seq_bytes <= 40 * 1024;
+        const size_t ring_bytes = ((size_t)pl->ring_slots * 3 * pl->slot_w * sizeof(int16_t) + 15) & ~(size_t)15;
+        pl->lds = aim::kMetaRing * sizeof(aim::WfMeta) + ring_bytes + (pl->seq_lds ? seq_bytes : 0);
+        // persistent single-wave workgroups: exactly what is resident (4 waves/SIMD by VGPRs, 160 KiB LDS per CU);
+        // a larger grid runs in uneven rounds
+        const uint32_t wg_per_cu = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, (160 * 1024) / (pl->lds + 256)));
+        uint32_t grid = 256 * wg_per_cu;
         const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
         if (grid > need) grid = std::max(8u, need);
         uint64_t per = (uint64_t)pl->meta_cap * sizeof(aim::WfMeta) + cap * sizeof(int16_t);
         per = (per + 255) & ~255ull;
-        while (grid > 512 && per * grid > budget) grid /= 2;
+        while (grid > 512 && per * grid > budget) grid = ((grid / 2) + 7u) & ~7u;
         if (per * grid > budget) {   // shrink the pool; overflow then reports AIM_PAIR_NOMEM like the DPU arena
             const uint64_t meta_b = (uint64_t)pl->meta_cap * sizeof(aim::WfMeta);
             uint64_t avail = budget / grid;
@@ -150,9 +169,6 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         pl->grid = grid;
         pl->pool_cap = (uint32_t)std::min<uint64_t>(cap, 0x7fffffffu);
         pl->scratch_per_wg = per;
-        const size_t seq_bytes = 2 * ((size_t)p.read_size + 8);
-        pl->seq_lds = seq_bytes <= 40 * 1024;
-        pl->lds = aim::kMetaRing * sizeof(aim::WfMeta) + (pl->seq_lds ? seq_bytes : 0);
         pl->scratch_total = (size_t)(per * grid);
         return AIM_OK;
     }
@@ -217,6 +233,8 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
     ka.scratch_per_wave = pl.scratch_per_wg;
     ka.pool_cap = pl.pool_cap;
     ka.meta_cap = pl.meta_cap;
+    ka.ring_slots = pl.ring_slots;
+    ka.slot_w = pl.slot_w;
     ka.todo = nullptr;
     switch (pl.kid) {
     case K_WFA_WAVE:

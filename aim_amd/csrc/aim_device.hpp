@@ -24,6 +24,8 @@ struct KArgs {
     uint64_t scratch_per_wave;  // bytes
     uint32_t pool_cap;    // int16 entries per wave (WFA)
     uint32_t meta_cap;    // WfMeta entries per wave (WFA)
+    uint32_t ring_slots;  // WFA wave kernel: LDS offset ring, slots (0 = none) ...
+    uint32_t slot_w;      // ... and diagonals per slot
     const uint32_t *todo; // nullptr: units are pairs 0..n_pairs-1; else {count @0, pair ids @16..} written by wfa_lane
 };
 
@@ -45,14 +47,21 @@ __device__ __forceinline__ bool xcd_unit(uint32_t n_units, uint32_t it, uint32_t
     return true;
 }
 
+// Wave-wide minimum, result uniform.  DPP row operations + two row broadcasts (no LDS crossbar): the
+// classic gfx9 reduction ladder; lane 63 ends up with the minimum of all 64 lanes.
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off, kWave);
-        v = o < v ? o : v;
-    }
-    return v;
+    constexpr int big = 0x7fffffff;
+#define AIM_DPP_MIN(ctrl, rmask)                                                               \
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, ctrl, rmask, 0xf, false))
+    AIM_DPP_MIN(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    AIM_DPP_MIN(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    AIM_DPP_MIN(0x141, 0xf);   // row_half_mirror
+    AIM_DPP_MIN(0x140, 0xf);   // row_mirror  -> every lane holds its row's (16 lanes) minimum
+    AIM_DPP_MIN(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    AIM_DPP_MIN(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef AIM_DPP_MIN
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // 4 bytes starting at byte offset `off` of a dword array (little endian).

@@ -7,9 +7,13 @@
 // Mapping: lanes run along the diagonals k of the current wavefront (64 per
 // step, looping for wider wavefronts).  Sequences are staged once per pair in
 // LDS (the DPU's WRAM copy, wfa.c:417-459); the descriptors of the last 64
-// scores live in an LDS ring; the offset vectors (M/I/D per score) live in a
-// per-wave HBM scratch pool (the DPU's WRAM arena / MRAM spill,
-// allocate_new_score wfa.c:143-183) that stays L2-resident in practice.
+// scores live in an LDS ring; the offset vectors (M/I/D) of the live window --
+// the max(x, o+e)+1 most recent scores, all that affine_wfa_compute_next ever
+// reads -- live in a second LDS ring (one slot per score, slot_w diagonals), so a
+// score step costs LDS round trips, not L2 ones.  With BACKTRACE every
+// wavefront is also streamed to a per-wave HBM pool (the DPU's WRAM arena /
+// MRAM spill, allocate_new_score wfa.c:143-183) that the traceback walks; a
+// wavefront wider than a slot lives in that pool only (slower, same results).
 // Handles any MAX_SCORE / READ_SIZE / penalties; the short-read fast path is
 // wfa_lane.hpp.
 #pragma once
@@ -26,11 +30,11 @@ struct __attribute__((aligned(16))) WfMeta {
     int klo, khi;   // current (possibly reduced) bounds
     int lo, hi;     // allocation bounds (lo_base / hi_base)
     int off_m;      // pool index of M[lo]
-    int off_i;      // pool index of I[lo], -1 when iwavefront == NULL
-    int off_d;      // pool index of D[lo], -1 when dwavefront == NULL
+    int off_i;      // pool index of I[lo] (iwavefront != NULL <=> WF_HASI)
+    int off_d;      // pool index of D[lo] (dwavefront != NULL <=> WF_HASD)
     int flags;
 };
-enum { WF_PRESENT = 1, WF_MNULL = 2, WF_INULL = 4, WF_DNULL = 8 };
+enum { WF_PRESENT = 1, WF_MNULL = 2, WF_INULL = 4, WF_DNULL = 8, WF_INLDS = 16, WF_HASI = 32, WF_HASD = 64 };
 
 constexpr int kMetaRing = 64;        // scores kept in the LDS descriptor ring
 
@@ -82,7 +86,9 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
     const int rs = a.p.read_size;
     const int rsw = rs >> 2;                 // dwords per sequence row (read_size % 8 == 0)
     WfMeta *ring = reinterpret_cast<WfMeta *>(smem);
-    uint32_t *ldsP = reinterpret_cast<uint32_t *>(smem + kMetaRing * sizeof(WfMeta));
+    awf_t *oring = reinterpret_cast<awf_t *>(smem + kMetaRing * sizeof(WfMeta));
+    const int ring_slots = (int)a.ring_slots, slot_w = (int)a.slot_w;
+    uint32_t *ldsP = reinterpret_cast<uint32_t *>(smem + kMetaRing * sizeof(WfMeta) + (((size_t)ring_slots * 3 * slot_w * sizeof(awf_t) + 15) & ~(size_t)15));
     uint32_t *ldsT = ldsP + rsw + 2;
 
     char *wscr = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
@@ -95,7 +101,22 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
 
     const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e;
     const int MS = a.p.max_score;
+    // component comp (0 M, 1 I, 2 D) of the wavefront of score sc: LDS slot or HBM pool
+    auto slot = [&](int sc, int comp) -> awf_t * { return oring + ((sc % ring_slots) * 3 + comp) * slot_w; };
+    // row pointer (biased so that row[k] is diagonal k) -- computed once per score step, never per element
+    auto rowp = [&](const WfMeta &m, int sc, int comp) -> const awf_t * {
+        const awf_t *b = (m.flags & WF_INLDS) ? slot(sc, comp) : pool + (comp == 0 ? m.off_m : (comp == 1 ? m.off_i : m.off_d));
+        return b - m.lo;
+    };
 
+    // Single-wave workgroup: LDS operations of one wave execute in issue order, so data exchanged through LDS
+    // needs no hardware wait, only a compiler fence.  __syncthreads() would add s_waitcnt vmcnt(0), i.e. a full
+    // round trip for the history / descriptor stores still in flight -- only paid when a row lives in the HBM pool.
+    const bool meta_in_lds = max(X, OE) < kMetaRing;
+    auto sync = [&](bool rows_in_lds) {
+        if (rows_in_lds && meta_in_lds) asm volatile("" ::: "memory");
+        else __syncthreads();
+    };
     // direct mode: every pair of the batch; indirect mode: the pairs the lane kernel could not pack
     const uint32_t n_units = a.todo ? min(a.todo[0], a.n_pairs) : a.n_pairs;
 
@@ -134,9 +155,12 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
         WfMeta cur;
         cur.klo = cur.khi = cur.lo = cur.hi = 0;
         cur.off_m = 0; cur.off_i = -1; cur.off_d = -1;
-        cur.flags = WF_PRESENT | WF_INULL | WF_DNULL;
+        cur.flags = WF_PRESENT | WF_INULL | WF_DNULL | (ring_slots > 0 ? WF_INLDS : 0);
         ctx.cur_score = 0;
-        if (lane == 0) pool[0] = 0;
+        if (lane == 0) {
+            pool[0] = 0;
+            if (ring_slots > 0) slot(0, 0)[0] = 0;
+        }
         wf_put_meta(ctx, 0, cur, lane);
         __syncthreads();
 
@@ -145,27 +169,36 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
             const bool live = (cur.flags & WF_PRESENT) && !(cur.flags & WF_MNULL);
             // ---- affine_wfa_extend, wfa.c:186-208 -------------------------------
             if (live) {
-                for (int k = cur.klo + lane; k <= cur.khi; k += kWave) {
-                    const int idx = cur.off_m + (k - cur.lo);
-                    const int moff = pool[idx];
-                    if (moff >= 0) {
-                        const int cnt = SEQ_LDS
-                            ? wf_extend_count((const uint32_t *)ldsP, (const uint32_t *)ldsT, moff - k, moff, plen, tlen, last_word)
-                            : wf_extend_count(gP, gT, moff - k, moff, plen, tlen, last_word);
-                        if (cnt) pool[idx] = (awf_t)(moff + cnt);
+                const bool inlds = cur.flags & WF_INLDS;
+                // one body, two call sites: after inlining the LDS call site compiles to ds_read/ds_write and the
+                // pool call site to global loads/stores (a merged pointer would force flat accesses)
+                auto extend_row = [&](awf_t *mrow) {
+                    for (int k = cur.klo + lane; k <= cur.khi; k += kWave) {
+                        const int moff = mrow[k - cur.lo];
+                        if (moff >= 0) {
+                            const int cnt = SEQ_LDS
+                                ? wf_extend_count((const uint32_t *)ldsP, (const uint32_t *)ldsT, moff - k, moff, plen, tlen, last_word)
+                                : wf_extend_count(gP, gT, moff - k, moff, plen, tlen, last_word);
+                            if (cnt) mrow[k - cur.lo] = (awf_t)(moff + cnt);
+                            if (BT && inlds) pool[cur.off_m + (k - cur.lo)] = (awf_t)(moff + cnt);   // HBM history for the traceback
+                        } else if (BT && inlds) {
+                            pool[cur.off_m + (k - cur.lo)] = (awf_t)moff;
+                        }
                     }
-                }
-                __syncthreads();
+                };
+                if (inlds) extend_row(slot(score, 0));
+                else extend_row(pool + cur.off_m);
+                sync(inlds);
             }
             // ---- affine_wfa_reduce_wvs (WFA-adaptive), wfa.c:69-140 --------------
             if (REDUCE && live && (cur.khi - cur.klo + 1) >= 10) {
+                auto reduce_row = [&](const awf_t *mk) {
                 int mind = max(plen, tlen);
-                for (int base = cur.klo; base <= cur.khi; base += kWave) {
-                    const int k = base + lane;
-                    int d = 0x7fffffff;
-                    if (k <= cur.khi) {
-                        const int off = pool[cur.off_m + (k - cur.lo)];
-                        d = max(plen - (off - k), tlen - off);
+                {
+                    int d = 0x7fffffff;   // per-lane minimum over its diagonals, then ONE wave reduction
+                    for (int k = cur.klo + lane; k <= cur.khi; k += kWave) {
+                        const int off = mk[k];
+                        d = min(d, max(plen - (off - k), tlen - off));
                     }
                     mind = min(mind, wave_min_i32(d));
                 }
@@ -177,7 +210,7 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                         const int k = base + lane;
                         bool ok = false;
                         if (k < top_limit) {
-                            const int off = pool[cur.off_m + (k - cur.lo)];
+                            const int off = mk[k];
                             ok = (max(plen - (off - k), tlen - off) - mind) <= 50;
                         }
                         const unsigned long long mask = __ballot(ok);
@@ -192,7 +225,7 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                         const int k = top - lane;
                         bool ok = false;
                         if (k > bottom_limit) {
-                            const int off = pool[cur.off_m + (k - cur.lo)];
+                            const int off = mk[k];
                             ok = (max(plen - (off - k), tlen - off) - mind) <= 50;
                         }
                         const unsigned long long mask = __ballot(ok);
@@ -207,12 +240,15 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                     cur.khi = nkhi;
                 }
                 wf_put_meta(ctx, score, cur, lane);
-                __syncthreads();
+                sync(true);
+                };
+                if (cur.flags & WF_INLDS) reduce_row(slot(score, 0) - cur.lo);
+                else reduce_row(pool + cur.off_m - cur.lo);
             }
             // ---- affine_wfa_end_reached, wfa.c:210-230 ---------------------------
             bool done = false;
             if ((cur.flags & WF_PRESENT) && !(cur.flags & WF_MNULL) && cur.klo <= ak && cur.khi >= ak) {
-                const int off = pool[cur.off_m + (ak - cur.lo)];
+                const int off = (cur.flags & WF_INLDS) ? (int)slot(score, 0)[ak - cur.lo] : (int)pool[cur.off_m + (ak - cur.lo)];
                 done = off >= tlen;
             }
             if (done) { final_score = score; break; }
@@ -229,8 +265,8 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
             if (s_e >= 0) me = wf_get_meta(ctx, s_e);
             const bool m_sub_null = (s_sub < 0) || !(ms.flags & WF_PRESENT) || (ms.flags & WF_MNULL);
             const bool m_o_null = (s_o < 0) || !(mo.flags & WF_PRESENT) || (mo.flags & WF_MNULL);
-            const bool i_e_null = (s_e < 0) || !(me.flags & WF_PRESENT) || me.off_i < 0 || (me.flags & WF_INULL);
-            const bool d_e_null = (s_e < 0) || !(me.flags & WF_PRESENT) || me.off_d < 0 || (me.flags & WF_DNULL);
+            const bool i_e_null = (s_e < 0) || !(me.flags & WF_PRESENT) || !(me.flags & WF_HASI) || (me.flags & WF_INULL);
+            const bool d_e_null = (s_e < 0) || !(me.flags & WF_PRESENT) || !(me.flags & WF_HASD) || (me.flags & WF_DNULL);
             const bool i_out_null = m_o_null && i_e_null;
             const bool d_out_null = m_o_null && d_e_null;
             if (m_sub_null && i_out_null && d_out_null) {
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                 cur.klo = cur.lo = 0; cur.khi = cur.hi = -1;
                 cur.off_m = cur.off_i = cur.off_d = -1;
                 wf_put_meta(ctx, score, cur, lane);
-                __syncthreads();
+                sync(true);
                 continue;
             }
             const int sub_lo = m_sub_null ? 1 : ms.klo, sub_hi = m_sub_null ? -1 : ms.khi;
@@ -249,8 +285,11 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
             const int hi = max(max(sub_hi, o_hi), e_hi) + 1;
             const int len = hi - lo + 1;
             const int narr = 1 + (d_out_null ? 0 : 1) + (i_out_null ? 0 : 1);
-            // allocate_new_score, wfa.c:143-183
-            if (pool_used + len * narr > pool_cap) {
+            // allocate_new_score, wfa.c:143-183: an LDS slot when the wavefront fits one; an HBM pool
+            // region when it does not, and always with BACKTRACE (history)
+            const bool inlds = ring_slots > 0 && len <= slot_w;
+            const bool in_pool = BT || !inlds;
+            if (in_pool && pool_used + len * narr > pool_cap) {
                 if (BT) {   // allocate_new(): "out of memory" + exit(1), dpu_allocator_wram.c:19-23
                     status = AIM_PAIR_NOMEM;
                     final_score = score;
@@ -258,38 +297,53 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                 }
                 pool_used = 0;   // score-only: the pool is a ring sized for the live window
             }
-            cur.flags = WF_PRESENT | (i_out_null ? WF_INULL : 0) | (d_out_null ? WF_DNULL : 0);
+            cur.flags = WF_PRESENT | (i_out_null ? WF_INULL : WF_HASI) | (d_out_null ? WF_DNULL : WF_HASD) | (inlds ? WF_INLDS : 0);
             cur.klo = cur.lo = lo;
             cur.khi = cur.hi = hi;
-            cur.off_m = pool_used;
-            cur.off_d = d_out_null ? -1 : pool_used + len;
-            cur.off_i = i_out_null ? -1 : pool_used + len * (d_out_null ? 1 : 2);
-            pool_used += len * narr;
+            cur.off_m = in_pool ? pool_used : -1;
+            cur.off_d = (d_out_null || !in_pool) ? -1 : pool_used + len;
+            cur.off_i = (i_out_null || !in_pool) ? -1 : pool_used + len * (d_out_null ? 1 : 2);
+            if (in_pool) pool_used += len * narr;
             wf_put_meta(ctx, score, cur, lane);
-
-            // affine_wfa_compute_offsets, wfa.c:231-266
-            for (int k = lo + lane; k <= hi; k += kWave) {
-                int ins = -10;
-                if (!i_out_null) {
-                    const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? (int)pool[mo.off_m + (k - 1 - mo.lo)] : kAwfNull;
-                    const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? (int)pool[me.off_i + (k - 1 - me.lo)] : kAwfNull;
-                    ins = (ins_g == kAwfNull && ins_i == kAwfNull) ? kAwfNull : (int)(awf_t)(max(ins_g, ins_i) + 1);
-                    pool[cur.off_i + (k - lo)] = (awf_t)ins;
+            // affine_wfa_compute_offsets, wfa.c:231-266 -- one body, LDS-typed and generic call sites (see extend)
+            auto compute_row = [&](const awf_t *r_mo, const awf_t *r_ie, const awf_t *r_de, const awf_t *r_ms, awf_t *om, awf_t *oi,
+                                   awf_t *od) {
+                for (int k = lo + lane; k <= hi; k += kWave) {
+                    int ins = -10;
+                    if (!i_out_null) {
+                        const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? (int)r_mo[k - 1] : kAwfNull;
+                        const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? (int)r_ie[k - 1] : kAwfNull;
+                        ins = (ins_g == kAwfNull && ins_i == kAwfNull) ? kAwfNull : (int)(awf_t)(max(ins_g, ins_i) + 1);
+                        oi[k - lo] = (awf_t)ins;
+                        if (BT && inlds) pool[cur.off_i + (k - lo)] = (awf_t)ins;
+                    }
+                    int del = -10;
+                    if (!d_out_null) {
+                        const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? (int)r_mo[k + 1] : kAwfNull;
+                        const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? (int)r_de[k + 1] : kAwfNull;
+                        del = max(del_g, del_d);
+                        od[k - lo] = (awf_t)del;
+                        if (BT && inlds) pool[cur.off_d + (k - lo)] = (awf_t)del;
+                    }
+                    int sub = -10;
+                    if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(awf_t)(r_ms[k] + 1) : kAwfNull;
+                    om[k - lo] = (awf_t)max(del, max(sub, ins));
                 }
-                int del = -10;
-                if (!d_out_null) {
-                    const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? (int)pool[mo.off_m + (k + 1 - mo.lo)] : kAwfNull;
-                    const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? (int)pool[me.off_d + (k + 1 - me.lo)] : kAwfNull;
-                    del = max(del_g, del_d);
-                    pool[cur.off_d + (k - lo)] = (awf_t)del;
-                }
-                int sub = -10;
-                if (!m_sub_null)
-                    sub = (sub_lo <= k && k <= sub_hi) ? (int)(awf_t)(pool[ms.off_m + (k - ms.lo)] + 1) : kAwfNull;
-                pool[cur.off_m + (k - lo)] = (awf_t)max(del, max(sub, ins));
+            };
+            const bool all_lds = inlds && (m_o_null || (mo.flags & WF_INLDS)) && (e_none || (me.flags & WF_INLDS)) &&
+                                 (m_sub_null || (ms.flags & WF_INLDS));
+            if (all_lds) {
+                compute_row(slot(s_o < 0 ? 0 : s_o, 0) - mo.lo, slot(s_e < 0 ? 0 : s_e, 1) - me.lo, slot(s_e < 0 ? 0 : s_e, 2) - me.lo,
+                            slot(s_sub < 0 ? 0 : s_sub, 0) - ms.lo, slot(score, 0), slot(score, 1), slot(score, 2));
+            } else {
+                compute_row(m_o_null ? nullptr : rowp(mo, s_o, 0), i_e_null ? nullptr : rowp(me, s_e, 1),
+                            d_e_null ? nullptr : rowp(me, s_e, 2), m_sub_null ? nullptr : rowp(ms, s_sub, 0),
+                            inlds ? slot(score, 0) : pool + cur.off_m, inlds ? slot(score, 1) : pool + cur.off_i,
+                            inlds ? slot(score, 2) : pool + cur.off_d);
             }
-            __syncthreads();
+            sync(inlds);
         }
+        __syncthreads();   // history and descriptors in HBM are complete before the traceback reads them
 
         // ---- affine_wavefronts_backtrace, wfa_backtracing.c:210-351 ---------------
         // Wave-uniform scalar walk; the ops row is pre-filled with 'M' so match
@@ -336,7 +390,7 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                         del_open = pool[mo.off_m + (k + 1 - mo.lo)];
                 }
                 if (bt != BT_D) {
-                    if ((me.flags & WF_PRESENT) && me.off_i >= 0 && me.klo <= k - 1 && k - 1 <= me.khi)
+                    if ((me.flags & WF_PRESENT) && (me.flags & WF_HASI) && me.klo <= k - 1 && k - 1 <= me.khi)
                         ins_ext = (awf_t)(pool[me.off_i + (k - 1 - me.lo)] + 1);
                     if ((mo.flags & WF_PRESENT) && mo.klo <= k - 1 && k - 1 <= mo.khi)
                         ins_open = (awf_t)(pool[mo.off_m + (k - 1 - mo.lo)] + 1);

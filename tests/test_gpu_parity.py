@@ -380,3 +380,21 @@ def test_dp_wave_exotic_and_literal_paths(gpu, monkeypatch):
     for algo, ms, kw in (("nw", 40, dict(backtrace=True)), ("swg", 200, dict(backtrace=True)), ("swg", 40, dict(backtrace=True)),
                          ("nw", 40, dict(backtrace=True, gap=50))):
         _compare(algo, engine.make_params(algo, ms, 336, **kw), req, pat, txt, threads=2)
+
+
+@pytest.mark.parametrize("env", [dict(AIM_WFA_NO_RING="1"), dict(AIM_WFA_SLOTW="16"), dict(AIM_WFA_SLOTW="64")])
+def test_wfa_wave_storage_modes(gpu, monkeypatch, env):
+    """The general WFA kernel keeps the live wavefront window in an LDS ring; wavefronts wider than a slot (forced
+    here with tiny slots) and the ring-less mode live in the HBM pool.  All modes must give the same results."""
+    from aim_amd import engine
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("AIM_FORCE_WAVE", "1")
+    ms, rs = engine.launcher_sizes("wfa", 1000, 0.05)
+    req, pat, txt = engine.gen_pairs(21, 0, 200, 1000, 0.05, rs)
+    for kw in (dict(backtrace=True, reduce=True), dict(backtrace=True), dict(reduce=True), dict()):
+        _compare("wfa", engine.make_params("wfa", ms, rs, **kw), req, pat, txt)
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.10)
+    req, pat, txt = engine.gen_pairs(22, 0, 1500, 100, 0.10, rs)
+    for kw in (dict(backtrace=True, reduce=True), dict()):
+        _compare("wfa", engine.make_params("wfa", ms, rs, **kw), req, pat, txt)
