@@ -398,3 +398,75 @@ def test_wfa_wave_storage_modes(gpu, monkeypatch, env):
     req, pat, txt = engine.gen_pairs(22, 0, 1500, 100, 0.10, rs)
     for kw in (dict(backtrace=True, reduce=True), dict()):
         _compare("wfa", engine.make_params("wfa", ms, rs, **kw), req, pat, txt)
+
+
+# ------------------------------------------------------------------ BASELINE full sizes: properties + bit-exactness
+def _cigar_properties(req, pat, txt, res, ops, mismatch, gap_o, gap_e, check_score):
+    """Size-independent properties of a (score, CIGAR) answer: the ops consume exactly the pattern (M/X/D) and the text
+    (M/X/I), 'M' only over equal bases and 'X' only over different ones, and the affine cost of the CIGAR equals the score."""
+    n = len(req)
+    for i in range(n):
+        b, e = int(res["begin_offset"][i]), int(res["end_offset"][i])
+        o = ops[i, b:e]
+        pl, tl = int(req["pattern_len"][i]), int(req["text_len"][i])
+        is_m, is_x, is_i, is_d = (o == ord("M")), (o == ord("X")), (o == ord("I")), (o == ord("D"))
+        assert (is_m | is_x | is_i | is_d).all()
+        adv_p = (is_m | is_x | is_d).astype(np.int64)
+        adv_t = (is_m | is_x | is_i).astype(np.int64)
+        assert adv_p.sum() == pl and adv_t.sum() == tl, i
+        pi = np.cumsum(adv_p) - adv_p
+        ti = np.cumsum(adv_t) - adv_t
+        diag = is_m | is_x
+        eq = pat[i, pi[diag]] == txt[i, ti[diag]]
+        assert (eq == is_m[diag]).all(), i
+        if check_score:
+            gap = is_i | is_d
+            kind = np.where(is_i, 1, np.where(is_d, 2, 0))
+            opens = gap & np.concatenate(([True], kind[1:] != kind[:-1]))
+            cost = mismatch * int(is_x.sum()) + gap_e * int(gap.sum()) + gap_o * int(opens.sum())
+            assert cost == int(res["score"][i]), (i, cost, int(res["score"][i]))
+
+
+def test_cfg3_full_size_262144_pairs(gpu):
+    """BASELINE config 3 at full size: WFA-adaptive with CIGAR, l=1000, e=5%, 262 144 pairs -- bit-exact against the
+    oracle over the whole batch (scores, offsets) plus CIGAR properties on a sample."""
+    from aim_amd import engine
+    from oracle import oracle
+    n = 1 << 18
+    ms, rs = engine.launcher_sizes("wfa", 1000, 0.05)
+    req, pat, txt = engine.gen_pairs(3, 0, n, 1000, 0.05, rs)
+    params = engine.make_params("wfa", ms, rs, backtrace=True, reduce=True)
+    res, ops = engine.align(params, req, pat, txt)
+    op = oracle.params("wfa", ms, rs, backtrace=True, reduce=True)
+    ores, oops, worst = oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=min(64, os.cpu_count() or 8))
+    assert worst == 0
+    for f in ("score", "begin_offset", "end_offset", "max_operations"):
+        assert np.array_equal(res[f], ores[f]), f
+    # every CIGAR byte inside [begin, end): rows are compared with a mask
+    col = np.arange(ops.shape[1])[None, :]
+    inside = (col >= res["begin_offset"][:, None]) & (col < res["end_offset"][:, None])
+    assert np.array_equal(np.where(inside, ops, 0), np.where(inside, oops, 0))
+    _cigar_properties(req[:512], pat[:512], txt[:512], res[:512], ops[:512], 3, 4, 1, check_score=True)
+
+
+def test_cfg4_full_size_1024_pairs_properties(gpu, monkeypatch):
+    """BASELINE config 4 at full size: SWG with CIGAR, l=10 000, e=1%, 1024 pairs.  The CPU oracle needs 0.6 GB and
+    ~0.5 s per pair, so the whole batch is checked through properties and a 48-pair subset bit-exactly."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_SCRATCH_GB", "64")
+    n = 1024
+    ms, rs = engine.launcher_sizes("swg", 10000, 0.01)
+    req, pat, txt = engine.gen_pairs(4, 0, n, 10000, 0.01, rs)
+    params = engine.make_params("swg", ms, rs, backtrace=True)
+    res, ops = engine.align(params, req, pat, txt)
+    assert np.array_equal(res["idx"], np.arange(n, dtype=np.uint32)) and (res["status"] == 0).all()
+    # the alignment properties only hold where the reference's flat-index aliasing (S1) is not in play: with
+    # plen > tlen the reference itself emits CIGARs that put 'M' over different bases (checked against the oracle)
+    ok = req["pattern_len"] <= req["text_len"]
+    assert 200 < ok.sum() < 900
+    _cigar_properties(req[ok], pat[ok], txt[ok], res[ok], ops[ok], 3, 4, 1, check_score=True)
+    for i in np.nonzero(~ok)[0]:
+        o = ops[i, res["begin_offset"][i]:res["end_offset"][i]]
+        assert np.isin(o, np.frombuffer(b"MXID", dtype=np.uint8)).all()
+    sub = slice(0, 48)
+    _compare("swg", params, req[sub], pat[sub], txt[sub], threads=8)
