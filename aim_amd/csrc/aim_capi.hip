@@ -20,6 +20,7 @@
 #include "aim_device.hpp"
 #include "wfa_wave.hpp"
 #include "wfa_lane.hpp"
+#include "wfa_group.hpp"
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
 
@@ -47,7 +48,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4 };
 
 struct Plan {
     KernelId kid;
@@ -60,9 +61,11 @@ struct Plan {
     bool seq_lds;
     size_t scratch_total;
     size_t todo_bytes;      // K_WFA_LANE: to-do region in front of the fallback kernel's scratch
-    uint32_t fb_grid;       // K_WFA_LANE: grid / LDS of the fallback (general) kernel
+    uint32_t fb_grid;       // K_WFA_LANE / K_WFA_GROUP: grid / LDS of the fallback (general) kernel
     size_t fb_lds;
     bool no_lane;
+    aim::GroupCfg gcfg;     // K_WFA_GROUP
+    int group_g;
 };
 
 uint64_t scratch_budget_bytes()
@@ -107,7 +110,15 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
     const uint64_t budget = scratch_budget_bytes();
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     if (p.algo == AIM_ALGO_WFA) {
-        if (!force_wave_kernel() && !pl->no_lane && aim::wfa_lane_supported(p)) {
+        const bool lane_ok = !force_wave_kernel() && !pl->no_lane && aim::wfa_lane_supported(p);
+        aim::GroupCfg gc;
+        int gg = 0;
+        uint32_t ggrid = 0;
+        size_t glds = 0;
+        const bool no_group = getenv("AIM_NO_GROUP") && getenv("AIM_NO_GROUP")[0] == '1';
+        const bool group_ok = !lane_ok && !force_wave_kernel() && !pl->no_lane && !no_group &&
+                              aim::wfa_group_plan(p, n_pairs, &gc, &gg, &ggrid, &glds);
+        if (lane_ok || group_ok) {
             // fast path + the general kernel in to-do mode behind it (its plan goes into *pl first)
             Plan fb;
             memset(&fb, 0, sizeof fb);
@@ -115,10 +126,19 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
             rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), &fb);
             if (rc) return rc;
             *pl = fb;
-            pl->kid = K_WFA_LANE;
             pl->fb_grid = fb.grid;
             pl->fb_lds = fb.lds;
-            aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+            if (lane_ok) {
+                pl->kid = K_WFA_LANE;
+                aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+            } else {
+                pl->kid = K_WFA_GROUP;
+                pl->gcfg = gc;
+                pl->group_g = gg;
+                pl->grid = ggrid;
+                pl->block = 64;
+                pl->lds = glds;
+            }
             pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
             pl->scratch_total = pl->todo_bytes + fb.scratch_total;
             return AIM_OK;
@@ -243,11 +263,13 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         else if (red) launch_wfa_wave<false, true>(pl, ka, stream);
         else launch_wfa_wave<false, false>(pl, ka, stream);
         break;
-    case K_WFA_LANE: {
-        // [to-do region | general kernel scratch]: count zeroed per launch, lane kernel, then the drain
+    case K_WFA_LANE:
+    case K_WFA_GROUP: {
+        // [to-do region | general kernel scratch]: count zeroed per launch, fast kernel, then the drain
         HIP_TRY(hipMemsetAsync(d_scratch, 0, 64, stream));
         ka.scratch_per_wave = pl.todo_bytes;   // (diagnostic builds park their stamps behind the to-do region)
-        aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
+        if (pl.kid == K_WFA_LANE) aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
+        else aim::wfa_group_launch(p, pl.group_g, pl.gcfg, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         aim::KArgs kb = ka;
         kb.todo = reinterpret_cast<const uint32_t *>(d_scratch);
@@ -496,7 +518,7 @@ int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback
     Plan pl;
     int rc = make_plan(set->params, set->max_pairs, &pl);
     if (rc) return rc;
-    if (pl.kid != K_WFA_LANE || d.n_pairs == 0) return AIM_OK;
+    if ((pl.kid != K_WFA_LANE && pl.kid != K_WFA_GROUP) || d.n_pairs == 0) return AIM_OK;
     HIP_TRY(hipSetDevice(d.dev));
     HIP_TRY(hipMemcpy(n_fallback, d.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return AIM_OK;
@@ -556,6 +578,7 @@ const char *aim_kernel_name(const aim_params_t *params)
     switch (pl.kid) {
     case K_WFA_WAVE: return "wfa_wave_kernel";
     case K_WFA_LANE: return "wfa_lane_kernel";
+    case K_WFA_GROUP: return "wfa_group_kernel";
     case K_DP_LANE: return p_is_nw(params) ? "nw_lane_kernel" : "swg_lane_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
     }

@@ -1,0 +1,350 @@
+// wfa_group.hpp -- short-read WFA / WFA-adaptive for ANY penalties / MAX_SCORE (score-only): G LANES PER PAIR,
+// 64/G pairs per wavefront, everything after the HBM->LDS DMA in LDS and registers.
+//
+// Same results as affine_wfa_compute (WFA/DPU-WRAM/dpu/wfa.c:342-379, with -DREDUCE wfa.c:69-140).  The static
+// kernel (wfa_lane.hpp) covers the reference's default shape at MAX_SCORE <= 5; this one covers the rest of the
+// short-read space (READ_SIZE <= 512, MAX_SCORE up to ~120) at run-time parameters:
+//   * a pair is owned by G consecutive lanes (G = 1,2,4,8,16, picked so that the wavefront window of all 64/G
+//     pairs of a wavefront fits ~24 KiB of LDS); the lanes of a group take the diagonals k = lo+g, lo+g+G, ...
+//   * the live window of wavefronts -- M for the last max(x,o+e)+1 scores, I and D for the last e+1 -- lives in
+//     LDS as int16, indexed [ring slot][k + MAX_SCORE + 1], so every diagonal a score can ever touch has a fixed
+//     home and the +/-1 neighbours of affine_wfa_compute_offsets (wfa.c:231-266) are plain LDS reads;
+//   * sequences arrive by LDS-DMA exactly as in wfa_lane.hpp, are validated (A/C/G/T only) and packed 2 bits per
+//     base into LDS; affine_wfa_extend (wfa.c:186-208) compares 16 bases per step with funnel shifts;
+//   * per-pair descriptors (klo, khi, flags) sit in a small LDS ring, so WFA-adaptive's per-pair bounds
+//     (wfa.c:96-139) cost nothing when they do not fire.
+// Pairs with non-ACGT bytes go to the to-do list drained by wfa_wave_kernel, as in wfa_lane.hpp.
+#pragma once
+
+#include "aim_device.hpp"
+#include "wfa_lane.hpp"
+
+#ifndef AIM_GROUP_WGS_PER_CU
+#define AIM_GROUP_WGS_PER_CU 8   // persistent single-wave workgroups per CU (cap; LDS may allow fewer)
+#endif
+
+namespace aim {
+
+struct GroupCfg {
+    int kbias;        // MAX_SCORE + 1: slot index of diagonal k is k + kbias
+    int wcap;         // 2*MAX_SCORE + 3 entries per ring row
+    int ring_m;       // power of two > max(x, o+e)
+    int ring_e;       // power of two > e
+    int np;           // packed dwords per sequence (READ_SIZE/16 rounded up) + 1 pad
+    int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)
+    int rows_per_wave;
+};
+
+enum { GF_PRESENT = 1, GF_MNULL = 2, GF_INULL = 4, GF_DNULL = 8, GF_HASI = 16, GF_HASD = 32 };
+constexpr int kGrpNull = -16384;
+
+template <int G, bool REDUCE>
+__global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PPW = kWave / G;                       // pairs per wavefront
+    const int lane = threadIdx.x;
+    const int g = lane % G, q = lane / G;
+    const int rs = a.p.read_size;
+    uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);                    // raw rows, PPW * rs bytes each
+    uint32_t *rowsT = rowsP + (PPW * rs) / 4;
+    uint32_t *pairmem = rowsT + (PPW * rs) / 4 + ((2 * PPW * rs / 4) & 1 ? 1 : 0);
+    // per-pair region
+    uint32_t *mine = pairmem + q * c.pair_dwords;
+    int16_t *Mw = reinterpret_cast<int16_t *>(mine);                        // [ring_m][wcap]
+    int16_t *Iw = Mw + c.ring_m * c.wcap;                                    // [ring_e][wcap]
+    int16_t *Dw = Iw + c.ring_e * c.wcap;                                    // [ring_e][wcap]
+    int16_t *meta = Dw + c.ring_e * c.wcap;                                  // [ring_m][4] = klo, khi, flags, pad
+    uint32_t *packed = mine + ((c.ring_m + 2 * c.ring_e) * c.wcap * 2 + c.ring_m * 8 + 3) / 4;   // P then T, np dwords each
+    uint32_t *pkP = packed, *pkT = packed + c.np;
+
+    const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
+    const int kb = c.kbias;
+    uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
+    const uint32_t n_units = (a.n_pairs + PPW - 1) / PPW;
+    const int nchunk_total = (PPW * rs) / 16;            // 16-B chunks per array per unit (PPW*rs % 16 == 0, checked by the planner)
+
+    auto dma = [&](uint32_t unit) {
+        const uint32_t pair0 = unit * PPW;
+        const uint32_t rows = min((uint32_t)PPW, a.n_pairs - pair0);
+        const int nchunks = (int)((rows * rs + 15) / 16);
+        const char *gp = a.patterns + (uint64_t)pair0 * rs, *gt = a.texts + (uint64_t)pair0 * rs;
+        for (int base = 0; base < nchunk_total; base += kWave) {
+            const int ch = base + lane;
+            if (ch < nchunks) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)ch * 16),
+                                                 (__attribute__((address_space(3))) void *)(rowsP + base * 4), 16, 0, AIM_LANE_DMA_AUX);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gt + (size_t)ch * 16),
+                                                 (__attribute__((address_space(3))) void *)(rowsT + base * 4), 16, 0, AIM_LANE_DMA_AUX);
+            }
+        }
+    };
+    auto mslot = [&](int s) { return Mw + (s & (c.ring_m - 1)) * c.wcap + kb; };   // row pointer biased: row[k]
+    auto islot = [&](int s) { return Iw + (s & (c.ring_e - 1)) * c.wcap + kb; };
+    auto dslot = [&](int s) { return Dw + (s & (c.ring_e - 1)) * c.wcap + kb; };
+    auto fence = [&]() { asm volatile("" ::: "memory"); };   // same-wave LDS traffic is ordered; compiler fence only
+
+    uint32_t unit;
+    bool have = xcd_unit(n_units, 0, &unit);
+    aim_request_t rq_next;
+    rq_next.pattern_len = rq_next.text_len = 0; rq_next.padding = 0; rq_next.idx = 0;
+    if (have) {
+        dma(unit);
+        if (unit * PPW + q < a.n_pairs) rq_next = a.req[unit * PPW + q];
+    }
+    for (uint32_t it = 0; have; ++it) {
+        const uint32_t pair = unit * PPW + q;
+        const bool active = pair < a.n_pairs;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        const aim_request_t rq = rq_next;
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        // ---- validate + pack: the G lanes of a group split the packed dwords of their pair ------------------------
+        uint32_t bad = 0;
+        {
+            const uint32_t *rp = rowsP + (q * rs) / 4, *rt = rowsT + (q * rs) / 4;
+            const int npw = (rs + 15) / 16;
+            for (int j = g; j < npw; j += G) {
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const uint32_t *r = side ? rt : rp;
+                    const int len = side ? tlen : plen;
+                    uint32_t out = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int w = 4 * j + i;
+                        const uint32_t av = (4 * w < rs) ? r[w] : 0u;
+                        const uint32_t t = (av >> 1) & 0x03030303u;
+                        const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);
+                        const int rem = len - 4 * w;
+                        const uint32_t mask = rem >= 4 ? ~0u : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+                        bad |= (rec ^ av) & mask;
+                        out |= __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false) << (8 * i);
+                    }
+                    (side ? pkT : pkP)[j] = out;
+                }
+            }
+            if (g == 0) { pkP[c.np - 1] = 0u; pkT[c.np - 1] = 0u; }
+        }
+        // group-wide "bad": OR over the G lanes
+        {
+            const unsigned long long bm = __ballot(bad != 0u);
+            const unsigned long long gm = (G == 64) ? ~0ull : (((1ull << G) - 1ull) << (q * G));
+            bad = (bm & gm) ? 1u : 0u;
+        }
+        // the raw image is consumed: next unit's DMA flies under the compute
+        uint32_t nunit = 0;
+        const bool nhave = xcd_unit(n_units, it + 1, &nunit);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __syncthreads();
+        if (nhave) {
+            dma(nunit);
+            if (nunit * PPW + q < a.n_pairs) rq_next = a.req[nunit * PPW + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- affine_wfa_extend on packed words (wfa.c:186-208) -----------------------------------------------------
+        auto extend = [&](int k, int off) -> int {
+            int v = off - k, h = off;
+            if (off < 0 || v < 0) return off;
+            int rem = min(plen - v, tlen - h);
+            while (rem > 0) {
+                const int wp = v >> 4, wt = h >> 4;
+                const uint32_t pw = __builtin_amdgcn_alignbit(pkP[wp + 1], pkP[wp], (uint32_t)((v & 15) * 2));
+                const uint32_t tw = __builtin_amdgcn_alignbit(pkT[wt + 1], pkT[wt], (uint32_t)((h & 15) * 2));
+                const uint32_t x = pw ^ tw;
+                const int n = x ? (__builtin_ctz(x) >> 1) : 16;
+                if (n >= rem) { v += rem; h += rem; break; }
+                v += n; h += n; rem -= n;
+                if (n < 16) break;
+            }
+            return h;
+        };
+
+        const int ak = tlen - plen;
+        int score = 0, final_score = -1;
+        bool done = !active || bad != 0u;
+        // wavefronts[0]: lo = hi = 0, M[0] = 0 (wfa.c:347-348)
+        int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
+        if (g == 0) {
+            mslot(0)[0] = 0;
+            meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
+        }
+        fence();
+        for (;;) {
+            if (!done) {
+                const bool live = (flags & GF_PRESENT) && !(flags & GF_MNULL);
+                int16_t *mrow = mslot(score);
+                if (live) {
+                    for (int k = klo + g; k <= khi; k += G) {
+                        const int off = mrow[k];
+                        const int noff = extend(k, off);
+                        if (noff != off) mrow[k] = (int16_t)noff;
+                    }
+                    fence();
+                }
+                if (REDUCE && live && (khi - klo + 1) >= 10) {   // affine_wfa_reduce_wvs, wfa.c:69-140 (every lane, redundantly)
+                    int mind = max(plen, tlen);
+                    for (int k = klo; k <= khi; ++k) {
+                        const int off = mrow[k];
+                        mind = min(mind, max(plen - (off - k), tlen - off));
+                    }
+                    int nklo = klo, nkhi = khi;
+                    const int top_limit = min(ak - 1, khi);
+                    for (int k = klo; k < top_limit; ++k) {
+                        const int off = mrow[k];
+                        if ((max(plen - (off - k), tlen - off) - mind) <= 50) break;
+                        ++nklo;
+                    }
+                    const int bottom_limit = max(ak + 1, nklo);
+                    for (int k = khi; k > bottom_limit; --k) {
+                        const int off = mrow[k];
+                        if ((max(plen - (off - k), tlen - off) - mind) <= 50) break;
+                        --nkhi;
+                    }
+                    if (nklo > nkhi) flags |= GF_MNULL | GF_INULL | GF_DNULL;
+                    else { klo = nklo; khi = nkhi; }
+                    if (g == 0) {
+                        int16_t *me = meta + (score & (c.ring_m - 1)) * 4;
+                        me[0] = (int16_t)klo; me[1] = (int16_t)khi; me[2] = (int16_t)flags;
+                    }
+                    fence();
+                }
+                // affine_wfa_end_reached, wfa.c:210-230
+                if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[ak] >= tlen) {
+                    done = true;
+                    final_score = score;
+                } else if (score + 1 > MS) {   // wfa.c:368-376
+                    done = true;
+                    final_score = score + 1;
+                }
+            }
+            if (__ballot(!done) == 0ull) break;
+            ++score;
+            if (!done) {
+                // ---- affine_wfa_compute_next, wfa.c:268-340 --------------------------------------------------------
+                const int s_sub = score - X, s_o = score - OE, s_e = score - E;
+                int sub_f = 0, o_f = 0, e_f = 0, sub_lo = 1, sub_hi = -1, o_lo = 1, o_hi = -1, e_lo = 1, e_hi = -1;
+                if (s_sub >= 0) { const int16_t *m = meta + (s_sub & (c.ring_m - 1)) * 4; sub_lo = m[0]; sub_hi = m[1]; sub_f = m[2]; }
+                if (s_o >= 0) { const int16_t *m = meta + (s_o & (c.ring_m - 1)) * 4; o_lo = m[0]; o_hi = m[1]; o_f = m[2]; }
+                if (s_e >= 0) { const int16_t *m = meta + (s_e & (c.ring_m - 1)) * 4; e_lo = m[0]; e_hi = m[1]; e_f = m[2]; }
+                const bool m_sub_null = (s_sub < 0) || !(sub_f & GF_PRESENT) || (sub_f & GF_MNULL);
+                const bool m_o_null = (s_o < 0) || !(o_f & GF_PRESENT) || (o_f & GF_MNULL);
+                const bool i_e_null = (s_e < 0) || !(e_f & GF_PRESENT) || !(e_f & GF_HASI) || (e_f & GF_INULL);
+                const bool d_e_null = (s_e < 0) || !(e_f & GF_PRESENT) || !(e_f & GF_HASD) || (e_f & GF_DNULL);
+                const bool i_out_null = m_o_null && i_e_null, d_out_null = m_o_null && d_e_null;
+                if (m_sub_null && i_out_null && d_out_null) {
+                    flags = 0; klo = 0; khi = -1;
+                } else {
+                    if (m_sub_null) { sub_lo = 1; sub_hi = -1; }
+                    if (m_o_null) { o_lo = 1; o_hi = -1; }
+                    if (i_e_null && d_e_null) { e_lo = 1; e_hi = -1; }
+                    const int lo = min(min(sub_lo, o_lo), e_lo) - 1;
+                    const int hi = max(max(sub_hi, o_hi), e_hi) + 1;
+                    flags = GF_PRESENT | (i_out_null ? GF_INULL : GF_HASI) | (d_out_null ? GF_DNULL : GF_HASD);
+                    klo = lo; khi = hi;
+                    const int16_t *r_ms = mslot(s_sub < 0 ? 0 : s_sub), *r_mo = mslot(s_o < 0 ? 0 : s_o);
+                    const int16_t *r_ie = islot(s_e < 0 ? 0 : s_e), *r_de = dslot(s_e < 0 ? 0 : s_e);
+                    int16_t *om = mslot(score), *oi = islot(score), *od = dslot(score);
+                    for (int k = lo + g; k <= hi; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266
+                        int ins = -10;
+                        if (!i_out_null) {
+                            const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? (int)r_mo[k - 1] : kGrpNull;
+                            const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? (int)r_ie[k - 1] : kGrpNull;
+                            ins = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : (int)(int16_t)(max(ins_g, ins_i) + 1);
+                            oi[k] = (int16_t)ins;
+                        }
+                        int del = -10;
+                        if (!d_out_null) {
+                            const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? (int)r_mo[k + 1] : kGrpNull;
+                            const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? (int)r_de[k + 1] : kGrpNull;
+                            del = max(del_g, del_d);
+                            od[k] = (int16_t)del;
+                        }
+                        int sub = -10;
+                        if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(int16_t)(r_ms[k] + 1) : kGrpNull;
+                        om[k] = (int16_t)max(del, max(sub, ins));
+                    }
+                }
+                if (g == 0) {
+                    int16_t *me = meta + (score & (c.ring_m - 1)) * 4;
+                    me[0] = (int16_t)klo; me[1] = (int16_t)khi; me[2] = (int16_t)flags;
+                }
+            }
+            fence();
+        }
+        if (active && g == 0) {
+            if (bad != 0u) {
+                const uint32_t slot = atomicAdd(&todo[LANE_TODO_COUNT], 1u);
+                todo[LANE_TODO_LIST + slot] = pair;
+            } else {
+                aim_result_t r;
+                r.max_operations = plen + tlen;
+                r.begin_offset = plen + tlen - 1;
+                r.end_offset = plen + tlen;
+                r.score = final_score;
+                r.status = AIM_PAIR_OK;
+                r.idx = rq.idx;
+                a.res[pair] = r;
+            }
+        }
+        have = nhave;
+        unit = nunit;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c, int *G, uint32_t *grid, size_t *lds)
+{
+    if (p.algo != AIM_ALGO_WFA || (p.flags & AIM_FLAG_BACKTRACE)) return false;
+    if (p.read_size > 512 || p.max_score > 120) return false;
+    const int R = p.mismatch > p.gap_o + p.gap_e ? p.mismatch : p.gap_o + p.gap_e;
+    int ring_m = 1, ring_e = 1;
+    while (ring_m <= R) ring_m *= 2;
+    while (ring_e <= p.gap_e) ring_e *= 2;
+    if (ring_m > 32 || ring_e > 16) return false;
+    c->kbias = p.max_score + 1;
+    c->wcap = 2 * p.max_score + 3;
+    c->ring_m = ring_m;
+    c->ring_e = ring_e;
+    c->np = (p.read_size + 15) / 16 + 1;
+    int dw = ((ring_m + 2 * ring_e) * c->wcap * 2 + ring_m * 8 + 3) / 4 + 2 * c->np;
+    dw |= 1;
+    c->pair_dwords = dw;
+    int g = 1;
+    while (g <= 16 && (size_t)(kWave / g) * dw * 4 > 24 * 1024) g *= 2;
+    if (g > 16) return false;
+    if (((kWave / g) * p.read_size) % 16 != 0) return false;
+    *G = g;
+    c->rows_per_wave = kWave / g;
+    const size_t rows_bytes = (size_t)2 * (kWave / g) * p.read_size + 4;
+    *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(AIM_GROUP_WGS_PER_CU, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
+    uint32_t gr = 256 * per_cu;
+    const uint32_t need = ((n_units + 7u) / 8u) * 8u;
+    if (gr > need) gr = need < 8u ? 8u : need;
+    *grid = gr;
+    return true;
+}
+
+inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const bool red = p.flags & AIM_FLAG_REDUCE;
+#define AIM_GRP(GG)                                                                                          \
+    do {                                                                                                     \
+        if (red) hipLaunchKernelGGL((wfa_group_kernel<GG, true>), dim3(grid), dim3(kWave), lds, s, ka, c);   \
+        else hipLaunchKernelGGL((wfa_group_kernel<GG, false>), dim3(grid), dim3(kWave), lds, s, ka, c);      \
+    } while (0)
+    switch (G) {
+    case 1: AIM_GRP(1); break;
+    case 2: AIM_GRP(2); break;
+    case 4: AIM_GRP(4); break;
+    case 8: AIM_GRP(8); break;
+    case 16: AIM_GRP(16); break;
+    default: break;
+    }
+#undef AIM_GRP
+}
+
+}  // namespace aim

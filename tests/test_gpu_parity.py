@@ -470,3 +470,29 @@ def test_cfg4_full_size_1024_pairs_properties(gpu, monkeypatch):
         assert np.isin(o, np.frombuffer(b"MXID", dtype=np.uint8)).all()
     sub = slice(0, 48)
     _compare("swg", params, req[sub], pat[sub], txt[sub], threads=8)
+
+
+def test_wfa_group_kernel_coverage(gpu):
+    """The G-lanes-per-pair kernel: every group width (G = 1..16), WFA-adaptive on/off with wavefronts wide enough
+    for the reduction to fire, custom penalties, non-ACGT fallback, ragged tails."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    lib = capi.load()
+    cases = [(100, 0.02, {}), (100, 0.05, {}), (100, 0.10, {}), (150, 0.05, {}), (250, 0.05, {}), (250, 0.08, {}),
+             (100, 0.05, dict(mismatch=2, gap_o=3, gap_e=1)), (100, 0.04, dict(mismatch=5, gap_o=4, gap_e=2)),
+             (200, 0.03, dict(mismatch=1, gap_o=1, gap_e=1))]
+    seen_g = set()
+    for l, e, cost in cases:
+        ms, rs = engine.launcher_sizes("wfa", l, e, **cost)
+        req, pat, txt = engine.gen_pairs(31 + l, 0, 1203, l, e, rs)
+        pat[5, 3] = ord("N")
+        txt[77, 10] = ord("n")
+        for red in (True, False):
+            params = engine.make_params("wfa", ms, rs, reduce=red, **cost)
+            assert lib.aim_kernel_name(C.byref(params)) == b"wfa_group_kernel", (l, e, ms, rs)
+            with engine.DeviceSet(1) as ds:
+                res, _ = ds.align(params, req, pat, txt)
+                assert ds.fallback_pairs(0) == 2
+            _compare("wfa", params, req, pat, txt)
+        seen_g.add((ms, rs))
+    assert len(seen_g) >= 6
