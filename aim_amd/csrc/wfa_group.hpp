@@ -16,6 +16,8 @@
 // Pairs with non-ACGT bytes go to the to-do list drained by wfa_wave_kernel, as in wfa_lane.hpp.
 #pragma once
 
+#include <cstdlib>
+
 #include "aim_device.hpp"
 #include "wfa_lane.hpp"
 
@@ -37,6 +39,18 @@ struct GroupCfg {
 
 enum { GF_PRESENT = 1, GF_MNULL = 2, GF_INULL = 4, GF_DNULL = 8, GF_HASI = 16, GF_HASD = 32 };
 constexpr int kGrpNull = -16384;
+
+// minimum over the G lanes of a group (G-aligned inside a 16-lane DPP row); every lane of the group gets it
+template <int G>
+__device__ __forceinline__ int group_min(int v)
+{
+    constexpr int big = 0x7fffffff;
+    if (G >= 2) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    if (G >= 4) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    if (G >= 8) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    if (G >= 16) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
 
 template <int G, bool REDUCE>
 __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
@@ -183,24 +197,32 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     }
                     fence();
                 }
-                if (REDUCE && live && (khi - klo + 1) >= 10) {   // affine_wfa_reduce_wvs, wfa.c:69-140 (every lane, redundantly)
-                    int mind = max(plen, tlen);
-                    for (int k = klo; k <= khi; ++k) {
+                if (REDUCE && live && (khi - klo + 1) >= 10) {   // affine_wfa_reduce_wvs, wfa.c:69-140
+                    // the group's lanes split the diagonals; min / first-from-bottom / first-from-top are group reductions
+                    int part = 0x7fffffff;
+                    for (int k = klo + g; k <= khi; k += G) {
                         const int off = mrow[k];
-                        mind = min(mind, max(plen - (off - k), tlen - off));
+                        part = min(part, max(plen - (off - k), tlen - off));
                     }
+                    const int mind = min(max(plen, tlen), group_min<G>(part));
                     int nklo = klo, nkhi = khi;
                     const int top_limit = min(ak - 1, khi);
-                    for (int k = klo; k < top_limit; ++k) {
-                        const int off = mrow[k];
-                        if ((max(plen - (off - k), tlen - off) - mind) <= 50) break;
-                        ++nklo;
+                    if (klo < top_limit) {   // first k in [klo, top_limit) whose distance is within 50 of the best, else top_limit
+                        int first = top_limit;
+                        for (int k = klo + g; k < top_limit; k += G) {
+                            const int off = mrow[k];
+                            if ((max(plen - (off - k), tlen - off) - mind) <= 50) { first = k; break; }
+                        }
+                        nklo = group_min<G>(first);
                     }
                     const int bottom_limit = max(ak + 1, nklo);
-                    for (int k = khi; k > bottom_limit; --k) {
-                        const int off = mrow[k];
-                        if ((max(plen - (off - k), tlen - off) - mind) <= 50) break;
-                        --nkhi;
+                    if (khi > bottom_limit) {   // last k in (bottom_limit, khi] within 50 of the best, else bottom_limit
+                        int last = bottom_limit;
+                        for (int k = khi - g; k > bottom_limit; k -= G) {
+                            const int off = mrow[k];
+                            if ((max(plen - (off - k), tlen - off) - mind) <= 50) { last = k; break; }
+                        }
+                        nkhi = -group_min<G>(-last);
                     }
                     if (nklo > nkhi) flags |= GF_MNULL | GF_INULL | GF_DNULL;
                     else { klo = nklo; khi = nkhi; }
@@ -311,8 +333,16 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     int dw = ((ring_m + 2 * ring_e) * c->wcap * 2 + ring_m * 8 + 3) / 4 + 2 * c->np;
     dw |= 1;
     c->pair_dwords = dw;
-    int g = 1;
-    while (g <= 16 && (size_t)(kWave / g) * dw * 4 > 24 * 1024) g *= 2;
+    // LDS budget for the wavefront windows of one wavefront's pairs: 12 KiB measured best (occupancy beats lanes per
+    // pair: 24 KiB -15..30 %, 48 KiB -45 %); wider budgets only when 16 lanes per pair do not fit otherwise
+    int g = 32;
+    for (size_t cap_kb : {12, 24, 48}) {
+        size_t cap_bytes = cap_kb * 1024;
+        if (const char *e = getenv("AIM_GROUP_LDS_KB")) cap_bytes = (size_t)atoi(e) * 1024;
+        g = 1;
+        while (g <= 16 && (size_t)(kWave / g) * dw * 4 > cap_bytes) g *= 2;
+        if (g <= 16) break;
+    }
     if (g > 16) return false;
     if (((kWave / g) * p.read_size) % 16 != 0) return false;
     *G = g;
