@@ -64,6 +64,7 @@ struct Plan {
     uint32_t fb_grid;       // K_WFA_LANE / K_WFA_GROUP: grid / LDS of the fallback (general) kernel
     size_t fb_lds;
     bool no_lane;
+    size_t hist_bytes;      // K_WFA_GROUP + BACKTRACE: per-pair history slabs between to-do region and fallback scratch
     aim::GroupCfg gcfg;     // K_WFA_GROUP
     int group_g;
 };
@@ -114,10 +115,10 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         aim::GroupCfg gc;
         int gg = 0;
         uint32_t ggrid = 0;
-        size_t glds = 0;
+        size_t glds = 0, ghist = 0;
         const bool no_group = getenv("AIM_NO_GROUP") && getenv("AIM_NO_GROUP")[0] == '1';
         const bool group_ok = !lane_ok && !force_wave_kernel() && !pl->no_lane && !no_group &&
-                              aim::wfa_group_plan(p, n_pairs, &gc, &gg, &ggrid, &glds);
+                              aim::wfa_group_plan(p, n_pairs, &gc, &gg, &ggrid, &glds, &ghist) && ghist <= budget / 2;
         if (lane_ok || group_ok) {
             // fast path + the general kernel in to-do mode behind it (its plan goes into *pl first)
             Plan fb;
@@ -140,7 +141,8 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
                 pl->lds = glds;
             }
             pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
-            pl->scratch_total = pl->todo_bytes + fb.scratch_total;
+            pl->hist_bytes = lane_ok ? 0 : ghist;
+            pl->scratch_total = pl->todo_bytes + pl->hist_bytes + fb.scratch_total;
             return AIM_OK;
         }
         pl->kid = K_WFA_WAVE;
@@ -273,7 +275,7 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         HIP_TRY(hipGetLastError());
         aim::KArgs kb = ka;
         kb.todo = reinterpret_cast<const uint32_t *>(d_scratch);
-        kb.scratch = (char *)d_scratch + pl.todo_bytes;
+        kb.scratch = (char *)d_scratch + pl.todo_bytes + pl.hist_bytes;
         kb.scratch_per_wave = pl.scratch_per_wg;
         Plan fb = pl;
         fb.grid = pl.fb_grid;

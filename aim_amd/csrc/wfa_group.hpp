@@ -35,6 +35,7 @@ struct GroupCfg {
     int np;           // packed dwords per sequence (READ_SIZE/16 rounded up) + 1 pad
     int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)
     int rows_per_wave;
+    int hist_stride;  // BACKTRACE: int16 entries of one pair's HBM history slab = (MAX_SCORE+2) * (3*wcap + 4)
 };
 
 enum { GF_PRESENT = 1, GF_MNULL = 2, GF_INULL = 4, GF_DNULL = 8, GF_HASI = 16, GF_HASD = 32 };
@@ -52,7 +53,7 @@ __device__ __forceinline__ int group_min(int v)
     return v;
 }
 
-template <int G, bool REDUCE>
+template <int G, bool REDUCE, bool BT>
 __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -75,6 +76,14 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
     const int kb = c.kbias;
     uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
+    // BACKTRACE: every wavefront is also streamed to a per-pair HBM slab [score][M | I | D | klo,khi,flags,-]
+    // (fixed homes, no allocator); the traceback of a pair is walked by the first lane of its group.
+    int16_t *hist = BT ? reinterpret_cast<int16_t *>(a.scratch + a.scratch_per_wave) + ((size_t)blockIdx.x * PPW + q) * c.hist_stride : nullptr;
+    const int hrow = 3 * c.wcap + 4;
+    auto hM = [&](int s) { return hist + (size_t)s * hrow + kb; };
+    auto hI = [&](int s) { return hist + (size_t)s * hrow + c.wcap + kb; };
+    auto hD = [&](int s) { return hist + (size_t)s * hrow + 2 * c.wcap + kb; };
+    auto hMeta = [&](int s) { return hist + (size_t)s * hrow + 3 * c.wcap; };
     const uint32_t n_units = (a.n_pairs + PPW - 1) / PPW;
     const int nchunk_total = (PPW * rs) / 16;            // 16-B chunks per array per unit (PPW*rs % 16 == 0, checked by the planner)
 
@@ -184,6 +193,11 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             mslot(0)[0] = 0;
             meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
         }
+        if (BT && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465
+            uint4 *orow = reinterpret_cast<uint4 *>(a.ops + (uint64_t)pair * 2 * rs);
+            const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+            for (int j = g; j < (2 * rs) / 16; j += G) orow[j] = mm;
+        }
         fence();
         for (;;) {
             if (!done) {
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         const int off = mrow[k];
                         const int noff = extend(k, off);
                         if (noff != off) mrow[k] = (int16_t)noff;
+                        if (BT) hM(score)[k] = (int16_t)noff;
                     }
                     fence();
                 }
@@ -231,6 +246,10 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         me[0] = (int16_t)klo; me[1] = (int16_t)khi; me[2] = (int16_t)flags;
                     }
                     fence();
+                }
+                if (BT && g == 0) {   // final descriptor of this score (after reduction)
+                    int16_t *hm = hMeta(score);
+                    hm[0] = (int16_t)klo; hm[1] = (int16_t)khi; hm[2] = (int16_t)flags;
                 }
                 // affine_wfa_end_reached, wfa.c:210-230
                 if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[ak] >= tlen) {
@@ -275,6 +294,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                             const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? (int)r_ie[k - 1] : kGrpNull;
                             ins = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : (int)(int16_t)(max(ins_g, ins_i) + 1);
                             oi[k] = (int16_t)ins;
+                            if (BT) hI(score)[k] = (int16_t)ins;
                         }
                         int del = -10;
                         if (!d_out_null) {
@@ -282,6 +302,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                             const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? (int)r_de[k + 1] : kGrpNull;
                             del = max(del_g, del_d);
                             od[k] = (int16_t)del;
+                            if (BT) hD(score)[k] = (int16_t)del;
                         }
                         int sub = -10;
                         if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(int16_t)(r_ms[k] + 1) : kGrpNull;
@@ -295,6 +316,83 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             }
             fence();
         }
+        int begin_offset = plen + tlen - 1, status = AIM_PAIR_OK;
+        if (BT) {
+            __syncthreads();   // the history stores of the whole wave have landed
+            if (active && g == 0 && bad == 0u && final_score <= MS) {
+                // affine_wavefronts_backtrace (wfa_backtracing.c:210-351) over the HBM history; ops row pre-filled with 'M'
+                char *ops = a.ops + (uint64_t)pair * 2 * rs;
+                const int cap = 2 * rs;
+                enum { BT_M = 0, BT_I = 1, BT_D = 2 };
+                auto put = [&](char ch) {
+                    if (begin_offset >= 0 && begin_offset < cap) ops[begin_offset] = ch;
+                    --begin_offset;
+                };
+                auto valid_loc = [&](int kk_, int off_) {
+                    const int v_ = off_ - kk_, h_ = off_;
+                    return v_ > 0 && v_ <= plen && h_ > 0 && h_ <= tlen;
+                };
+                int sc = final_score, k = ak;
+                int offset = hM(sc)[k];
+                bool valid = valid_loc(k, offset);
+                int bt = BT_M;
+                int v = offset - k, h = offset;
+                while (v > 0 && h > 0 && sc > 0) {
+                    if (!valid) {
+                        valid = valid_loc(k, offset);
+                        if (valid) {
+                            if (k < ak) for (int i = k; i < ak; ++i) put('I');
+                            else if (k > ak) for (int i = ak; i < k; ++i) put('D');
+                        }
+                    }
+                    const int s_o = sc - OE, s_e = sc - E, s_x = sc - X;
+                    int o_lo = 1, o_hi = -1, o_f = 0, e_lo = 1, e_hi = -1, e_f = 0, x_lo = 1, x_hi = -1, x_f = 0;
+                    if (s_o >= 0) { const int16_t *m = hMeta(s_o); o_lo = m[0]; o_hi = m[1]; o_f = m[2]; }
+                    if (s_e >= 0) { const int16_t *m = hMeta(s_e); e_lo = m[0]; e_hi = m[1]; e_f = m[2]; }
+                    if (s_x >= 0 && bt == BT_M) { const int16_t *m = hMeta(s_x); x_lo = m[0]; x_hi = m[1]; x_f = m[2]; }
+                    int del_ext = kGrpNull, del_open = kGrpNull, ins_ext = kGrpNull, ins_open = kGrpNull, misms = kGrpNull;
+                    if (bt != BT_I) {
+                        if ((e_f & GF_PRESENT) && !(e_f & GF_DNULL) && e_lo <= k + 1 && k + 1 <= e_hi) del_ext = hD(s_e)[k + 1];
+                        if ((o_f & GF_PRESENT) && o_lo <= k + 1 && k + 1 <= o_hi) del_open = hM(s_o)[k + 1];
+                    }
+                    if (bt != BT_D) {
+                        if ((e_f & GF_PRESENT) && (e_f & GF_HASI) && e_lo <= k - 1 && k - 1 <= e_hi) ins_ext = (int16_t)(hI(s_e)[k - 1] + 1);
+                        if ((o_f & GF_PRESENT) && o_lo <= k - 1 && k - 1 <= o_hi) ins_open = (int16_t)(hM(s_o)[k - 1] + 1);
+                    }
+                    if (bt == BT_M) {
+                        if ((x_f & GF_PRESENT) && x_lo <= k && k <= x_hi) misms = (int16_t)(hM(s_x)[k] + 1);
+                    }
+                    const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
+                    if (bt == BT_M) {
+                        const int num_matches = offset - max_all;
+                        if (num_matches > 0) begin_offset -= num_matches;
+                        offset = max_all;
+                        v = offset - k;
+                        h = offset;
+                        if (v <= 0 || h <= 0) break;
+                    }
+                    char op;
+                    if (max_all == del_ext) { op = 'D'; sc = s_e; ++k; bt = BT_D; }
+                    else if (max_all == del_open) { op = 'D'; sc = s_o; ++k; bt = BT_M; }
+                    else if (max_all == ins_ext) { op = 'I'; sc = s_e; --k; offset = (int16_t)(offset - 1); bt = BT_I; }
+                    else if (max_all == ins_open) { op = 'I'; sc = s_o; --k; offset = (int16_t)(offset - 1); bt = BT_M; }
+                    else if (max_all == misms) { op = 'X'; sc = s_x; offset = (int16_t)(offset - 1); }
+                    else { status = AIM_PAIR_WFA_NO_LINK; break; }
+                    if (valid) put(op);
+                    v = offset - k;
+                    h = offset;
+                }
+                if (status == AIM_PAIR_OK) {
+                    if (sc == 0) {
+                        if (offset > 0) begin_offset -= offset;
+                    } else {
+                        for (; v > 0; --v) put('D');
+                        for (; h > 0; --h) put('I');
+                    }
+                    ++begin_offset;
+                }
+            }
+        }
         if (active && g == 0) {
             if (bad != 0u) {
                 const uint32_t slot = atomicAdd(&todo[LANE_TODO_COUNT], 1u);
@@ -302,10 +400,10 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             } else {
                 aim_result_t r;
                 r.max_operations = plen + tlen;
-                r.begin_offset = plen + tlen - 1;
+                r.begin_offset = begin_offset;
                 r.end_offset = plen + tlen;
                 r.score = final_score;
-                r.status = AIM_PAIR_OK;
+                r.status = status;
                 r.idx = rq.idx;
                 a.res[pair] = r;
             }
@@ -316,9 +414,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c, int *G, uint32_t *grid, size_t *lds)
+inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c, int *G, uint32_t *grid, size_t *lds, size_t *hist_bytes)
 {
-    if (p.algo != AIM_ALGO_WFA || (p.flags & AIM_FLAG_BACKTRACE)) return false;
+    if (p.algo != AIM_ALGO_WFA) return false;
     if (p.read_size > 512 || p.max_score > 120) return false;
     const int R = p.mismatch > p.gap_o + p.gap_e ? p.mismatch : p.gap_o + p.gap_e;
     int ring_m = 1, ring_e = 1;
@@ -355,16 +453,20 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     const uint32_t need = ((n_units + 7u) / 8u) * 8u;
     if (gr > need) gr = need < 8u ? 8u : need;
     *grid = gr;
+    c->hist_stride = (p.max_score + 2) * (3 * c->wcap + 4);
+    *hist_bytes = (p.flags & AIM_FLAG_BACKTRACE) ? (((size_t)gr * (kWave / g) * c->hist_stride * 2 + 255) & ~(size_t)255) : 0;
     return true;
 }
 
 inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
-    const bool red = p.flags & AIM_FLAG_REDUCE;
-#define AIM_GRP(GG)                                                                                          \
-    do {                                                                                                     \
-        if (red) hipLaunchKernelGGL((wfa_group_kernel<GG, true>), dim3(grid), dim3(kWave), lds, s, ka, c);   \
-        else hipLaunchKernelGGL((wfa_group_kernel<GG, false>), dim3(grid), dim3(kWave), lds, s, ka, c);      \
+    const bool red = p.flags & AIM_FLAG_REDUCE, bt = p.flags & AIM_FLAG_BACKTRACE;
+#define AIM_GRP(GG)                                                                                                     \
+    do {                                                                                                                \
+        if (red && bt) hipLaunchKernelGGL((wfa_group_kernel<GG, true, true>), dim3(grid), dim3(kWave), lds, s, ka, c);  \
+        else if (red) hipLaunchKernelGGL((wfa_group_kernel<GG, true, false>), dim3(grid), dim3(kWave), lds, s, ka, c);  \
+        else if (bt) hipLaunchKernelGGL((wfa_group_kernel<GG, false, true>), dim3(grid), dim3(kWave), lds, s, ka, c);   \
+        else hipLaunchKernelGGL((wfa_group_kernel<GG, false, false>), dim3(grid), dim3(kWave), lds, s, ka, c);          \
     } while (0)
     switch (G) {
     case 1: AIM_GRP(1); break;

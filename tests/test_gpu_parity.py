@@ -487,8 +487,8 @@ def test_wfa_group_kernel_coverage(gpu):
         req, pat, txt = engine.gen_pairs(31 + l, 0, 1203, l, e, rs)
         pat[5, 3] = ord("N")
         txt[77, 10] = ord("n")
-        for red in (True, False):
-            params = engine.make_params("wfa", ms, rs, reduce=red, **cost)
+        for red, bt in ((True, False), (False, False), (True, True), (False, True)):
+            params = engine.make_params("wfa", ms, rs, reduce=red, backtrace=bt, **cost)
             assert lib.aim_kernel_name(C.byref(params)) == b"wfa_group_kernel", (l, e, ms, rs)
             with engine.DeviceSet(1) as ds:
                 res, _ = ds.align(params, req, pat, txt)
