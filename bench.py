@@ -67,11 +67,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the alignment path has no CPU fallback", file=sys.stderr)
         sys.exit(1)
+    # Test hook only (single-GPU boxes): AIM_BENCH_SHARE_GPU=1 puts every rank on device 0 and uses gloo, so the
+    # multi-rank control flow can be exercised without N GPUs.  Never set by the driver.
+    share = os.environ.get("AIM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from aim_amd import capi, engine, shard
     lib = capi.load()
