@@ -198,9 +198,8 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
     const bool force_dpw = getenv("AIM_FORCE_DPWAVE") && getenv("AIM_FORCE_DPWAVE")[0] == '1';
     if (p.read_size > 320 || force_dpw) {
         pl->kid = K_DP_WAVE;
-        pl->block = 64;
         const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
-        return aim::dp_wave_plan(p, n_pairs, budget, cell8, &pl->grid, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total)
+        return aim::dp_wave_plan(p, n_pairs, budget, cell8, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total)
                    ? AIM_OK
                    : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
     }

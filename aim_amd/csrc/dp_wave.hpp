@@ -1,4 +1,5 @@
-// dp_wave.hpp -- long-read NW / SWG: ONE PAIR PER WAVEFRONT, row by row, 64 lanes x K cells per step.
+// dp_wave.hpp -- long-read NW / SWG: ONE PAIR PER WORKGROUP of NW wavefronts, row by row, each wavefront takes
+// one 512-cell block (64 lanes x 8 cells) per step and the in-row carry is combined across wavefronts through LDS.
 //
 // Same results as nw_compute/nw_traceback (NW/DPU-WRAM/dpu/nw.c:67-153) and swg_compute/swg_traceback
 // (SWG/DPU-WRAM/dpu/swg.c:45-171) for reads whose table does not fit the one-pair-per-lane kernel
@@ -33,17 +34,22 @@ constexpr int kDpK = 8;                      // cells per lane per step
 constexpr int kDpBlock = kWave * kDpK;       // 512 cells per step
 constexpr int kDpInf = 0x3fffffff;
 
+// Exclusive prefix-min over the 64 lanes (and the wave total), all in DPP: row_shr 1/2/4/8 scan each 16-lane row,
+// row_bcast:15 / row_bcast:31 carry the row totals across rows, wave_shr:1 makes it exclusive.
 __device__ __forceinline__ int wave_excl_scan_min(int x, int lane, int *total)
 {
-    int v = x;   // inclusive Kogge-Stone prefix-min
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const int o = __shfl_up(v, off, kWave);
-        if (lane >= off) v = min(v, o);
-    }
-    *total = __shfl(v, kWave - 1, kWave);
-    const int e = __shfl_up(v, 1, kWave);
-    return lane == 0 ? kDpInf : e;
+    (void)lane;
+    int v = x;
+#define AIM_SCAN_STEP(ctrl, rmask) v = min(v, __builtin_amdgcn_update_dpp(kDpInf, v, ctrl, rmask, 0xf, false))
+    AIM_SCAN_STEP(0x111, 0xf);
+    AIM_SCAN_STEP(0x112, 0xf);
+    AIM_SCAN_STEP(0x114, 0xf);
+    AIM_SCAN_STEP(0x118, 0xf);
+    AIM_SCAN_STEP(0x142, 0xa);
+    AIM_SCAN_STEP(0x143, 0xc);
+#undef AIM_SCAN_STEP
+    *total = __builtin_amdgcn_readlane(v, kWave - 1);
+    return __builtin_amdgcn_update_dpp(kDpInf, v, 0x138, 0xf, 0xf, false);   // wave_shr:1
 }
 
 struct DpCell { int M, I, D; };
@@ -63,19 +69,25 @@ __host__ __device__ inline bool dp_wave_exact_ok(const aim_params_t &p, bool swg
 }
 
 // ALGO: AIM_ALGO_NW or AIM_ALGO_SWG.  CELL8: SWG with int8 cells (literal path only).
-template <int ALGO, bool BT, bool CELL8>
-__global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
+template <int ALGO, bool BT, bool CELL8, int NW>
+__global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool SWG = (ALGO == AIM_ALGO_SWG);
-    const int lane = threadIdx.x;
+    constexpr int NT = kWave * NW;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wv = tid >> 6;
     const int rs = a.p.read_size;
-    const int rowcap = rs + 16;                       // int16 entries per LDS row buffer
+    const int rowcap = (rs + 31) & ~7;                // int16 entries per LDS row buffer; cell v lives at index v + 7 so
+                                                      // that the 8-cell groups starting at v = 1 + 8j are 16-B aligned
     unsigned char *ldsP = reinterpret_cast<unsigned char *>(smem);
-    int16_t *rowbuf = reinterpret_cast<int16_t *>(smem + ((rs + 15) & ~15));
-    int16_t *Mrow[2] = {rowbuf, rowbuf + rowcap};
-    int16_t *Irow[2] = {rowbuf + 2 * rowcap, rowbuf + 3 * rowcap};   // SWG only
-    int16_t *tailM = rowbuf + (SWG ? 4 : 2) * rowcap;                 // tail cells of the current row (<= rs)
+    int16_t *rowbuf = reinterpret_cast<int16_t *>(smem + ((rs + 31) & ~15));
+    int16_t *Mrow[2] = {rowbuf + 7, rowbuf + rowcap + 7};
+    int16_t *Irow[2] = {rowbuf + 2 * rowcap + 7, rowbuf + 3 * rowcap + 7};   // SWG only
+    int16_t *tailM = rowbuf + (SWG ? 4 : 2) * rowcap;                 // {M, D} of cell (h, W-1): up-neighbour of the first tail cell
+    int *wt = reinterpret_cast<int *>(tailM + 8);                     // [2][NW] per-wave block minima (double buffered by step)
+    int *Bl = wt + 2 * NW;                                            // boundary cell published by the tail phase {M, I, D}
+    int *sc_sh = Bl + 4;                                              // score broadcast
     // table slab: canonical rows of stride S, layers as planes
     const int S = (rs + 16) & ~7;
     const size_t plane = (size_t)S * (size_t)(rs + 3);
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
         __syncthreads();
         if (BT && SWG) {   // memset(cigar->operations, 'M', 2*READ_SIZE), swg.c:261
             uint32_t *o4 = reinterpret_cast<uint32_t *>(ops);
-            for (int w = lane; w < (rs >> 1); w += kWave) o4[w] = 0x4D4D4D4Du;
+            for (int w = tid; w < (rs >> 1); w += NT) o4[w] = 0x4D4D4D4Du;
         }
         const bool literal = !exact_ok || plen > 2 * tlen;
 
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
             // ------------------------------------------------------------------ literal single-lane path
             // The reference's loops verbatim over a flat table (plane-separated) in the slab.
             typedef typename std::conditional<CELL8, int8_t, int16_t>::type cell_t;
-            if (lane == 0) {
+            if (tid == 0) {
                 if (!SWG) {
                     int cell = 0;
                     TM[0] = 0;
@@ -148,16 +160,17 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
                     }
                 }
             }
-            score = __shfl(score, 0, kWave);
+            if (tid == 0) sc_sh[0] = score;
             __syncthreads();
+            score = sc_sh[0];
         } else {
             // ------------------------------------------------------------------ row-scan path
-            for (int i = lane; i < plen; i += kWave) ldsP[i] = gP[i];
+            for (int i = tid; i < plen; i += NT) ldsP[i] = gP[i];
             const int Rr = min(plen, W - 1);          // regular columns 1..Rr
             const bool has_tail = plen >= W;
             // row 0 (and its table image) ; boundary column of the table
             int cur = 0;
-            for (int v = lane; v <= Rr; v += kWave) {
+            for (int v = tid; v <= Rr; v += NT) {
                 int m0, i0;
                 if (SWG) { m0 = v ? O + v * E : 0; i0 = MAXS; }
                 else { m0 = v * GD; i0 = 0; }
@@ -166,39 +179,69 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
                 TM[7 + v] = (int16_t)m0;
                 if (SWG) { TI[7 + v] = (int16_t)i0; TD[7 + v] = (int16_t)(v ? m0 : MAXS); }
             }
-            for (int h = 1 + lane; h <= tlen; h += kWave) {   // row-init boundary cells flat[W*h]
+            for (int h = 1 + tid; h <= tlen; h += NT) {   // row-init boundary cells flat[W*h]
                 const size_t at = (size_t)h * S + 7;
                 if (SWG) { TM[at] = (int16_t)(O + h * E); TI[at] = (int16_t)(O + h * E); TD[at] = (int16_t)MAXS; }
                 else TM[at] = (int16_t)(h * GI);
             }
-            __syncthreads();
             DpCell B;                                  // boundary cell of the current row (flat[W*h])
-            DpCell lastTail = {0, 0, 0};
+            const int nblocks = (Rr + kDpBlock - 1) / kDpBlock;
+            const int nsteps = (nblocks + NW - 1) / NW;
             for (int h = 1; h <= tlen; ++h) {
+                __syncthreads();                       // previous row (and its tail / boundary cell) is complete in LDS
                 const int nxt = cur ^ 1;
                 const int tch = gT[h - 1];
                 if (h == 1 || !has_tail) {
                     if (SWG) { B.M = O + h * E; B.I = B.M; B.D = MAXS; }
                     else { B.M = h * GI; B.I = B.D = 0; }
                 } else {
-                    B = lastTail;                      // cell (h-1, W) landed on flat[W*h]
+                    B.M = Bl[0]; B.I = Bl[1]; B.D = Bl[2];   // cell (h-1, W) landed on flat[W*h]
                 }
-                if (lane == 0) { Mrow[nxt][0] = (int16_t)B.M; if (SWG) Irow[nxt][0] = (int16_t)B.I; }
+                if (tid == 0) { Mrow[nxt][0] = (int16_t)B.M; if (SWG) Irow[nxt][0] = (int16_t)B.I; }
                 int carry = SWG ? min(B.D, B.M + O) : B.M;     // G[0]
-                int lastD = B.D, lastM = B.M;                   // up-neighbour of the first tail cell: cell (h, W-1)
                 const size_t trow = (size_t)h * S + 7;
-                for (int base = 1; base <= Rr; base += kDpBlock) {
+                for (int step = 0; step < nsteps; ++step) {
+                    const int base = 1 + (step * NW + wv) * kDpBlock;   // may lie past Rr: the wave still joins the barrier
                     const int v0 = base + lane * kDpK;
+                    const bool full = v0 + kDpK - 1 <= Rr;   // whole 8-cell group inside the row: 16-B vector traffic
                     int A[kDpK], Iv[kDpK], G[kDpK];
                     int lane_min = kDpInf;
+                    int16_t lm[kDpK + 1], li[kDpK];
+                    unsigned char pc[kDpK];
+                    if (full) {
+                        const uint4 qm = *reinterpret_cast<const uint4 *>(&Mrow[cur][v0]);
+                        const uint32_t wm[4] = {qm.x, qm.y, qm.z, qm.w};
+                        lm[0] = Mrow[cur][v0 - 1];
+#pragma unroll
+                        for (int t = 0; t < kDpK; ++t) lm[t + 1] = (int16_t)(wm[t >> 1] >> ((t & 1) * 16));
+                        if (SWG) {
+                            const uint4 qi = *reinterpret_cast<const uint4 *>(&Irow[cur][v0]);
+                            const uint32_t wi[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+                            for (int t = 0; t < kDpK; ++t) li[t] = (int16_t)(wi[t >> 1] >> ((t & 1) * 16));
+                        }
+                        const uint2 qp = *reinterpret_cast<const uint2 *>(&ldsP[v0 - 1]);
+#pragma unroll
+                        for (int t = 0; t < kDpK; ++t) pc[t] = (unsigned char)((t < 4 ? qp.x : qp.y) >> ((t & 3) * 8));
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < kDpK; ++t) {
+                            const int v = v0 + t;
+                            const bool in = v <= Rr;
+                            lm[t + 1] = in ? Mrow[cur][v] : (int16_t)0;
+                            li[t] = (SWG && in) ? Irow[cur][v] : (int16_t)0;
+                            pc[t] = in ? ldsP[v - 1] : (unsigned char)0;
+                        }
+                        lm[0] = (v0 <= Rr) ? Mrow[cur][v0 - 1] : (int16_t)0;
+                    }
 #pragma unroll
                     for (int t = 0; t < kDpK; ++t) {
                         const int v = v0 + t;
                         if (v <= Rr) {
-                            const int leftM = Mrow[cur][v], diagM = Mrow[cur][v - 1];
-                            const int pch = ldsP[v - 1];
+                            const int leftM = lm[t + 1], diagM = lm[t];
+                            const int pch = pc[t];
                             if (SWG) {
-                                const int ins = min(leftM + OE, (int)Irow[cur][v] + E);
+                                const int ins = min(leftM + OE, (int)li[t] + E);
                                 Iv[t] = ins;
                                 A[t] = min(diagM + ((pch == tch) ? MATCH : MISMATCH), ins);
                                 G[t] = A[t] + OE - (v + 1) * E;
@@ -214,32 +257,74 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
                         lane_min = min(lane_min, G[t]);
                     }
                     int total;
-                    int pre = min(carry, wave_excl_scan_min(lane_min, lane, &total));
+                    const int lane_pre = wave_excl_scan_min(lane_min, lane, &total);
+                    int *wts = wt + (step & 1) * NW;
+                    if (NW > 1) {
+                        if (lane == 0) wts[wv] = total;
+                        __syncthreads();
+                    }
+                    int before = carry;                // minimum over everything left of this wave's block
+                    if (NW > 1) {
+#pragma unroll
+                        for (int u = 0; u < NW; ++u) {
+                            const int tu = wts[u];
+                            if (u < wv) before = min(before, tu);
+                            carry = min(carry, tu);
+                        }
+                    } else {
+                        carry = min(carry, total);
+                    }
+                    int pre = min(before, lane_pre);
+                    int Mo[kDpK], Do[kDpK];
 #pragma unroll
                     for (int t = 0; t < kDpK; ++t) {
                         const int v = v0 + t;
-                        if (v <= Rr) {
-                            const int d = pre + v * (SWG ? E : GD);
-                            const int m = min(A[t], d);
-                            Mrow[nxt][v] = (int16_t)m;
-                            TM[trow + v] = (int16_t)m;
-                            if (SWG) {
-                                Irow[nxt][v] = (int16_t)Iv[t];
-                                TI[trow + v] = (int16_t)Iv[t];
-                                TD[trow + v] = (int16_t)d;
+                        Do[t] = pre + v * (SWG ? E : GD);
+                        Mo[t] = min(A[t], Do[t]);
+                        pre = min(pre, G[t]);
+                    }
+                    if (full) {
+                        auto pack8 = [](const int (&x)[kDpK]) {
+                            uint4 r;
+                            r.x = (uint32_t)(x[0] & 0xffff) | ((uint32_t)x[1] << 16);
+                            r.y = (uint32_t)(x[2] & 0xffff) | ((uint32_t)x[3] << 16);
+                            r.z = (uint32_t)(x[4] & 0xffff) | ((uint32_t)x[5] << 16);
+                            r.w = (uint32_t)(x[6] & 0xffff) | ((uint32_t)x[7] << 16);
+                            return r;
+                        };
+                        const uint4 pm = pack8(Mo);
+                        *reinterpret_cast<uint4 *>(&Mrow[nxt][v0]) = pm;
+                        *reinterpret_cast<uint4 *>(&TM[trow + v0]) = pm;
+                        if (SWG) {
+                            const uint4 pi = pack8(Iv), pd = pack8(Do);
+                            *reinterpret_cast<uint4 *>(&Irow[nxt][v0]) = pi;
+                            *reinterpret_cast<uint4 *>(&TI[trow + v0]) = pi;
+                            *reinterpret_cast<uint4 *>(&TD[trow + v0]) = pd;
+                        }
+                        if (v0 + kDpK - 1 == Rr) { tailM[0] = (int16_t)Mo[kDpK - 1]; tailM[1] = (int16_t)Do[kDpK - 1]; }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < kDpK; ++t) {
+                            const int v = v0 + t;
+                            if (v <= Rr) {
+                                Mrow[nxt][v] = (int16_t)Mo[t];
+                                TM[trow + v] = (int16_t)Mo[t];
+                                if (SWG) {
+                                    Irow[nxt][v] = (int16_t)Iv[t];
+                                    TI[trow + v] = (int16_t)Iv[t];
+                                    TD[trow + v] = (int16_t)Do[t];
+                                }
+                                if (v == Rr) { tailM[0] = (int16_t)Mo[t]; tailM[1] = (int16_t)Do[t]; }
                             }
-                            if (v == Rr) { tailM[0] = (int16_t)m; tailM[1] = (int16_t)d; }
-                            pre = min(pre, G[t]);
                         }
                     }
-                    carry = min(carry, total);
                 }
-                __syncthreads();
                 if (has_tail) {
-                    // cells v = W .. plen, sequentially (wave-uniform), with the aliased inputs
-                    lastM = tailM[0];
-                    lastD = tailM[1];
-                    DpCell up = {lastM, 0, lastD};
+                    __syncthreads();                   // the whole regular part of row h is in LDS
+                  if (wv == 0) {
+                    // cells v = W .. plen, sequentially (wave-uniform, first wavefront only), with the aliased inputs
+                    DpCell up = {(int)tailM[0], 0, (int)tailM[1]};
+                    DpCell lastTail = {0, 0, 0};
                     const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical row of flat[W*h + v], v >= W
                     for (int v = W; v <= plen; ++v) {
                         int leftM, leftI, diagM;
@@ -266,18 +351,22 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
                         }
                         up = c;
                     }
-                    if (h == tlen) score = up.M;
-                } else if (h == tlen) {
-                    score = plen >= 1 ? (int)Mrow[nxt][plen] : 0;
+                    if (lane == 0) {
+                        Bl[0] = lastTail.M; Bl[1] = lastTail.I; Bl[2] = lastTail.D;
+                        if (h == tlen) sc_sh[0] = up.M;
+                    }
+                  }
                 }
                 cur = nxt;
-                __syncthreads();
             }
+            __syncthreads();
+            if (has_tail) score = sc_sh[0];
+            else score = (plen >= 1 && tlen >= 1) ? (int)Mrow[cur][plen] : 0;
             if (plen == 0 || tlen == 0) score = 0;
         }
 
-        if (BT) {
-            // nw_traceback / swg_traceback over flat indices; canonical slab unless literal
+        if (BT && wv == 0) {
+            // nw_traceback / swg_traceback over flat indices (first wavefront); canonical slab unless literal
             auto addr = [&](int f) -> size_t {
                 if (literal) return (size_t)f;
                 const int r = f / W;
@@ -326,7 +415,7 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
             }
             begin_offset = sentinel + 1;
         }
-        if (lane == 0) {
+        if (tid == 0) {
             aim_result_t r;
             r.max_operations = plen + tlen;
             r.begin_offset = begin_offset;
@@ -339,42 +428,62 @@ __global__ __launch_bounds__(64) void dp_wave_kernel(KArgs a)
     }
 }
 
-inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, bool cell8, uint32_t *grid, size_t *lds,
-                         uint64_t *scratch_per_wg, size_t *scratch_total)
+inline int dp_wave_nw(const aim_params_t &p)
+{
+    const int nblocks = (p.read_size + kDpBlock - 1) / kDpBlock;
+    return nblocks <= 2 ? 1 : (nblocks <= 4 ? 2 : (nblocks <= 8 ? 4 : 8));
+}
+
+inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, bool cell8, uint32_t *grid, uint32_t *block,
+                         size_t *lds, uint64_t *scratch_per_wg, size_t *scratch_total)
 {
     const uint64_t rs = (uint64_t)p.read_size;
     const uint64_t S = (rs + 16) & ~7ull;
     uint64_t per = 3 * S * (rs + 3) * 2;   // three int16 planes (NW uses the first)
     per = (per + 255) & ~255ull;
-    uint32_t g = 256 * 4;
+    (void)cell8;
+    const int nw = dp_wave_nw(p);
+    *block = (uint32_t)(kWave * nw);
+    const bool swg = p.algo == AIM_ALGO_SWG;
+    const uint64_t rowcap = (rs + 31) & ~7ull;
+    *lds = ((rs + 31) & ~15ull) + (size_t)((swg ? 4 : 2) * rowcap + 64) * 2 + 256;
+    if (*lds > 160 * 1024) return false;
+    const uint32_t per_cu = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(16, 32 / nw), std::max<uint64_t>(1, (160 * 1024) / (*lds + 256)));
+    uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     while (g > 8 && per * g > budget) g -= 8;
     if (per * g > budget) return false;
-    (void)cell8;
     *grid = g;
-    const bool swg = p.algo == AIM_ALGO_SWG;
-    *lds = ((rs + 15) & ~15ull) + (size_t)((swg ? 4 : 2) * (rs + 16) + rs + 16) * 2;
     *scratch_per_wg = per;
     *scratch_total = (size_t)(per * g);
-    return *lds <= 160 * 1024;
+    return true;
 }
 
 inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-#define AIM_DPW(KERNEL)                                                                              \
+    const int nw = dp_wave_nw(p);
+#define AIM_DPW(KERNEL, NWV)                                                                          \
     do {                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWave), lds, s, ka);                             \
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWave * NWV), lds, s, ka);                       \
+    } while (0)
+#define AIM_DPW_NW(ALGOV, BTV, C8V)                                                                   \
+    do {                                                                                             \
+        if (nw == 1) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 1>), 1);                               \
+        else if (nw == 2) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 2>), 2);                          \
+        else if (nw == 4) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 4>), 4);                          \
+        else AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 8>), 8);                                       \
     } while (0)
     if (p.algo == AIM_ALGO_NW) {
-        if (bt) AIM_DPW((dp_wave_kernel<AIM_ALGO_NW, true, false>)); else AIM_DPW((dp_wave_kernel<AIM_ALGO_NW, false, false>));
+        if (bt) AIM_DPW_NW(AIM_ALGO_NW, true, false); else AIM_DPW_NW(AIM_ALGO_NW, false, false);
     } else if (cell8) {
-        if (bt) AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, true, true>)); else AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, false, true>));
+        if (bt) AIM_DPW_NW(AIM_ALGO_SWG, true, true); else AIM_DPW_NW(AIM_ALGO_SWG, false, true);
     } else {
-        if (bt) AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, true, false>)); else AIM_DPW((dp_wave_kernel<AIM_ALGO_SWG, false, false>));
+        if (bt) AIM_DPW_NW(AIM_ALGO_SWG, true, false); else AIM_DPW_NW(AIM_ALGO_SWG, false, false);
     }
+#undef AIM_DPW_NW
 #undef AIM_DPW
 }
 
