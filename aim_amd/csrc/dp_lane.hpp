@@ -10,11 +10,14 @@
 // serial walk.  Bit-exactness (including int8/int16 wrap on store, S3) needs
 // the reference's elementary operations in the reference's order; pairs are
 // independent, so the parallel axis is the pair: each lane evaluates its own
-// flat table literally.  The table lives in a per-wave HBM scratch slab,
-// lane-interleaved (cell idx of lane l at [idx*64 + l]) so lanes of equal tlen
-// touch contiguous 64-element segments; sequences are staged per wave in LDS,
-// transposed to [dword][lane] so every per-lane read is bank-conflict free.
+// table with the reference's cell order.  Rows live in LDS (in-place, see
+// below); with BACKTRACE the flat table is additionally streamed, write-only,
+// to a per-wave HBM slab that is lane-interleaved (cell idx of lane l at
+// [idx*64 + l]) and read back by the traceback; sequences are staged per wave
+// in LDS, transposed to [dword][lane] so every per-lane read is conflict free.
 #pragma once
+
+#include <type_traits>
 
 #include "aim_device.hpp"
 
@@ -38,6 +41,34 @@ __device__ __forceinline__ void stage_rows_transposed(uint32_t *img, const char 
     }
 }
 
+// In-place row arrays in LDS, transposed [cell][lane] (int16): lane l's cell v at R[v*64 + l]; a wave-instruction
+// touches one dword per lane pair whatever v each lane uses, so every access is bank-conflict free.
+//
+// One array per layer holds BOTH rows: while row h is computed, positions < v already hold row h and positions >= v
+// still hold row h-1.  That is exactly the overlap the reference's flat indexing creates (flat[W*(h-1) + v] for
+// v > W IS flat[W*h + (v-W)]), so its reads resolve as:
+//     left (flat[W*(h-1)+v])   : v < W -> R[v] (old),  v == W -> B_h,  v > W -> R[v-W] (new)
+//     diag (flat[W*(h-1)+v-1]) : v-1 < W -> old R[v-1] (carried in a register),  v-1 == W -> B_h,  v-1 > W -> R[v-1-W]
+//     up   (flat[W*h+v-1])     : the cell just computed (register); for v == 1 the boundary cell B_h
+//     B_h  (flat[W*h])         : h == 1 or plen < W -> the row-init value, else cell (h-1, W) = R[W] before row h
+// for every plen/tlen relation, with the reference's elementary operations in the reference's order (int8/int16
+// wrap on store included).  With BACKTRACE every computed cell (h, v) is also stored -- write-only -- at the
+// UNIFORM index (rs+1)*h + v of a lane-interleaved HBM slab, so all 64 lanes store to one contiguous segment per
+// step whatever their tlen.  The traceback reads flat index f = W*h + v exactly like the reference; flat_to_slab()
+// maps f to the cell that wrote flat[f] LAST in the reference's order:
+//     f = W*h' + v', v' >= 1, h' <= tlen  -> (h', v')          (an earlier tail cell (h'-1, v'+W) was overwritten)
+//     v' == 0                             -> (h'-1, W) if plen >= W and h' >= 2, else the row-init boundary (h', 0)
+//     h' > tlen                           -> (tlen, f - W*tlen)  (tail of the last row: nothing overwrote it)
+
+// flat index of the reference's table -> index in the uniform-stride slab (see the comment above)
+__device__ __forceinline__ int flat_to_slab(int f, int W, int S, int plen, int tlen)
+{
+    int hq = f / W, vq = f - hq * W;
+    if (hq > tlen) { vq = f - W * tlen; hq = tlen; }
+    else if (vq == 0 && hq >= 2 && plen >= W) { hq -= 1; vq = W; }
+    return S * hq + vq;
+}
+
 template <bool BT, bool SEQ_LDS>
 __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
 {
@@ -45,12 +76,13 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
     typedef int16_t cell_t;   // NW_W16, NW/DPU-WRAM/common/common.h:87-97
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
-    uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *imgT = imgP + (SEQ_LDS ? rsw * kWave : 0);
-    cell_t *tb = reinterpret_cast<cell_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
+    uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);                             // pattern image [dword][lane]
+    int16_t *R = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));    // [(rs+1)][64]
+    cell_t *tb = BT ? reinterpret_cast<cell_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
 #define TB(idx) tb[(size_t)(idx) * kWave + lane]
+#define RW(v) R[(v) * kWave + lane]
 
     for (uint32_t it = 0;; ++it) {
         uint32_t grp;
@@ -60,44 +92,86 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         const bool active = pair < a.n_pairs;
         const int n_rows = min((uint32_t)kWave, a.n_pairs - pair0);
         __syncthreads();
-        if (SEQ_LDS) {
-            stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
-            stage_rows_transposed(imgT, a.texts + (uint64_t)pair0 * rs, rsw, n_rows, lane);
-        }
+        if (SEQ_LDS) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
         __syncthreads();
         if (!active) continue;
         const aim_request_t rq = a.req[pair];
         const int plen = rq.pattern_len, tlen = rq.text_len;
-        const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
-        const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
-        const int num_cols = tlen + 1;
+        const uint32_t *gP32 = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
+        const uint32_t *gT32 = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
+        const int W = tlen + 1;   // num_cols
+        const int S = rs + 1;     // uniform slab stride
+        uint32_t tw = 0;
 
         // nw_compute, nw.c:109-153
-        int cell = 0;
-        TB(0) = 0;
-        for (int v = 1; v <= plen; ++v) { cell += GAP_D; TB(v) = (cell_t)cell; }
-        cell = 0;
-        for (int h = 1; h <= tlen; ++h) { cell += GAP_I; TB(num_cols * h) = (cell_t)cell; }
+        {
+            int cell = 0;
+            RW(0) = 0;
+            if (BT) TB(0) = 0;
+            for (int v = 1; v <= plen; ++v) { cell += GAP_D; RW(v) = (cell_t)cell; if (BT) TB(v) = (cell_t)cell; }
+            if (BT) {
+                cell = 0;
+                for (int h = 1; h <= tlen; ++h) { cell += GAP_I; TB(S * h) = (cell_t)cell; }
+            }
+        }
         cell_t score = 0;
         for (int h = 1; h <= tlen; ++h) {
-            const uint32_t tch = SEQ_LDS ? seq_byte(imgT, h - 1, lane) : gT[h - 1];
-            const int row = num_cols * h, prow = row - num_cols;
-            // flat[row + v - 1] is the cell just written (v >= 2) and flat[prow + v - 1] is the
-            // previous iteration's `ins` source: both carried in registers (same values the
-            // reference re-reads; no store can intervene, see DESIGN.md "NW/SWG").
-            cell_t up = TB(row);
-            cell_t diag = TB(prow);
-            for (int v = 1; v <= plen; ++v) {
-                const cell_t left = TB(prow + v);
-                const uint32_t pch = SEQ_LDS ? seq_byte(imgP, v - 1, lane) : gP[v - 1];
-                const cell_t del = (cell_t)(up + GAP_D);
-                const cell_t ins = (cell_t)(left + GAP_I);
-                const cell_t mm = (cell_t)(diag + ((pch == tch) ? 0 : MISMATCH));
-                const cell_t m = min(mm, min(ins, del));
-                TB(row + v) = m;
-                score = m;
-                up = m;
-                diag = left;
+            if (((h - 1) & 3) == 0) tw = gT32[(h - 1) >> 2];          // one text dword per 4 rows
+            const uint32_t tch = (tw >> (((h - 1) & 3) * 8)) & 0xffu;
+            const cell_t B = (h == 1 || plen < W) ? (cell_t)(h * GAP_I) : (cell_t)RW(W);
+            cell_t dgc = RW(0);
+            RW(0) = B;
+            cell_t up = B;
+            const int row = S * h;
+            // chunks of 8 cells: the old-row values and pattern bytes of a chunk are fetched up front (the
+            // writes of the chunk only touch lower indices), then the 8 cells run back to back in registers
+            for (int v0 = 1; v0 <= plen; v0 += 8) {
+                const int w0 = (v0 - 1) >> 2;
+                const uint32_t pa = SEQ_LDS ? imgP[w0 * kWave + lane] : gP32[w0];
+                const uint32_t pb = (w0 + 1 < rsw) ? (SEQ_LDS ? imgP[(w0 + 1) * kWave + lane] : gP32[w0 + 1]) : 0u;
+                cell_t olds[8];
+                if (__all((v0 + 7 <= plen) && (v0 + 7 < W))) {
+                    // whole chunk inside the row and left of the aliasing column for EVERY lane: no guards, no branches
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) olds[j] = (cell_t)RW(v0 + j);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t pch = ((j < 4 ? pa : pb) >> ((j & 3) * 8)) & 0xffu;
+                        const cell_t del = (cell_t)(up + GAP_D);
+                        const cell_t ins = (cell_t)(olds[j] + GAP_I);
+                        const cell_t mm = (cell_t)(dgc + ((pch == tch) ? 0 : MISMATCH));
+                        const cell_t m = min(mm, min(ins, del));
+                        RW(v0 + j) = m;
+                        if (BT) TB(row + v0 + j) = m;
+                        up = m;
+                        dgc = olds[j];
+                    }
+                    score = up;
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) olds[j] = (v0 + j <= plen) ? (cell_t)RW(v0 + j) : (cell_t)0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int v = v0 + j;
+                    if (v <= plen) {
+                        const cell_t old = olds[j];
+                        cell_t left, dg;
+                        if (v < W) { left = old; dg = dgc; }
+                        else if (v == W) { left = B; dg = dgc; }
+                        else { left = RW(v - W); dg = (v - 1 == W) ? B : (cell_t)RW(v - 1 - W); }
+                        const uint32_t pch = ((j < 4 ? pa : pb) >> ((j & 3) * 8)) & 0xffu;
+                        const cell_t del = (cell_t)(up + GAP_D);
+                        const cell_t ins = (cell_t)(left + GAP_I);
+                        const cell_t mm = (cell_t)(dg + ((pch == tch) ? 0 : MISMATCH));
+                        const cell_t m = min(mm, min(ins, del));
+                        RW(v) = m;
+                        if (BT) TB(row + v) = m;
+                        score = m;
+                        up = m;
+                        dgc = old;
+                    }
+                }
             }
         }
         int begin_offset = plen + tlen - 1;
@@ -105,13 +179,13 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         if (BT) {   // nw_traceback, nw.c:67-107
             char *ops = a.ops + (uint64_t)pair * 2 * rs;
             int sentinel = end_offset - 1;
-            int h = num_cols - 1, v = plen;
+            int h = tlen, v = plen;
             while (h > 0 && v > 0) {
-                const int at = num_cols * h + v;
-                const int c = TB(at);
-                if (c == TB(at - 1) + GAP_D) { ops[sentinel--] = 'D'; --v; }
-                else if (c == TB(at - num_cols) + GAP_I) { ops[sentinel--] = 'I'; --h; }
-                else { ops[sentinel--] = (c == TB(at - num_cols - 1) + MISMATCH) ? 'X' : 'M'; --h; --v; }
+                const int at = W * h + v;
+                const int c = TB(flat_to_slab(at, W, S, plen, tlen));
+                if (c == TB(flat_to_slab(at - 1, W, S, plen, tlen)) + GAP_D) { ops[sentinel--] = 'D'; --v; }
+                else if (c == TB(flat_to_slab(at - W, W, S, plen, tlen)) + GAP_I) { ops[sentinel--] = 'I'; --h; }
+                else { ops[sentinel--] = (c == TB(flat_to_slab(at - W - 1, W, S, plen, tlen)) + MISMATCH) ? 'X' : 'M'; --h; --v; }
             }
             while (h > 0) { ops[sentinel--] = 'I'; --h; }
             while (v > 0) { ops[sentinel--] = 'D'; --v; }
@@ -127,6 +201,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         a.res[pair] = r;
     }
 #undef TB
+#undef RW
 }
 
 template <typename CELL, bool BT, bool SEQ_LDS>
@@ -135,16 +210,35 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
-    uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *imgT = imgP + (SEQ_LDS ? rsw * kWave : 0);
-    CELL *tb = reinterpret_cast<CELL *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
+    uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);                             // pattern image [dword][lane]
+    int16_t *RMa = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));  // M row, [(rs+1)][64]
+    int16_t *RIa = RMa + (rs + 1) * kWave;                                            // I row
+    // dp_cell_t {M, I, D} (SWG/DPU-WRAM/common/common.h:112-118): one packed word per cell and lane, [idx][lane]:
+    // int8 cells -> uint32 (M | I<<8 | D<<16), int16 cells -> uint2 ({M | I<<16}, D): a single store per cell
+    typedef typename std::conditional<sizeof(CELL) == 1, uint32_t, uint2>::type cellpack_t;
+    cellpack_t *tb = BT ? reinterpret_cast<cellpack_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
+    auto tb_store = [&](int idx, CELL m, CELL i, CELL d) {
+        if constexpr (sizeof(CELL) == 1) {
+            tb[(size_t)idx * kWave + lane] = (uint32_t)(uint8_t)m | ((uint32_t)(uint8_t)i << 8) | ((uint32_t)(uint8_t)d << 16);
+        } else {
+            tb[(size_t)idx * kWave + lane] = make_uint2((uint32_t)(uint16_t)m | ((uint32_t)(uint16_t)i << 16), (uint32_t)(uint16_t)d);
+        }
+    };
+    auto tb_load = [&](int idx, int &m, int &i, int &d) {
+        if constexpr (sizeof(CELL) == 1) {
+            const uint32_t w = tb[(size_t)idx * kWave + lane];
+            m = (int8_t)(w & 0xff); i = (int8_t)((w >> 8) & 0xff); d = (int8_t)((w >> 16) & 0xff);
+        } else {
+            const uint2 w = tb[(size_t)idx * kWave + lane];
+            m = (int16_t)(w.x & 0xffff); i = (int16_t)(w.x >> 16); d = (int16_t)(w.y & 0xffff);
+        }
+    };
     const int GAP_O = a.p.gap_o, GAP_E = a.p.gap_e, MATCH = a.p.match, MISMATCH = a.p.mismatch;
+    const int OE = GAP_O + GAP_E;
     const int MAX_SCORE = a.p.max_score;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
-    // dp_cell_t {M, I, D} (SWG/DPU-WRAM/common/common.h:112-118) as three lane-interleaved planes per cell
-#define TM(idx) tb[((size_t)(idx) * 3 + 0) * kWave + lane]
-#define TI(idx) tb[((size_t)(idx) * 3 + 1) * kWave + lane]
-#define TD(idx) tb[((size_t)(idx) * 3 + 2) * kWave + lane]
+#define RM(v) RMa[(v) * kWave + lane]
+#define RI(v) RIa[(v) * kWave + lane]
 
     for (uint32_t it = 0;; ++it) {
         uint32_t grp;
@@ -154,58 +248,101 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         const bool active = pair < a.n_pairs;
         const int n_rows = min((uint32_t)kWave, a.n_pairs - pair0);
         __syncthreads();
-        if (SEQ_LDS) {
-            stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
-            stage_rows_transposed(imgT, a.texts + (uint64_t)pair0 * rs, rsw, n_rows, lane);
-        }
+        if (SEQ_LDS) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
         __syncthreads();
         if (!active) continue;
         const aim_request_t rq = a.req[pair];
         const int plen = rq.pattern_len, tlen = rq.text_len;
-        const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
-        const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
-        const int num_cols = tlen + 1;
+        const uint32_t *gP32 = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
+        const uint32_t *gT32 = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
+        const int W = tlen + 1;
+        const int S = rs + 1;     // uniform slab stride
+        uint32_t tw = 0;
 
         // swg_compute, swg.c:121-171
-        TD(0) = (CELL)MAX_SCORE;
-        TI(0) = (CELL)MAX_SCORE;
-        TM(0) = 0;
+        RM(0) = 0;
+        RI(0) = (CELL)MAX_SCORE;
+        if (BT) tb_store(0, 0, (CELL)MAX_SCORE, (CELL)MAX_SCORE);
         for (int v = 1; v <= plen; ++v) {
             const CELL d = (CELL)(GAP_O + v * GAP_E);
-            TD(v) = d;
-            TI(v) = (CELL)MAX_SCORE;
-            TM(v) = d;
+            RM(v) = d;
+            RI(v) = (CELL)MAX_SCORE;
+            if (BT) tb_store(v, d, (CELL)MAX_SCORE, d);
         }
-        for (int h = 1; h <= tlen; ++h) {
-            const CELL i = (CELL)(GAP_O + h * GAP_E);
-            TD(num_cols * h) = (CELL)MAX_SCORE;
-            TI(num_cols * h) = i;
-            TM(num_cols * h) = i;
+        if (BT) {
+            for (int h = 1; h <= tlen; ++h) {
+                const CELL i = (CELL)(GAP_O + h * GAP_E);
+                tb_store(S * h, i, i, (CELL)MAX_SCORE);
+            }
         }
         int score = 0;
+        CELL nextBD = (CELL)MAX_SCORE;   // D of cell (h-1, W): the D layer of the next row's boundary cell
         for (int h = 1; h <= tlen; ++h) {
-            const uint32_t tch = SEQ_LDS ? seq_byte(imgT, h - 1, lane) : gT[h - 1];
-            const int row = num_cols * h, prow = row - num_cols;
-            CELL upM = TM(row), upD = TD(row);
-            CELL diagM = TM(prow);
-            for (int v = 1; v <= plen; ++v) {
-                const CELL leftM = TM(prow + v), leftI = TI(prow + v);
-                const uint32_t pch = SEQ_LDS ? seq_byte(imgP, v - 1, lane) : gP[v - 1];
-                const CELL del_new = (CELL)(upM + GAP_O + GAP_E);
-                const CELL del_ext = (CELL)(upD + GAP_E);
-                const CELL del = min(del_new, del_ext);
-                const CELL ins_new = (CELL)(leftM + GAP_O + GAP_E);
-                const CELL ins_ext = (CELL)(leftI + GAP_E);
-                const CELL ins = min(ins_new, ins_ext);
-                const CELL mm = (CELL)(diagM + ((pch == tch) ? MATCH : MISMATCH));
-                const CELL m = (CELL)min(mm, min(ins, del));
-                TD(row + v) = del;
-                TI(row + v) = ins;
-                TM(row + v) = m;
-                score = m;
-                upM = m;
-                upD = del;
-                diagM = leftM;
+            if (((h - 1) & 3) == 0) tw = gT32[(h - 1) >> 2];
+            const uint32_t tch = (tw >> (((h - 1) & 3) * 8)) & 0xffu;
+            CELL BM, BI, BD;
+            if (h == 1 || plen < W) { BM = BI = (CELL)(GAP_O + h * GAP_E); BD = (CELL)MAX_SCORE; }
+            else { BM = (CELL)RM(W); BI = (CELL)RI(W); BD = nextBD; }
+            CELL dgc = (CELL)RM(0);
+            RM(0) = BM;
+            RI(0) = BI;
+            CELL upM = BM, upD = BD;
+            const int row = S * h;
+            for (int v0 = 1; v0 <= plen; v0 += 8) {   // chunked as in nw_lane_kernel
+                const int w0 = (v0 - 1) >> 2;
+                const uint32_t pa = SEQ_LDS ? imgP[w0 * kWave + lane] : gP32[w0];
+                const uint32_t pb = (w0 + 1 < rsw) ? (SEQ_LDS ? imgP[(w0 + 1) * kWave + lane] : gP32[w0 + 1]) : 0u;
+                CELL oldMs[8], oldIs[8];
+                if (__all((v0 + 7 <= plen) && (v0 + 7 < W))) {   // guard-free chunk (see nw_lane_kernel)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { oldMs[j] = (CELL)RM(v0 + j); oldIs[j] = (CELL)RI(v0 + j); }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t pch = ((j < 4 ? pa : pb) >> ((j & 3) * 8)) & 0xffu;
+                        const CELL del = min((CELL)(upM + OE), (CELL)(upD + GAP_E));
+                        const CELL ins = min((CELL)(oldMs[j] + OE), (CELL)(oldIs[j] + GAP_E));
+                        const CELL mm = (CELL)(dgc + ((pch == tch) ? MATCH : MISMATCH));
+                        const CELL m = (CELL)min(mm, min(ins, del));
+                        RM(v0 + j) = m;
+                        RI(v0 + j) = ins;
+                        if (BT) tb_store(row + v0 + j, m, ins, del);
+                        upM = m;
+                        upD = del;
+                        dgc = oldMs[j];
+                    }
+                    score = upM;
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = v0 + j <= plen;
+                    oldMs[j] = in ? (CELL)RM(v0 + j) : (CELL)0;
+                    oldIs[j] = in ? (CELL)RI(v0 + j) : (CELL)0;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int v = v0 + j;
+                    if (v <= plen) {
+                        const CELL oldM = oldMs[j], oldI = oldIs[j];
+                        CELL leftM, leftI, dg;
+                        if (v < W) { leftM = oldM; leftI = oldI; dg = dgc; }
+                        else if (v == W) { leftM = BM; leftI = BI; dg = dgc; }
+                        else { leftM = (CELL)RM(v - W); leftI = (CELL)RI(v - W); dg = (v - 1 == W) ? BM : (CELL)RM(v - 1 - W); }
+                        const uint32_t pch = ((j < 4 ? pa : pb) >> ((j & 3) * 8)) & 0xffu;
+                        const CELL del = min((CELL)(upM + OE), (CELL)(upD + GAP_E));
+                        const CELL ins = min((CELL)(leftM + OE), (CELL)(leftI + GAP_E));
+                        const CELL mm = (CELL)(dg + ((pch == tch) ? MATCH : MISMATCH));
+                        const CELL m = (CELL)min(mm, min(ins, del));
+                        RM(v) = m;
+                        RI(v) = ins;
+                        if (v == W) nextBD = del;
+                        if (BT) tb_store(row + v, m, ins, del);
+                        score = m;
+                        upM = m;
+                        upD = del;
+                        dgc = oldM;
+                    }
+                }
             }
         }
         int begin_offset = plen + tlen - 1;
@@ -219,24 +356,28 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
             }
             enum { L_M, L_I, L_D };
             int sentinel = end_offset - 1;
-            int h = num_cols - 1, v = plen;
+            int h = tlen, v = plen;
             int layer = L_M;
             while (h > 0 && v > 0) {
-                const int at = num_cols * h + v;
+                const int at = W * h + v;
+                int cm, ci, cd, um, ui, ud, lm, li, ld, gm, gi, gd;
+                tb_load(flat_to_slab(at, W, S, plen, tlen), cm, ci, cd);
+                tb_load(flat_to_slab(at - 1, W, S, plen, tlen), um, ui, ud);
+                tb_load(flat_to_slab(at - W, W, S, plen, tlen), lm, li, ld);
+                tb_load(flat_to_slab(at - W - 1, W, S, plen, tlen), gm, gi, gd);
                 if (layer == L_D) {
                     ops[sentinel--] = 'D';
-                    if ((int)TD(at) == (int)TM(at - 1) + GAP_O + GAP_E) layer = L_M;
+                    if (cd == um + OE) layer = L_M;
                     --v;
                 } else if (layer == L_I) {
                     ops[sentinel--] = 'I';
-                    if ((int)TI(at) == (int)TM(at - num_cols) + GAP_O + GAP_E) layer = L_M;
+                    if (ci == lm + OE) layer = L_M;
                     --h;
                 } else {
-                    const int m = TM(at);
-                    if (m == (int)TD(at)) layer = L_D;
-                    else if (m == (int)TI(at)) layer = L_I;
-                    else if (m == (int)TM(at - num_cols - 1) + MATCH) { ops[sentinel--] = 'M'; --h; --v; }
-                    else if (m == (int)TM(at - num_cols - 1) + MISMATCH) { ops[sentinel--] = 'X'; --h; --v; }
+                    if (cm == cd) layer = L_D;
+                    else if (cm == ci) layer = L_I;
+                    else if (cm == gm + MATCH) { ops[sentinel--] = 'M'; --h; --v; }
+                    else if (cm == gm + MISMATCH) { ops[sentinel--] = 'X'; --h; --v; }
                     else { status = AIM_PAIR_SWG_NO_OP; break; }
                 }
             }
@@ -255,9 +396,8 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         r.idx = rq.idx;
         a.res[pair] = r;
     }
-#undef TM
-#undef TI
-#undef TD
+#undef RM
+#undef RI
 }
 
 inline int swg_cell_bytes(const aim_params_t &p)
@@ -271,10 +411,11 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
                          size_t *lds, uint64_t *scratch_per_wg, size_t *scratch_total, bool *seq_lds)
 {
     const uint64_t rs = (uint64_t)p.read_size;
-    const uint64_t cells = (rs + 1) * rs + rs + 2;   // max flat index num_cols*tlen + plen, lengths <= read_size
-    const uint64_t cell_b = (p.algo == AIM_ALGO_NW) ? 2 : 3ull * swg_cell_bytes(p);
+    const uint64_t cells = (rs + 1) * (rs + 2);       // uniform-stride slab: (rs+1) columns x (rs+1) rows
+    const uint64_t cell_b = (p.algo == AIM_ALGO_NW) ? 2 : (swg_cell_bytes(p) == 1 ? 4ull : 8ull);   // SWG: one packed word per cell
     uint64_t per = cells * cell_b * kWave;
     per = (per + 255) & ~255ull;
+    if (!(p.flags & AIM_FLAG_BACKTRACE)) per = 256;   // score-only: no table at all
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
     uint32_t g = 256 * 8;
     const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
@@ -283,9 +424,16 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     if (per * g > budget) return false;
     *grid = g;
     *block = kWave;
-    const size_t img = 2 * (size_t)(p.read_size >> 2) * kWave * 4;
-    *seq_lds = img <= 64 * 1024;
-    *lds = *seq_lds ? img : 0;
+    const size_t img = (size_t)(p.read_size >> 2) * kWave * 4;   // pattern image only
+    const size_t rows = (size_t)(p.algo == AIM_ALGO_NW ? 1 : 2) * (p.read_size + 1) * kWave * 2;
+    *seq_lds = img + rows <= 150 * 1024;
+    *lds = rows + (*seq_lds ? img : 0);
+    if (*lds > 160 * 1024) return false;
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(12, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    if (g > 256 * per_cu) {
+        g = 256 * per_cu;
+        *grid = g;
+    }
     *scratch_per_wg = per;
     *scratch_total = (size_t)(per * g);
     return true;
@@ -294,7 +442,11 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
 inline void dp_lane_launch(const aim_params_t &p, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-#define AIM_DP_LAUNCH(KERNEL) hipLaunchKernelGGL((KERNEL), dim3(grid), dim3(kWave), lds, s, ka)
+#define AIM_DP_LAUNCH(KERNEL)                                                                                             \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWave), lds, s, ka);                                                  \
+    } while (0)
     if (p.algo == AIM_ALGO_NW) {
         if (bt) { if (seq_lds) AIM_DP_LAUNCH((nw_lane_kernel<true, true>)); else AIM_DP_LAUNCH((nw_lane_kernel<true, false>)); }
         else    { if (seq_lds) AIM_DP_LAUNCH((nw_lane_kernel<false, true>)); else AIM_DP_LAUNCH((nw_lane_kernel<false, false>)); }

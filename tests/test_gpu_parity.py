@@ -496,3 +496,28 @@ def test_wfa_group_kernel_coverage(gpu):
             _compare("wfa", params, req, pat, txt)
         seen_g.add((ms, rs))
     assert len(seen_g) >= 6
+
+
+def test_dp_lane_all_length_relations(gpu):
+    """Short-read NW/SWG over every plen/tlen relation, including plen >= 2*(tlen+1) where a tail cell lands two
+    rows further down the flat table: the in-place LDS rows and the last-writer mapping must still equal the oracle."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    pairs = []
+    for _ in range(300):
+        pl, tl = int(rng.integers(0, 112)), int(rng.integers(0, 112))
+        if rng.random() < 0.3:
+            tl = int(rng.integers(0, 12))
+        p = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=pl).tolist())
+        t = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=tl).tolist())
+        if rng.random() < 0.5 and pl > 10 and tl > 10:     # related sequences, so real alignments appear too
+            t = (p[: tl // 2] + t)[:tl]
+        pairs.append((p, t))
+    req, pat, txt = _mk(pairs, 112)
+    assert (req["pattern_len"] > 2 * req["text_len"] + 2).sum() > 20
+    for algo, ms, kw in (("nw", 40, dict(backtrace=True)), ("nw", 40, dict()), ("swg", 40, dict(backtrace=True)),
+                         ("swg", 200, dict(backtrace=True)), ("swg", 40, dict())):
+        params = engine.make_params(algo, ms, 112, **kw)
+        assert capi.load().aim_kernel_name(C.byref(params)) in (b"nw_lane_kernel", b"swg_lane_kernel")
+        _compare(algo, params, req, pat, txt, threads=4)
