@@ -46,6 +46,7 @@ template <int G>
 __device__ __forceinline__ int group_min(int v)
 {
     constexpr int big = 0x7fffffff;
+    if (G == 64) return wave_min_i32(v);   // a whole wavefront per pair
     if (G >= 2) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     if (G >= 4) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
     if (G >= 8) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
@@ -61,9 +62,10 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int lane = threadIdx.x;
     const int g = lane % G, q = lane / G;
     const int rs = a.p.read_size;
-    uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);                    // raw rows, PPW * rs bytes each
-    uint32_t *rowsT = rowsP + (PPW * rs) / 4;
-    uint32_t *pairmem = rowsT + (PPW * rs) / 4 + ((2 * PPW * rs / 4) & 1 ? 1 : 0);
+    const int rows_dw = ((PPW * rs + 15) / 16) * 4;                          // raw rows of one array, whole 16-B chunks
+    uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *rowsT = rowsP + rows_dw;
+    uint32_t *pairmem = rowsT + rows_dw + 1;
     // per-pair region
     uint32_t *mine = pairmem + q * c.pair_dwords;
     int16_t *Mw = reinterpret_cast<int16_t *>(mine);                        // [ring_m][wcap]
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     auto hD = [&](int s) { return hist + (size_t)s * hrow + 2 * c.wcap + kb; };
     auto hMeta = [&](int s) { return hist + (size_t)s * hrow + 3 * c.wcap; };
     const uint32_t n_units = (a.n_pairs + PPW - 1) / PPW;
-    const int nchunk_total = (PPW * rs) / 16;            // 16-B chunks per array per unit (PPW*rs % 16 == 0, checked by the planner)
+    const int nchunk_total = (PPW * rs + 15) / 16;       // 16-B chunks per array per unit (the last one may run into the next row / tail slack)
 
     auto dma = [&](uint32_t unit) {
         const uint32_t pair0 = unit * PPW;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c, int *G, uint32_t *grid, size_t *lds, size_t *hist_bytes)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
-    if (p.read_size > 512 || p.max_score > 120) return false;
+    if (p.read_size > 2048 || p.max_score > 400) return false;
     const int R = p.mismatch > p.gap_o + p.gap_e ? p.mismatch : p.gap_o + p.gap_e;
     int ring_m = 1, ring_e = 1;
     while (ring_m <= R) ring_m *= 2;
@@ -441,11 +443,13 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
         while (g <= 16 && (size_t)(kWave / g) * dw * 4 > cap_bytes) g *= 2;
         if (g <= 16) break;
     }
-    if (g > 16) return false;
-    if (((kWave / g) * p.read_size) % 16 != 0) return false;
+    if (g > 16) {   // a whole wavefront per pair (long reads / large MAX_SCORE)
+        if ((size_t)dw * 4 > 48 * 1024) return false;
+        g = 64;
+    }
     *G = g;
     c->rows_per_wave = kWave / g;
-    const size_t rows_bytes = (size_t)2 * (kWave / g) * p.read_size + 4;
+    const size_t rows_bytes = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(AIM_GROUP_WGS_PER_CU, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
@@ -474,6 +478,7 @@ inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, ui
     case 4: AIM_GRP(4); break;
     case 8: AIM_GRP(8); break;
     case 16: AIM_GRP(16); break;
+    case 64: AIM_GRP(64); break;
     default: break;
     }
 #undef AIM_GRP
