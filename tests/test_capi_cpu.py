@@ -80,6 +80,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_scratch_bytes(C.byref(engine.make_params("wfa", 5, 110)), 16) == 0   # invalid read_size
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112))) == b"wfa_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True))) == b"wfa_lane_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True, mismatch=4))) == b"wfa_wave_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112))) == b"wfa_wave_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True, mismatch=4))) == b"wfa_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112))) == b"wfa_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 250, 1064, backtrace=True, reduce=True))) == b"wfa_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 2000, 8000))) == b"wfa_wave_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 500, 10112, backtrace=True))) == b"dp_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_lane_kernel"
