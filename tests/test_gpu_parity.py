@@ -521,3 +521,33 @@ def test_dp_lane_all_length_relations(gpu):
         params = engine.make_params(algo, ms, 112, **kw)
         assert capi.load().aim_kernel_name(C.byref(params)) in (b"nw_lane_kernel", b"swg_lane_kernel")
         _compare(algo, params, req, pat, txt, threads=4)
+
+
+def test_host_cli_parser_quirks_match_oracle_cli(gpu, sample_bytes, tmp_path):
+    """The parallel mmap parser keeps get_reads' behaviour (host.c:91-134, 191): a last line without newline loses
+    its final base, a trailing unpaired line is dropped, n is not a cap (ROUND_UP_8(n/d)*d pairs are consumed) --
+    whole-file comparison with the oracle's restatement of the reference host."""
+    import subprocess
+    from conftest import ROOT
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    cli = os.path.join(ROOT, "oracle", "oracle_cli")
+    lines = sample_bytes.split(b"\n")[:2001]                  # 1000 pairs + one unpaired line
+    variants = {
+        "plain": b"\n".join(lines[:2000]) + b"\n",
+        "no_final_newline": b"\n".join(lines[:2000]),         # last text line loses its last base
+        "unpaired_tail": b"\n".join(lines[:2001]) + b"\n",
+    }
+    for name, data in variants.items():
+        inp = tmp_path / (name + ".seq")
+        inp.write_bytes(data)
+        for n, d, flags_h, flags_o in ((1000, 1, ["--backtrace", "--reduce"], ["-b", "-r"]), (100, 4, [], []),
+                                       (5000, 3, ["--backtrace"], ["-b"])):
+            oh, oo = tmp_path / "h.out", tmp_path / "o.out"
+            rh = subprocess.run([host, str(inp), str(oh), str(n), "--algo", "wfa", "--max-score", "5", "--read-size", "112",
+                                 "--nr-dpus", str(d), "--threads", "7"] + flags_h, capture_output=True, text=True, cwd=str(tmp_path))
+            ro = subprocess.run([cli, "wfa", "-i", str(inp), "-o", str(oo), "-n", str(n), "-l", "100", "-e", "0.01", "-d", str(d)] + flags_o,
+                                capture_output=True, text=True)
+            assert rh.returncode == 0 and ro.returncode == 0, (name, n, d, rh.stdout, rh.stderr, ro.stderr)
+            assert oh.read_bytes() == oo.read_bytes(), (name, n, d)
+            assert oh.read_bytes().count(b", \n") == min(len(data.split(b"\n")) // 2 if not data.endswith(b"\n") else data.count(b"\n") // 2,
+                                                          ((n // d + 7) // 8) * 8 * d)
