@@ -264,6 +264,20 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             }
             if (__ballot(!done) == 0ull) break;
             ++score;
+#if defined(AIM_GROUP_PAD_VALU) || defined(AIM_GROUP_PAD_SALU)
+            {   // diagnostic only: N independent ALU ops per score step, to tell issue-bound from stall-bound
+#ifdef AIM_GROUP_PAD_VALU
+                int padv[8] = {g, g, g, g, g, g, g, g};      // 8 accumulators round-robin: consecutive ops are independent
+#pragma unroll
+                for (int q = 0; q < AIM_GROUP_PAD_VALU; ++q) asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv[q & 7]));
+#endif
+#ifdef AIM_GROUP_PAD_SALU
+                int pads[8] = {score, score, score, score, score, score, score, score};
+#pragma unroll
+                for (int q = 0; q < AIM_GROUP_PAD_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pads[q & 7]));
+#endif
+            }
+#endif
             if (!done) {
                 // ---- affine_wfa_compute_next, wfa.c:268-340 --------------------------------------------------------
                 const int s_sub = score - X, s_o = score - OE, s_e = score - E;

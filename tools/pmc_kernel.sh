@@ -3,7 +3,8 @@
 # usage: tools/pmc_kernel.sh <config> <kernel-substring>
 cfg=$1; kern=$2
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
+if [ -n "$AIM_PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$AIM_PMC_SETS"; else SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES"); fi
+for set in "${SETS[@]}"; do
   d=gpurun_out/pmc_$$; rm -rf $d
   timeout 600 rocprofv3 --kernel-trace --pmc $set -d $d -o p --output-format csv -- python3 tools/bench_configs.py $cfg > /dev/null 2>&1
   python3 - "$d" "$kern" <<'PY'
