@@ -465,7 +465,11 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     c->rows_per_wave = kWave / g;
     const size_t rows_bytes = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(AIM_GROUP_WGS_PER_CU, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    const size_t lds_fit = std::max<size_t>(1, (160 * 1024) / (*lds + 256));
+    // the cap of 8 was measured on the G <= 16 plans; with a wavefront per pair the kernel still gains from residency up
+    // to what LDS admits (cfg3: 8 -> 10 per CU = 1.15x), so G = 64 takes everything that fits
+    uint32_t per_cu = g == 64 ? (uint32_t)std::min<size_t>(16, lds_fit) : (uint32_t)std::min<size_t>(AIM_GROUP_WGS_PER_CU, lds_fit);
+    if (const char *e = getenv("AIM_GROUP_PER_CU")) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), lds_fit);   // residency sweeps
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
     uint32_t gr = 256 * per_cu;
     const uint32_t need = ((n_units + 7u) / 8u) * 8u;
