@@ -18,6 +18,7 @@
 
 #include <cstdlib>
 
+#include <cstdio>
 #include "aim_device.hpp"
 #include "wfa_lane.hpp"
 
@@ -30,7 +31,7 @@ namespace aim {
 struct GroupCfg {
     int kbias;        // MAX_SCORE + 1: slot index of diagonal k is k + kbias
     int wcap;         // 2*MAX_SCORE + 3 entries per ring row
-    int ring_m;       // power of two > max(x, o+e)
+    int ring_m;       // rows of the M / descriptor ring: max(x, o+e) + 1 (wfa_diag_kernel: a power of two above it)
     int ring_e;       // power of two > e
     int np;           // packed dwords per sequence (READ_SIZE/16 rounded up) + 1 pad
     int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)
@@ -62,7 +63,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int lane = threadIdx.x;
     const int g = lane % G, q = lane / G;
     const int rs = a.p.read_size;
-    const int rows_dw = ((PPW * rs + 15) / 16) * 4;                          // raw rows of one array, whole 16-B chunks
+    // raw rows of one array, whole 16-B chunks; a whole-wavefront group (G == 64) packs straight from global memory
+    // instead (one pair per ~2 ms of compute: nothing to hide, and 2*READ_SIZE bytes of LDS buy residency)
+    const int rows_dw = G == 64 ? 0 : ((PPW * rs + 15) / 16) * 4;
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + rows_dw;
     uint32_t *pairmem = rowsT + rows_dw + 1;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int nchunk_total = (PPW * rs + 15) / 16;       // 16-B chunks per array per unit (the last one may run into the next row / tail slack)
 
     auto dma = [&](uint32_t unit) {
+        if (G == 64) return;
         const uint32_t pair0 = unit * PPW;
         const uint32_t rows = min((uint32_t)PPW, a.n_pairs - pair0);
         const int nchunks = (int)((rows * rs + 15) / 16);
@@ -104,7 +108,14 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             }
         }
     };
-    auto mslot = [&](int s) { return Mw + (s & (c.ring_m - 1)) * c.wcap + kb; };   // row pointer biased: row[k]
+    // M / descriptor ring of exactly max(x, o+e) + 1 rows, addressed by row index. The score counter is wave-uniform (all
+    // pairs of a wavefront step together), so sm = score % ring_m is a running scalar and the rows of score - x,
+    // score - (o+e) and score - e (the only ones ever read; all < ring_m back) are derived from it once per score step.
+    // Computing the index at every use instead measured 3-5 % slower on the G <= 16 plans.
+    int score = 0, sm = 0, i_x = 0, i_oe = 0, i_e = 0;
+    auto back = [&](int d) { const int i = sm - d; return i < 0 ? i + c.ring_m : i; };   // 0 <= d < ring_m
+    auto mrow_at = [&](int i) { return Mw + i * c.wcap + kb; };                      // row pointer biased: row[k]
+    auto meta_at = [&](int i) { return meta + i * 4; };
     auto islot = [&](int s) { return Iw + (s & (c.ring_e - 1)) * c.wcap + kb; };
     auto dslot = [&](int s) { return Dw + (s & (c.ring_e - 1)) * c.wcap + kb; };
     auto fence = [&]() { asm volatile("" ::: "memory"); };   // same-wave LDS traffic is ordered; compiler fence only
@@ -127,7 +138,8 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         // ---- validate + pack: the G lanes of a group split the packed dwords of their pair ------------------------
         uint32_t bad = 0;
         {
-            const uint32_t *rp = rowsP + (q * rs) / 4, *rt = rowsT + (q * rs) / 4;
+            const uint32_t *rp = G == 64 ? reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs) : rowsP + (q * rs) / 4;
+            const uint32_t *rt = G == 64 ? reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs) : rowsT + (q * rs) / 4;
             const int npw = (rs + 15) / 16;
             for (int j = g; j < npw; j += G) {
 #pragma unroll
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int w = 4 * j + i;
-                        const uint32_t av = (4 * w < rs) ? r[w] : 0u;
+                        const uint32_t av = (4 * w < rs && (G != 64 || active)) ? r[w] : 0u;
                         const uint32_t t = (av >> 1) & 0x03030303u;
                         const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);
                         const int rem = len - 4 * w;
@@ -187,12 +199,13 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         };
 
         const int ak = tlen - plen;
-        int score = 0, final_score = -1;
+        score = 0; sm = 0; i_x = i_oe = i_e = 0;
+        int final_score = -1;
         bool done = !active || bad != 0u;
         // wavefronts[0]: lo = hi = 0, M[0] = 0 (wfa.c:347-348)
         int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
         if (g == 0) {
-            mslot(0)[0] = 0;
+            mrow_at(0)[0] = 0;
             meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
         }
         if (BT && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         for (;;) {
             if (!done) {
                 const bool live = (flags & GF_PRESENT) && !(flags & GF_MNULL);
-                int16_t *mrow = mslot(score);
+                int16_t *mrow = mrow_at(sm);
                 if (live) {
                     for (int k = klo + g; k <= khi; k += G) {
                         const int off = mrow[k];
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     if (nklo > nkhi) flags |= GF_MNULL | GF_INULL | GF_DNULL;
                     else { klo = nklo; khi = nkhi; }
                     if (g == 0) {
-                        int16_t *me = meta + (score & (c.ring_m - 1)) * 4;
+                        int16_t *me = meta_at(sm);
                         me[0] = (int16_t)klo; me[1] = (int16_t)khi; me[2] = (int16_t)flags;
                     }
                     fence();
@@ -264,6 +277,8 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             }
             if (__ballot(!done) == 0ull) break;
             ++score;
+            sm = sm + 1 == c.ring_m ? 0 : sm + 1;
+            i_x = back(X); i_oe = back(OE); i_e = back(E);
 #if defined(AIM_GROUP_PAD_VALU) || defined(AIM_GROUP_PAD_SALU)
             {   // diagnostic only: N independent ALU ops per score step, to tell issue-bound from stall-bound
 #ifdef AIM_GROUP_PAD_VALU
@@ -282,9 +297,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                 // ---- affine_wfa_compute_next, wfa.c:268-340 --------------------------------------------------------
                 const int s_sub = score - X, s_o = score - OE, s_e = score - E;
                 int sub_f = 0, o_f = 0, e_f = 0, sub_lo = 1, sub_hi = -1, o_lo = 1, o_hi = -1, e_lo = 1, e_hi = -1;
-                if (s_sub >= 0) { const int16_t *m = meta + (s_sub & (c.ring_m - 1)) * 4; sub_lo = m[0]; sub_hi = m[1]; sub_f = m[2]; }
-                if (s_o >= 0) { const int16_t *m = meta + (s_o & (c.ring_m - 1)) * 4; o_lo = m[0]; o_hi = m[1]; o_f = m[2]; }
-                if (s_e >= 0) { const int16_t *m = meta + (s_e & (c.ring_m - 1)) * 4; e_lo = m[0]; e_hi = m[1]; e_f = m[2]; }
+                if (s_sub >= 0) { const int16_t *m = meta_at(i_x); sub_lo = m[0]; sub_hi = m[1]; sub_f = m[2]; }
+                if (s_o >= 0) { const int16_t *m = meta_at(i_oe); o_lo = m[0]; o_hi = m[1]; o_f = m[2]; }
+                if (s_e >= 0) { const int16_t *m = meta_at(i_e); e_lo = m[0]; e_hi = m[1]; e_f = m[2]; }
                 const bool m_sub_null = (s_sub < 0) || !(sub_f & GF_PRESENT) || (sub_f & GF_MNULL);
                 const bool m_o_null = (s_o < 0) || !(o_f & GF_PRESENT) || (o_f & GF_MNULL);
                 const bool i_e_null = (s_e < 0) || !(e_f & GF_PRESENT) || !(e_f & GF_HASI) || (e_f & GF_INULL);
@@ -300,9 +315,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     const int hi = max(max(sub_hi, o_hi), e_hi) + 1;
                     flags = GF_PRESENT | (i_out_null ? GF_INULL : GF_HASI) | (d_out_null ? GF_DNULL : GF_HASD);
                     klo = lo; khi = hi;
-                    const int16_t *r_ms = mslot(s_sub < 0 ? 0 : s_sub), *r_mo = mslot(s_o < 0 ? 0 : s_o);
+                    const int16_t *r_ms = mrow_at(i_x), *r_mo = mrow_at(i_oe);   // valid rows even when the score does not exist
                     const int16_t *r_ie = islot(s_e < 0 ? 0 : s_e), *r_de = dslot(s_e < 0 ? 0 : s_e);
-                    int16_t *om = mslot(score), *oi = islot(score), *od = dslot(score);
+                    int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
                     for (int k = lo + g; k <= hi; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266
                         int ins = -10;
                         if (!i_out_null) {
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     }
                 }
                 if (g == 0) {
-                    int16_t *me = meta + (score & (c.ring_m - 1)) * 4;
+                    int16_t *me = meta_at(sm);
                     me[0] = (int16_t)klo; me[1] = (int16_t)khi; me[2] = (int16_t)flags;
                 }
             }
@@ -436,7 +451,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     if (p.read_size > 2048 || p.max_score > 400) return false;
     const int R = p.mismatch > p.gap_o + p.gap_e ? p.mismatch : p.gap_o + p.gap_e;
     int ring_m = 1, ring_e = 1;
-    while (ring_m <= R) ring_m *= 2;
+    ring_m = R + 1;
     while (ring_e <= p.gap_e) ring_e *= 2;
     if (ring_m > 32 || ring_e > 16) return false;
     c->kbias = p.max_score + 1;
@@ -448,7 +463,8 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     dw |= 1;
     c->pair_dwords = dw;
     // LDS budget for the wavefront windows of one wavefront's pairs: 12 KiB measured best (occupancy beats lanes per
-    // pair: 24 KiB -15..30 %, 48 KiB -45 %); wider budgets only when 16 lanes per pair do not fit otherwise
+    // pair: 24 KiB -15..30 %, 48 KiB -45 %); wider budgets only when 16 lanes per pair do not fit otherwise, and only
+    // while they still leave 6 workgroups per CU (below)
     int g = 32;
     for (size_t cap_kb : {12, 24, 48}) {
         size_t cap_bytes = cap_kb * 1024;
@@ -460,10 +476,20 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     if (g > 16) {   // a whole wavefront per pair (long reads / large MAX_SCORE)
         if ((size_t)dw * 4 > 48 * 1024) return false;
         g = 64;
+    } else {
+        // A G <= 16 plan that LDS holds to fewer than 6 workgroups per CU loses to a wavefront per pair at up to 16
+        // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s): 3 per CU 1.53x (l=1000 e=5%), 4 per CU
+        // 1.51x (l=400 e=10%); 6 per CU 1.02x / 0.89x / 0.77x; 8 per CU 0.71x / 0.66x. 5 per CU is not measured.
+        const size_t wg = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8 + (size_t)(kWave / g) * dw * 4 + 64;
+        if ((160 * 1024) / (wg + 256) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
+    }
+    if (const char *e = getenv("AIM_GROUP_G")) {   // experiments: force the lanes per pair if the plan is feasible at all
+        const int fg = atoi(e);
+        if ((fg == 1 || fg == 2 || fg == 4 || fg == 8 || fg == 16 || fg == 64) && (size_t)(kWave / fg) * dw * 4 <= 48 * 1024) g = fg;
     }
     *G = g;
     c->rows_per_wave = kWave / g;
-    const size_t rows_bytes = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
+    const size_t rows_bytes = g == 64 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
     const size_t lds_fit = std::max<size_t>(1, (160 * 1024) / (*lds + 256));
     // the cap of 8 was measured on the G <= 16 plans; with a wavefront per pair the kernel still gains from residency up
@@ -475,6 +501,9 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     const uint32_t need = ((n_units + 7u) / 8u) * 8u;
     if (gr > need) gr = need < 8u ? 8u : need;
     *grid = gr;
+    if (getenv("AIM_PLAN_DEBUG"))
+        fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u\n", g, ring_m, ring_e,
+                c->wcap, dw * 4, *lds, lds_fit, per_cu, gr);
     c->hist_stride = (p.max_score + 2) * (3 * c->wcap + 4);
     *hist_bytes = (p.flags & AIM_FLAG_BACKTRACE) ? (((size_t)gr * (kWave / g) * c->hist_stride * 2 + 255) & ~(size_t)255) : 0;
     return true;
