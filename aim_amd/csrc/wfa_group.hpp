@@ -204,8 +204,12 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         bool done = !active || bad != 0u;
         // wavefronts[0]: lo = hi = 0, M[0] = 0 (wfa.c:347-348)
         int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
+        // Every later wavefront is extended by the lane that computes it (below); score 0 has no compute step.
+        int part = 0x7fffffff;                     // min over my diagonals of the distance to the end (for the reduction)
         if (g == 0) {
-            mrow_at(0)[0] = 0;
+            const int m00 = done ? 0 : extend(0, 0);
+            mrow_at(0)[0] = (int16_t)m00;
+            if (BT && !done) hM(0)[0] = (int16_t)m00;
             meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
         }
         if (BT && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465
@@ -217,43 +221,25 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         for (;;) {
             if (!done) {
                 const bool live = (flags & GF_PRESENT) && !(flags & GF_MNULL);
-                int16_t *mrow = mrow_at(sm);
-                if (live) {
-                    for (int k = klo + g; k <= khi; k += G) {
-                        const int off = mrow[k];
-                        const int noff = extend(k, off);
-                        if (noff != off) mrow[k] = (int16_t)noff;
-                        if (BT) hM(score)[k] = (int16_t)noff;
-                    }
-                    fence();
-                }
+                int16_t *mrow = mrow_at(sm);               // already extended by the lanes that produced it
                 if (REDUCE && live && (khi - klo + 1) >= 10) {   // affine_wfa_reduce_wvs, wfa.c:69-140
-                    // the group's lanes split the diagonals; min / first-from-bottom / first-from-top are group reductions
-                    int part = 0x7fffffff;
+                    // the group's lanes split the diagonals. `part` (min distance over my diagonals) came with the row;
+                    // one pass finds my lowest and highest diagonal within 50 of the best. The reference's two scans --
+                    // first such k in [klo, top_limit) else top_limit; last such k in (bottom_limit, khi] else
+                    // bottom_limit -- are min(top_limit, lowest) and max(bottom_limit, highest) over the whole row.
+                    const int mind = min(max(plen, tlen), group_min<G>(part));
+                    int kfirst = 0x7fffffff, klast = -0x7fffffff;
                     for (int k = klo + g; k <= khi; k += G) {
                         const int off = mrow[k];
-                        part = min(part, max(plen - (off - k), tlen - off));
+                        if ((max(plen - (off - k), tlen - off) - mind) <= 50) { kfirst = min(kfirst, k); klast = max(klast, k); }
                     }
-                    const int mind = min(max(plen, tlen), group_min<G>(part));
+                    kfirst = group_min<G>(kfirst);
+                    klast = -group_min<G>(-klast);
                     int nklo = klo, nkhi = khi;
                     const int top_limit = min(ak - 1, khi);
-                    if (klo < top_limit) {   // first k in [klo, top_limit) whose distance is within 50 of the best, else top_limit
-                        int first = top_limit;
-                        for (int k = klo + g; k < top_limit; k += G) {
-                            const int off = mrow[k];
-                            if ((max(plen - (off - k), tlen - off) - mind) <= 50) { first = k; break; }
-                        }
-                        nklo = group_min<G>(first);
-                    }
+                    if (klo < top_limit) nklo = min(top_limit, kfirst);
                     const int bottom_limit = max(ak + 1, nklo);
-                    if (khi > bottom_limit) {   // last k in (bottom_limit, khi] within 50 of the best, else bottom_limit
-                        int last = bottom_limit;
-                        for (int k = khi - g; k > bottom_limit; k -= G) {
-                            const int off = mrow[k];
-                            if ((max(plen - (off - k), tlen - off) - mind) <= 50) { last = k; break; }
-                        }
-                        nkhi = -group_min<G>(-last);
-                    }
+                    if (khi > bottom_limit) nkhi = max(bottom_limit, klast);
                     if (nklo > nkhi) flags |= GF_MNULL | GF_INULL | GF_DNULL;
                     else { klo = nklo; khi = nkhi; }
                     if (g == 0) {
@@ -318,7 +304,8 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     const int16_t *r_ms = mrow_at(i_x), *r_mo = mrow_at(i_oe);   // valid rows even when the score does not exist
                     const int16_t *r_ie = islot(s_e < 0 ? 0 : s_e), *r_de = dslot(s_e < 0 ? 0 : s_e);
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
-                    for (int k = lo + g; k <= hi; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266
+                    part = 0x7fffffff;
+                    for (int k = lo + g; k <= hi; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
                         int ins = -10;
                         if (!i_out_null) {
                             const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? (int)r_mo[k - 1] : kGrpNull;
@@ -337,7 +324,12 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         }
                         int sub = -10;
                         if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(int16_t)(r_ms[k] + 1) : kGrpNull;
-                        om[k] = (int16_t)max(del, max(sub, ins));
+                        // M[s][k] as the reference stores it (int16), then affine_wfa_extend (wfa.c:186-208) on that value: a
+                        // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
+                        const int ext = extend(k, (int)(int16_t)max(del, max(sub, ins)));
+                        om[k] = (int16_t)ext;
+                        if (BT) hM(score)[k] = (int16_t)ext;
+                        part = min(part, max(plen - (ext - k), tlen - ext));
                     }
                 }
                 if (g == 0) {
