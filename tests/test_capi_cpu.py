@@ -86,3 +86,59 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 2000, 8000))) == b"wfa_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 500, 10112, backtrace=True))) == b"dp_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_lane_kernel"
+
+
+def _plan_line(params, n, env):
+    """The [aim plan] line a fresh process prints for these parameters (the budget default is cached per process)."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from aim_amd import capi, engine; lib = capi.load(); "
+            "p = engine.make_params(%r, %d, %d, reduce=True, backtrace=%r); print('SCRATCH', lib.aim_scratch_bytes(C.byref(p), %d))"
+            % (ROOT, "wfa" if params[0] == "wfa" else params[0], params[1], params[2], params[3], n))
+    e = dict(os.environ, AIM_PLAN_DEBUG="1", **env)
+    r = subprocess.run([os.sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    plan = [l for l in r.stderr.splitlines() if l.startswith("[aim plan] wfa_group")]
+    scratch = int(re.search(r"SCRATCH (\d+)", r.stdout).group(1))
+    return (plan[-1] if plan else ""), scratch
+
+
+def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(built):
+    """wfa_group_plan (measured rule): a G <= 16 plan that LDS holds below 6 workgroups per CU yields to
+    G = 64; plans with enough residency keep G <= 16; AIM_GROUP_G forces either."""
+    from aim_amd import engine
+    def G(l, e, **env):
+        ms, rs = engine.launcher_sizes("wfa", l, e)
+        line, _ = _plan_line(("wfa", ms, rs, False), 1 << 16, env)
+        m = re.search(r"G=(\d+) ring_m=(\d+) .* per_cu=(\d+)", line)
+        assert m, line
+        return int(m.group(1)), int(m.group(2)), int(m.group(3))
+    g, ring_m, per_cu = G(1000, 0.05)            # config 3: window of 503 diagonals
+    assert (g, ring_m) == (64, 6) and per_cu >= 12     # exact-size ring: max(x, o+e) + 1 = 6 rows
+    assert G(400, 0.10)[0] == 64                # 4 per CU at G = 16 -> a wavefront per pair
+    assert G(250, 0.10)[0] == 16                # 6 per CU at G = 16 stays (measured break-even)
+    assert G(100, 0.10)[0] == 16 and G(100, 0.02)[0] <= 16
+    assert G(1000, 0.05, AIM_GROUP_G="16")[0] == 16 and G(100, 0.10, AIM_GROUP_G="64")[0] == 64
+
+
+def test_scratch_bound_default_and_override(built):
+    """scratch_budget_bytes: without a device the planning queries use 16 GB; AIM_SCRATCH_GB overrides; plans are
+    need-capped (the headline's scratch does not depend on the bound), config 4's table slabs scale with it."""
+    from aim_amd import engine
+    ms4, rs4 = engine.launcher_sizes("swg", 10000, 0.01)
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from aim_amd import capi, engine; lib = capi.load(); "
+            "p4 = engine.make_params('swg', %d, %d, backtrace=True); ms, rs = engine.launcher_sizes('wfa', 100, 0.01); "
+            "p2 = engine.make_params('wfa', ms, rs, reduce=True); "
+            "print(lib.aim_scratch_bytes(C.byref(p4), 128), lib.aim_scratch_bytes(C.byref(p2), 1 << 22))" % (ROOT, ms4, rs4))
+    def q(**env):
+        e = {k: v for k, v in os.environ.items() if k != "AIM_SCRATCH_GB"}
+        e.update(env)
+        r = subprocess.run([os.sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        return tuple(int(x) for x in r.stdout.split())
+    per_pair = 3 * ((rs4 + 16) & ~7) * (rs4 + 3) * 2
+    c4_default, c2_default = q()
+    c4_16, c2_16 = q(AIM_SCRATCH_GB="16")
+    c4_100, c2_100 = q(AIM_SCRATCH_GB="100")
+    assert c4_default == c4_16                               # no GPU here: 16 GB fallback
+    assert c2_default == c2_16 == c2_100                     # need-capped plan
+    assert c4_16 <= 16 << 30 and c4_16 // per_pair in range(20, 28)     # 5 rounds of 128 pairs
+    assert c4_100 // per_pair == 128                         # one round

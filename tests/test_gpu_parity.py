@@ -580,3 +580,31 @@ def test_wfa_diag_kernel_coverage(gpu, monkeypatch):
     # gap_e != 1 is not eligible
     p2 = engine.make_params("wfa", 30, 112, gap_e=2)
     assert lib.aim_kernel_name(C.byref(p2)) != b"wfa_diag_kernel"
+
+
+@pytest.mark.gpu
+def test_wfa_group_lanes_per_pair_plans_agree_with_oracle(gpu, monkeypatch):
+    """wfa_group_plan's measured rule: the default plan and the forced AIM_GROUP_G = 16 / 64 plans of the
+    mid-range configurations the rule moved (l=400 e=10 % -> G=64) or kept (l=250 e=10 % -> G=16), and a short-window
+    configuration forced onto a whole wavefront per pair, all bit-identical to the oracle; fused compute+extend and the
+    one-pass reduction are exercised with and without WFA-adaptive and CIGAR; one non-ACGT pair goes to the to-do list."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    lib = capi.load()
+    for l, e, n in ((400, 0.10, 300), (250, 0.10, 400), (100, 0.10, 600), (1000, 0.02, 200)):
+        ms, rs = engine.launcher_sizes("wfa", l, e)
+        req, pat, txt = engine.gen_pairs(1234 + l, 0, n, l, e, rs)
+        pat[5, 2] = ord("N")
+        for force in (None, "16", "64"):
+            if force is None:
+                monkeypatch.delenv("AIM_GROUP_G", raising=False)
+            else:
+                monkeypatch.setenv("AIM_GROUP_G", force)
+            for red, bt in ((True, True), (True, False), (False, True)):
+                params = engine.make_params("wfa", ms, rs, reduce=red, backtrace=bt)
+                assert lib.aim_kernel_name(C.byref(params)) == b"wfa_group_kernel", (l, e, force)
+                with engine.DeviceSet(1) as ds:
+                    ds.align(params, req, pat, txt)
+                    assert ds.fallback_pairs(0) == 1
+                _compare("wfa", params, req, pat, txt)
+    monkeypatch.delenv("AIM_GROUP_G", raising=False)
