@@ -81,7 +81,12 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
     cell_t *tb = BT ? reinterpret_cast<cell_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
-#define TB(idx) tb[(size_t)(idx) * kWave + lane]
+    // HBM table slab: 8 consecutive slab indices of a lane form one 16-B unit, units lane-interleaved. With S a multiple
+    // of 8 and the +7 offset every chunk of the row loop (v0 = 1, 9, 17, ...) starts a unit, so a guard-free chunk is ONE
+    // 16-B store per lane (1 KB per wavefront) instead of eight 2-B stores: the table stream was bound by store
+    // instructions (one per cell, ~16 cycles of address processing each), not by bytes.
+#define TBI(idx) ((((size_t)((idx) + 7) >> 3) * kWave + lane) * 8 + (size_t)(((idx) + 7) & 7))
+#define TB(idx) tb[TBI(idx)]
 #define RW(v) R[(v) * kWave + lane]
 
     for (uint32_t it = 0;; ++it) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         const uint32_t *gP32 = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
         const uint32_t *gT32 = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
         const int W = tlen + 1;   // num_cols
-        const int S = rs + 1;     // uniform slab stride
+        const int S = rs + 8;     // uniform slab stride: a multiple of 8 (READ_SIZE is), >= plen + 1
         uint32_t tw = 0;
 
         // nw_compute, nw.c:109-153
@@ -138,13 +143,22 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
                     for (int j = 0; j < 8; ++j) {
                         const uint32_t pch = ((j < 4 ? pa : pb) >> ((j & 3) * 8)) & 0xffu;
                         const cell_t del = (cell_t)(up + GAP_D);
-                        const cell_t ins = (cell_t)(olds[j] + GAP_I);
+                        const cell_t od = olds[j];
+                        const cell_t ins = (cell_t)(od + GAP_I);
                         const cell_t mm = (cell_t)(dgc + ((pch == tch) ? 0 : MISMATCH));
                         const cell_t m = min(mm, min(ins, del));
                         RW(v0 + j) = m;
-                        if (BT) TB(row + v0 + j) = m;
+                        olds[j] = m;          // olds[j] is consumed (dgc below reads the old value first): reuse as the output
                         up = m;
-                        dgc = olds[j];
+                        dgc = od;
+                    }
+                    if (BT) {
+                        uint4 pk;
+                        pk.x = (uint32_t)(uint16_t)olds[0] | ((uint32_t)(uint16_t)olds[1] << 16);
+                        pk.y = (uint32_t)(uint16_t)olds[2] | ((uint32_t)(uint16_t)olds[3] << 16);
+                        pk.z = (uint32_t)(uint16_t)olds[4] | ((uint32_t)(uint16_t)olds[5] << 16);
+                        pk.w = (uint32_t)(uint16_t)olds[6] | ((uint32_t)(uint16_t)olds[7] << 16);
+                        *reinterpret_cast<uint4 *>(tb + TBI(row + v0)) = pk;
                     }
                     score = up;
                     continue;
@@ -180,12 +194,19 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
             char *ops = a.ops + (uint64_t)pair * 2 * rs;
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
+            // The reference's walk reads table[at], then table[at-1], table[at-W], table[at-W-1] as its if/else chain
+            // needs them. The three neighbours are fetched together (one HBM round trip per step instead of up to three
+            // dependent ones) and the cell moved to is carried as the next step's table[at]: same cells, same values,
+            // same comparisons in the same order.
+            int c = (h > 0 && v > 0) ? (int)TB(flat_to_slab(W * h + v, W, S, plen, tlen)) : 0;
             while (h > 0 && v > 0) {
                 const int at = W * h + v;
-                const int c = TB(flat_to_slab(at, W, S, plen, tlen));
-                if (c == TB(flat_to_slab(at - 1, W, S, plen, tlen)) + GAP_D) { ops[sentinel--] = 'D'; --v; }
-                else if (c == TB(flat_to_slab(at - W, W, S, plen, tlen)) + GAP_I) { ops[sentinel--] = 'I'; --h; }
-                else { ops[sentinel--] = (c == TB(flat_to_slab(at - W - 1, W, S, plen, tlen)) + MISMATCH) ? 'X' : 'M'; --h; --v; }
+                const int cl = TB(flat_to_slab(at - 1, W, S, plen, tlen));
+                const int cu = TB(flat_to_slab(at - W, W, S, plen, tlen));
+                const int cd = TB(flat_to_slab(at - W - 1, W, S, plen, tlen));
+                if (c == cl + GAP_D) { ops[sentinel--] = 'D'; --v; c = cl; }
+                else if (c == cu + GAP_I) { ops[sentinel--] = 'I'; --h; c = cu; }
+                else { ops[sentinel--] = (c == cd + MISMATCH) ? 'X' : 'M'; --h; --v; c = cd; }
             }
             while (h > 0) { ops[sentinel--] = 'I'; --h; }
             while (v > 0) { ops[sentinel--] = 'D'; --v; }
@@ -201,6 +222,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         a.res[pair] = r;
     }
 #undef TB
+#undef TBI
 #undef RW
 }
 
@@ -411,7 +433,8 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
                          size_t *lds, uint64_t *scratch_per_wg, size_t *scratch_total, bool *seq_lds)
 {
     const uint64_t rs = (uint64_t)p.read_size;
-    const uint64_t cells = (rs + 1) * (rs + 2);       // uniform-stride slab: (rs+1) columns x (rs+1) rows
+    // uniform-stride slab: NW (rs+8) columns (16-B units of 8 cells, +7 offset), SWG (rs+1); (rs+1) rows + slack
+    const uint64_t cells = (p.algo == AIM_ALGO_NW ? rs + 8 : rs + 1) * (rs + 2);
     const uint64_t cell_b = (p.algo == AIM_ALGO_NW) ? 2 : (swg_cell_bytes(p) == 1 ? 4ull : 8ull);   // SWG: one packed word per cell
     uint64_t per = cells * cell_b * kWave;
     per = (per + 255) & ~255ull;

@@ -377,32 +377,38 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
             const int cap = 2 * rs;
             auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
             if (!SWG) {
+                // the three neighbours are fetched together (one HBM round trip per step instead of up to three dependent
+                // ones) and the cell moved to becomes the next step's table[at]: same cells, values and comparison order
+                int c = (h > 0 && v > 0) ? (int)TM[addr(W * h + v)] : 0;
                 while (h > 0 && v > 0) {
                     const int at = W * h + v;
-                    const int c = TM[addr(at)];
-                    if (c == (int)TM[addr(at - 1)] + GD) { put('D'); --v; }
-                    else if (c == (int)TM[addr(at - W)] + GI) { put('I'); --h; }
-                    else { put((c == (int)TM[addr(at - W - 1)] + MISMATCH) ? 'X' : 'M'); --h; --v; }
+                    const int cl = TM[addr(at - 1)], cu = TM[addr(at - W)], cg = TM[addr(at - W - 1)];
+                    if (c == cl + GD) { put('D'); --v; c = cl; }
+                    else if (c == cu + GI) { put('I'); --h; c = cu; }
+                    else { put((c == cg + MISMATCH) ? 'X' : 'M'); --h; --v; c = cg; }
                 }
             } else {
                 enum { L_M, L_I, L_D };
                 int layer = L_M;
                 while (h > 0 && v > 0) {
                     const int at = W * h + v;
+                    // everything any branch of this step compares, fetched together (one round trip, not a chain)
+                    const size_t a0 = addr(at);
+                    const int m = TM[a0], cdd = TD[a0], cii = TI[a0];
+                    const int mu = TM[addr(at - 1)], ml = TM[addr(at - W)], mg = TM[addr(at - W - 1)];
                     if (layer == L_D) {
                         put('D');
-                        if ((int)TD[addr(at)] == (int)TM[addr(at - 1)] + OE) layer = L_M;
+                        if (cdd == mu + OE) layer = L_M;
                         --v;
                     } else if (layer == L_I) {
                         put('I');
-                        if ((int)TI[addr(at)] == (int)TM[addr(at - W)] + OE) layer = L_M;
+                        if (cii == ml + OE) layer = L_M;
                         --h;
                     } else {
-                        const int m = TM[addr(at)];
-                        if (m == (int)TD[addr(at)]) layer = L_D;
-                        else if (m == (int)TI[addr(at)]) layer = L_I;
-                        else if (m == (int)TM[addr(at - W - 1)] + MATCH) { put('M'); --h; --v; }
-                        else if (m == (int)TM[addr(at - W - 1)] + MISMATCH) { put('X'); --h; --v; }
+                        if (m == cdd) layer = L_D;
+                        else if (m == cii) layer = L_I;
+                        else if (m == mg + MATCH) { put('M'); --h; --v; }
+                        else if (m == mg + MISMATCH) { put('X'); --h; --v; }
                         else { status = AIM_PAIR_SWG_NO_OP; break; }
                     }
                 }

@@ -23,6 +23,7 @@ CONFIGS = {
     "wfa_l1000_e5_cigar": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(backtrace=True, reduce=True)),
     "wfa_l1000_e5_score": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(reduce=True)),
     "nw_l100_e1_cigar": dict(algo="nw", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
+    "nw_l100_e1_score": dict(algo="nw", l=100, e=0.01, n=1 << 20, kw=dict()),
     "swg_l100_e1_cigar": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "swg_l100_e1_score": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict()),
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
