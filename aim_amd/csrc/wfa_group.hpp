@@ -369,21 +369,30 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         }
                     }
                     const int s_o = sc - OE, s_e = sc - E, s_x = sc - X;
-                    int o_lo = 1, o_hi = -1, o_f = 0, e_lo = 1, e_hi = -1, e_f = 0, x_lo = 1, x_hi = -1, x_f = 0;
-                    if (s_o >= 0) { const int16_t *m = hMeta(s_o); o_lo = m[0]; o_hi = m[1]; o_f = m[2]; }
-                    if (s_e >= 0) { const int16_t *m = hMeta(s_e); e_lo = m[0]; e_hi = m[1]; e_f = m[2]; }
-                    if (s_x >= 0 && bt == BT_M) { const int16_t *m = hMeta(s_x); x_lo = m[0]; x_hi = m[1]; x_f = m[2]; }
+                    // Every address of this step depends on (sc, k) only -- the descriptors decide validity, not location,
+                    // and each (score, diagonal) has a fixed home in the slab -- so the three descriptors and the five
+                    // candidate offsets are fetched together (one HBM round trip per step instead of a chain of guarded
+                    // loads); the range tests of the reference then select. A stale home is never selected.
+                    const int so_c = max(s_o, 0), se_c = max(s_e, 0), sx_c = max(s_x, 0);
+                    const int16_t *mo = hMeta(so_c), *me_ = hMeta(se_c), *mx = hMeta(sx_c);
+                    int o_lo = mo[0], o_hi = mo[1], o_f = mo[2], e_lo = me_[0], e_hi = me_[1], e_f = me_[2];
+                    int x_lo = mx[0], x_hi = mx[1], x_f = mx[2];
+                    const int v_de = hD(se_c)[k + 1], v_do = hM(so_c)[k + 1];
+                    const int v_ie = hI(se_c)[k - 1], v_io = hM(so_c)[k - 1], v_mx = hM(sx_c)[k];
+                    if (s_o < 0) { o_lo = 1; o_hi = -1; o_f = 0; }
+                    if (s_e < 0) { e_lo = 1; e_hi = -1; e_f = 0; }
+                    if (s_x < 0 || bt != BT_M) { x_lo = 1; x_hi = -1; x_f = 0; }
                     int del_ext = kGrpNull, del_open = kGrpNull, ins_ext = kGrpNull, ins_open = kGrpNull, misms = kGrpNull;
                     if (bt != BT_I) {
-                        if ((e_f & GF_PRESENT) && !(e_f & GF_DNULL) && e_lo <= k + 1 && k + 1 <= e_hi) del_ext = hD(s_e)[k + 1];
-                        if ((o_f & GF_PRESENT) && o_lo <= k + 1 && k + 1 <= o_hi) del_open = hM(s_o)[k + 1];
+                        if ((e_f & GF_PRESENT) && !(e_f & GF_DNULL) && e_lo <= k + 1 && k + 1 <= e_hi) del_ext = v_de;
+                        if ((o_f & GF_PRESENT) && o_lo <= k + 1 && k + 1 <= o_hi) del_open = v_do;
                     }
                     if (bt != BT_D) {
-                        if ((e_f & GF_PRESENT) && (e_f & GF_HASI) && e_lo <= k - 1 && k - 1 <= e_hi) ins_ext = (int16_t)(hI(s_e)[k - 1] + 1);
-                        if ((o_f & GF_PRESENT) && o_lo <= k - 1 && k - 1 <= o_hi) ins_open = (int16_t)(hM(s_o)[k - 1] + 1);
+                        if ((e_f & GF_PRESENT) && (e_f & GF_HASI) && e_lo <= k - 1 && k - 1 <= e_hi) ins_ext = (int16_t)(v_ie + 1);
+                        if ((o_f & GF_PRESENT) && o_lo <= k - 1 && k - 1 <= o_hi) ins_open = (int16_t)(v_io + 1);
                     }
                     if (bt == BT_M) {
-                        if ((x_f & GF_PRESENT) && x_lo <= k && k <= x_hi) misms = (int16_t)(hM(s_x)[k] + 1);
+                        if ((x_f & GF_PRESENT) && x_lo <= k && k <= x_hi) misms = (int16_t)(v_mx + 1);
                     }
                     const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
                     if (bt == BT_M) {
