@@ -158,7 +158,11 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
                         pk.y = (uint32_t)(uint16_t)olds[2] | ((uint32_t)(uint16_t)olds[3] << 16);
                         pk.z = (uint32_t)(uint16_t)olds[4] | ((uint32_t)(uint16_t)olds[5] << 16);
                         pk.w = (uint32_t)(uint16_t)olds[6] | ((uint32_t)(uint16_t)olds[7] << 16);
-                        *reinterpret_cast<uint4 *>(tb + TBI(row + v0)) = pk;
+                        {   // write-once stream, read sparsely by the traceback: nontemporal (same-box A/B -4.7 %)
+                            typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                            aim_u32x4 nv = {pk.x, pk.y, pk.z, pk.w};
+                            __builtin_nontemporal_store(nv, reinterpret_cast<aim_u32x4 *>(tb + TBI(row + v0)));
+                        }
                     }
                     score = up;
                     continue;
@@ -191,7 +195,13 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         int begin_offset = plen + tlen - 1;
         const int end_offset = plen + tlen;
         if (BT) {   // nw_traceback, nw.c:67-107
-            char *ops = a.ops + (uint64_t)pair * 2 * rs;
+            // Edit operations are produced one byte per step, backwards. Stored straight to HBM that is one byte-store
+            // instruction per step scattering to 64 different rows (measured: 1.06 of the traceback's 1.53 ms at l=100).
+            // They are staged in LDS instead -- the row buffer R is dead by now; 2*READ_SIZE bytes per lane, 16-B pieces
+            // lane-interleaved -- and the 16-B pieces covering [begin_offset, end_offset) are copied out afterwards.
+            char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+            unsigned char *ops_l = reinterpret_cast<unsigned char *>(R);
+#define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
             // The reference's walk reads table[at], then table[at-1], table[at-W], table[at-W-1] as its if/else chain
@@ -204,13 +214,19 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
                 const int cl = TB(flat_to_slab(at - 1, W, S, plen, tlen));
                 const int cu = TB(flat_to_slab(at - W, W, S, plen, tlen));
                 const int cd = TB(flat_to_slab(at - W - 1, W, S, plen, tlen));
-                if (c == cl + GAP_D) { ops[sentinel--] = 'D'; --v; c = cl; }
-                else if (c == cu + GAP_I) { ops[sentinel--] = 'I'; --h; c = cu; }
-                else { ops[sentinel--] = (c == cd + MISMATCH) ? 'X' : 'M'; --h; --v; c = cd; }
+                if (c == cl + GAP_D) { OPS(sentinel) = 'D'; --sentinel; --v; c = cl; }
+                else if (c == cu + GAP_I) { OPS(sentinel) = 'I'; --sentinel; --h; c = cu; }
+                else { OPS(sentinel) = (c == cd + MISMATCH) ? 'X' : 'M'; --sentinel; --h; --v; c = cd; }
             }
-            while (h > 0) { ops[sentinel--] = 'I'; --h; }
-            while (v > 0) { ops[sentinel--] = 'D'; --v; }
+            while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+            while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
             begin_offset = sentinel + 1;
+            {   // rows are 2*READ_SIZE bytes (a multiple of 16) at 16-B aligned addresses: whole pieces stay inside the row
+                const uint4 *src = reinterpret_cast<const uint4 *>(R);
+                uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q * kWave + lane];
+            }
+#undef OPS
         }
         aim_result_t r;
         r.max_operations = plen + tlen;
@@ -241,9 +257,12 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
     cellpack_t *tb = BT ? reinterpret_cast<cellpack_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     auto tb_store = [&](int idx, CELL m, CELL i, CELL d) {
         if constexpr (sizeof(CELL) == 1) {
-            tb[(size_t)idx * kWave + lane] = (uint32_t)(uint8_t)m | ((uint32_t)(uint8_t)i << 8) | ((uint32_t)(uint8_t)d << 16);
+            __builtin_nontemporal_store((uint32_t)(uint8_t)m | ((uint32_t)(uint8_t)i << 8) | ((uint32_t)(uint8_t)d << 16),
+                                        reinterpret_cast<uint32_t *>(tb) + (size_t)idx * kWave + lane);   // write-once stream
         } else {
-            tb[(size_t)idx * kWave + lane] = make_uint2((uint32_t)(uint16_t)m | ((uint32_t)(uint16_t)i << 16), (uint32_t)(uint16_t)d);
+            typedef uint32_t aim_u32x2 __attribute__((ext_vector_type(2)));
+            aim_u32x2 nv = {(uint32_t)(uint16_t)m | ((uint32_t)(uint16_t)i << 16), (uint32_t)(uint16_t)d};
+            __builtin_nontemporal_store(nv, reinterpret_cast<aim_u32x2 *>(tb) + (size_t)idx * kWave + lane);
         }
     };
     auto tb_load = [&](int idx, int &m, int &i, int &d) {
@@ -371,10 +390,16 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         const int end_offset = plen + tlen;
         int status = AIM_PAIR_OK;
         if (BT) {   // swg_traceback, swg.c:45-119 (ops row was memset to 'M', swg.c:261)
-            char *ops = a.ops + (uint64_t)pair * 2 * rs;
+            // The ops row (memset to 'M' by the reference, swg.c:261, then patched one byte per step) is built in LDS --
+            // the row buffers are dead by now; 2*READ_SIZE bytes per lane in lane-interleaved 16-B pieces -- and copied
+            // out whole: 2*READ_SIZE/16 16-B stores per pair instead of READ_SIZE/2 dword stores plus a byte store per step.
+            char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+            unsigned char *ops_l = reinterpret_cast<unsigned char *>(RMa);
+#define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
             {
-                uint32_t *o4 = reinterpret_cast<uint32_t *>(ops);
-                for (int w = 0; w < (rs >> 1); ++w) o4[w] = 0x4D4D4D4Du;
+                uint4 *l4 = reinterpret_cast<uint4 *>(RMa);
+                const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+                for (int q = 0; q < (rs >> 3); ++q) l4[q * kWave + lane] = mm;
             }
             enum { L_M, L_I, L_D };
             int sentinel = end_offset - 1;
@@ -388,26 +413,32 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
                 tb_load(flat_to_slab(at - W, W, S, plen, tlen), lm, li, ld);
                 tb_load(flat_to_slab(at - W - 1, W, S, plen, tlen), gm, gi, gd);
                 if (layer == L_D) {
-                    ops[sentinel--] = 'D';
+                    OPS(sentinel) = 'D', --sentinel;
                     if (cd == um + OE) layer = L_M;
                     --v;
                 } else if (layer == L_I) {
-                    ops[sentinel--] = 'I';
+                    OPS(sentinel) = 'I', --sentinel;
                     if (ci == lm + OE) layer = L_M;
                     --h;
                 } else {
                     if (cm == cd) layer = L_D;
                     else if (cm == ci) layer = L_I;
-                    else if (cm == gm + MATCH) { ops[sentinel--] = 'M'; --h; --v; }
-                    else if (cm == gm + MISMATCH) { ops[sentinel--] = 'X'; --h; --v; }
+                    else if (cm == gm + MATCH) { OPS(sentinel) = 'M', --sentinel; --h; --v; }
+                    else if (cm == gm + MISMATCH) { OPS(sentinel) = 'X', --sentinel; --h; --v; }
                     else { status = AIM_PAIR_SWG_NO_OP; break; }
                 }
             }
             if (status == AIM_PAIR_OK) {
-                while (h > 0) { ops[sentinel--] = 'I'; --h; }
-                while (v > 0) { ops[sentinel--] = 'D'; --v; }
+                while (h > 0) { OPS(sentinel) = 'I', --sentinel; --h; }
+                while (v > 0) { OPS(sentinel) = 'D', --sentinel; --v; }
             }
             begin_offset = sentinel + 1;
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(RMa);
+                uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                for (int q = 0; q < (rs >> 3); ++q) dst[q] = src[q * kWave + lane];
+            }
+#undef OPS
         }
         aim_result_t r;
         r.max_operations = plen + tlen;
