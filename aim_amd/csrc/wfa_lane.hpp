@@ -29,6 +29,12 @@
 #ifndef AIM_LANE_STAMPS
 #define AIM_LANE_STAMPS 0         // diagnostic build only: s_memtime per segment, summed per wave into scratch
 #endif
+#ifndef AIM_LANE_DIAG
+#define AIM_LANE_DIAG 0           // diagnostic builds only (results are wrong): 1 = stop after the row loads + next DMA issue,
+#endif                            // 2 = stop after pack/validate, 3 = everything but the result store, 4 = 1 without the result store
+#ifndef AIM_LANE_RES_STAGE
+#define AIM_LANE_RES_STAGE 1     // CIGAR instantiation only: results of a full group staged in LDS, stored as coalesced 16-B pieces
+#endif
 #ifndef AIM_LANE_DMA_AUX
 #define AIM_LANE_DMA_AUX 2        // cache policy of the sequence DMA: 2 = nt (rows are read exactly once; +5 % measured), 0 = default
 #endif
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + kWave * (RS / 4);
+    uint32_t *resL = rowsT + kWave * (RS / 4);          // 64 x aim_result_t (24 B) staged for a coalesced store
     const int lane = threadIdx.x;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
     uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
@@ -201,6 +208,10 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
     for (uint32_t it = 0; have; ++it) {
         const uint32_t pair = grp * kWave + lane;
         const bool active = pair < a.n_pairs;
+        // Result staging (below) is used with CIGAR only. Same-box A/B, 3 interleaved pairs each: with CIGAR -2.0 % time;
+        // score-only +2.6 % (slower) -- there the ~30 us the 24-B result store costs (removal decomposition)
+        // is the price of a write stream inside a read stream at the HBM ceiling, not of its access pattern.
+        const bool full_group = BT && AIM_LANE_RES_STAGE && (grp + 1u) * kWave <= a.n_pairs;   // wave-uniform
         AIM_STAMP(0);                           // loop overhead / previous store
         __builtin_amdgcn_s_waitcnt(0);          // this group's DMA has landed (and rq_next arrived)
         __syncthreads();
@@ -224,6 +235,20 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the DMA issue ahead of the ALU work
         AIM_STAMP(3);                           // DMA issue
+#if AIM_LANE_DIAG == 1 || AIM_LANE_DIAG == 4
+        {   // removal decomposition: the streaming floor of this structure (DMA + LDS reads [+ result store])
+            uint32_t x = 0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x ^= rawP[j].x ^ rawP[j].y ^ rawP[j].z ^ rawP[j].w ^ rawT[j].x ^ rawT[j].y ^ rawT[j].z ^ rawT[j].w;
+            if (active && (AIM_LANE_DIAG == 1 || x == 0x12345678u)) {
+                aim_result_t r;
+                r.max_operations = plen + tlen; r.begin_offset = 0; r.end_offset = 0; r.score = (int)x; r.status = 0; r.idx = rq.idx;
+                a.res[pair] = r;
+            }
+            have = nhave; grp = ngrp;
+            continue;
+        }
+#endif
         const int minlen = active ? min(plen, tlen) : 0x7fffffff;
         const int min_len_wave = __builtin_amdgcn_readfirstlane(wave_min_i32(minlen));
         uint32_t P[NP], T[NP];
@@ -231,6 +256,20 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         bad |= pack_row<NP>(rawT, tlen, min_len_wave, T);
 
         AIM_STAMP(4);                           // pack + validate
+#if AIM_LANE_DIAG == 2
+        {
+            uint32_t x = bad;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x ^= P[j] ^ T[j];
+            if (active) {
+                aim_result_t r;
+                r.max_operations = plen + tlen; r.begin_offset = 0; r.end_offset = 0; r.score = (int)x; r.status = 0; r.idx = rq.idx;
+                a.res[pair] = r;
+            }
+            have = nhave; grp = ngrp;
+            continue;
+        }
+#endif
         // ---- mismatch bit-vectors per diagonal: bit pair v of dk[k] != 0  <=>  P[v] != T[v + k] ----
         uint32_t dk[KW][NP];
 #pragma unroll
@@ -431,9 +470,33 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
                 r.score = score;
                 r.status = status;
                 r.idx = rq.idx;
+#if AIM_LANE_DIAG == 3
+                if (score == 0x12345678)
+#endif
+#if AIM_LANE_RES_STAGE
+                if (full_group) {
+                    // 24-B structs at a 24-B stride per lane touch every line piecemeal in two instructions; the removal
+                    // decomposition priced this store at ~30 of 203 us. Staged in LDS, the 1 536 B of a group leave as 96
+                    // contiguous 16-B pieces (full lines), nontemporal: nothing on the device reads them again.
+                    uint32_t *rl = resL + lane * 6;
+                    rl[0] = (uint32_t)r.max_operations; rl[1] = (uint32_t)r.begin_offset; rl[2] = (uint32_t)r.end_offset;
+                    rl[3] = (uint32_t)r.score; rl[4] = (uint32_t)r.status; rl[5] = (uint32_t)r.idx;
+                } else
+#endif
                 a.res[pair] = r;
             }
         }
+#if AIM_LANE_RES_STAGE
+        if (full_group) {   // wave-uniform; lanes handed to the to-do list leave a stale struct that the general kernel overwrites later
+            typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const aim_u32x4 *src = reinterpret_cast<const aim_u32x4 *>(resL);
+            aim_u32x4 *dst = reinterpret_cast<aim_u32x4 *>(a.res + (size_t)grp * kWave);
+            const aim_u32x4 c0 = src[lane];
+            __builtin_nontemporal_store(c0, dst + lane);
+            if (lane < 32) { const aim_u32x4 c1 = src[64 + lane]; __builtin_nontemporal_store(c1, dst + 64 + lane); }
+        }
+#endif
         have = nhave;
         grp = ngrp;
         AIM_STAMP(6);                           // result store issue
@@ -469,7 +532,7 @@ inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *gri
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;
     *block = kWave;
-    *lds = (size_t)2 * kWave * p.read_size;
+    *lds = (size_t)2 * kWave * p.read_size + ((p.flags & AIM_FLAG_BACKTRACE) ? kWave * sizeof(aim_result_t) : 0);
 }
 
 inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
