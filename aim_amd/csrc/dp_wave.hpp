@@ -294,12 +294,16 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                         };
                         const uint4 pm = pack8(Mo);
                         *reinterpret_cast<uint4 *>(&Mrow[nxt][v0]) = pm;
+#ifndef AIM_DPW_DIAG_NO_TABLE
                         *reinterpret_cast<uint4 *>(&TM[trow + v0]) = pm;
+#endif
                         if (SWG) {
                             const uint4 pi = pack8(Iv), pd = pack8(Do);
                             *reinterpret_cast<uint4 *>(&Irow[nxt][v0]) = pi;
+#ifndef AIM_DPW_DIAG_NO_TABLE
                             *reinterpret_cast<uint4 *>(&TI[trow + v0]) = pi;
                             *reinterpret_cast<uint4 *>(&TD[trow + v0]) = pd;
+#endif
                         }
                         if (v0 + kDpK - 1 == Rr) { tailM[0] = (int16_t)Mo[kDpK - 1]; tailM[1] = (int16_t)Do[kDpK - 1]; }
                     } else {
@@ -374,15 +378,53 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
             };
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
+#ifdef AIM_DPW_DIAG_NO_TRACEBACK
+            h = 0; v = 0;      // diagnostic builds only (results are wrong)
+#endif
             const int cap = 2 * rs;
             auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
+            // Tiled walk. The walk is wave-uniform and the slab is canonical -- flat index f lives at (R, C) = (f / W,
+            // f % W) -- so whenever C >= 1 the cells a step compares are (R, C), (R, C-1), (R-1, C), (R-1, C-1). The 64
+            // lanes fetch an 8-row x 64-column window ending at (R, C) with ONE 16-B load per lane and plane into LDS
+            // (the row buffers are dead by now) and the walk reads from it until it leaves: a refill every >= 7 steps
+            // instead of an HBM round trip per step (decomposition: the walk was 27 % / 20 % of NW / SWG at l = 1000).
+            // Steps on the boundary column (C == 0) and the literal path keep the per-step reads.
+            const bool use_tile = !literal && (size_t)(SWG ? 4 : 2) * rowcap * 2 >= (size_t)(SWG ? 3 : 1) * 1024;
+            int16_t *tileM = rowbuf, *tileI = rowbuf + 512, *tileD = rowbuf + 1024;   // [8 rows][8 units][8 cells]
+            int tR = -1, tC0 = 0;                                                       // rows tR-7..tR, columns tC0..tC0+63
+            auto refill = [&](int R, int C) {                                           // C >= 1
+                const int u0 = ((C - 1) >> 3) - 7;                                      // units of 8 columns: unit u = 8u+1 .. 8u+8
+                tR = R; tC0 = 8 * u0 + 1;
+                const int r = R - (lane >> 3), u = u0 + (lane & 7);
+                if (r >= 0 && u >= -1) {                                                // unit -1: column 0 (and row padding)
+                    const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);               // == r*S + 7 + (8u+1), 16-B aligned
+                    *reinterpret_cast<uint4 *>(&tileM[lane * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
+                    if (SWG) {
+                        *reinterpret_cast<uint4 *>(&tileI[lane * 8]) = *reinterpret_cast<const uint4 *>(&TI[e]);
+                        *reinterpret_cast<uint4 *>(&tileD[lane * 8]) = *reinterpret_cast<const uint4 *>(&TD[e]);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // one wavefront: in-order LDS, no barrier
+            };
+            auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - 7 && C - 1 >= tC0 && C <= tC0 + 63; };
+            auto tget = [&](const int16_t *t, int r, int c) {
+                const int cc = c - tC0;
+                return (int)t[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)];
+            };
             if (!SWG) {
                 // the three neighbours are fetched together (one HBM round trip per step instead of up to three dependent
                 // ones) and the cell moved to becomes the next step's table[at]: same cells, values and comparison order
                 int c = (h > 0 && v > 0) ? (int)TM[addr(W * h + v)] : 0;
                 while (h > 0 && v > 0) {
                     const int at = W * h + v;
-                    const int cl = TM[addr(at - 1)], cu = TM[addr(at - W)], cg = TM[addr(at - W - 1)];
+                    const int R = at / W, C = at - R * W;
+                    int cl, cu, cg;
+                    if (use_tile && C >= 1) {
+                        if (!in_tile(R, C)) refill(R, C);
+                        cl = tget(tileM, R, C - 1); cu = tget(tileM, R - 1, C); cg = tget(tileM, R - 1, C - 1);
+                    } else {
+                        cl = TM[addr(at - 1)]; cu = TM[addr(at - W)]; cg = TM[addr(at - W - 1)];
+                    }
                     if (c == cl + GD) { put('D'); --v; c = cl; }
                     else if (c == cu + GI) { put('I'); --h; c = cu; }
                     else { put((c == cg + MISMATCH) ? 'X' : 'M'); --h; --v; c = cg; }
@@ -393,9 +435,17 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 while (h > 0 && v > 0) {
                     const int at = W * h + v;
                     // everything any branch of this step compares, fetched together (one round trip, not a chain)
-                    const size_t a0 = addr(at);
-                    const int m = TM[a0], cdd = TD[a0], cii = TI[a0];
-                    const int mu = TM[addr(at - 1)], ml = TM[addr(at - W)], mg = TM[addr(at - W - 1)];
+                    const int R = at / W, C = at - R * W;
+                    int m, cdd, cii, mu, ml, mg;
+                    if (use_tile && C >= 1) {
+                        if (!in_tile(R, C)) refill(R, C);
+                        m = tget(tileM, R, C); cdd = tget(tileD, R, C); cii = tget(tileI, R, C);
+                        mu = tget(tileM, R, C - 1); ml = tget(tileM, R - 1, C); mg = tget(tileM, R - 1, C - 1);
+                    } else {
+                        const size_t a0 = addr(at);
+                        m = TM[a0]; cdd = TD[a0]; cii = TI[a0];
+                        mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
+                    }
                     if (layer == L_D) {
                         put('D');
                         if (cdd == mu + OE) layer = L_M;
