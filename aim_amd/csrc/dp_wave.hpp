@@ -26,6 +26,7 @@
 // single-lane path over a flat table in the same slab: correct for everything, slow, and rare.
 #pragma once
 
+#include <cstdlib>
 #include "aim_device.hpp"
 
 namespace aim {
@@ -330,7 +331,12 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                     DpCell up = {(int)tailM[0], 0, (int)tailM[1]};
                     DpCell lastTail = {0, 0, 0};
                     const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical row of flat[W*h + v], v >= W
-                    for (int v = W; v <= plen; ++v) {
+                    // Only cell (h, W) of a row before the last is ever used (it lands on flat[W*(h+1)] = row h+1's boundary);
+                    // cells (h, v > W) alias flat positions that row h+1 overwrites before anything reads them, and within
+                    // the tail they only feed each other. Walking the whole chain W..plen on every row was dead work that
+                    // set config 4's time: 87.6 ms vs 49.0 ms for the same pairs without tails (tools/cfg4_tail_probe.py).
+                    const int vend = (h == tlen) ? plen : W;
+                    for (int v = W; v <= vend; ++v) {
                         int leftM, leftI, diagM;
                         if (v == W) { leftM = B.M; leftI = B.I; diagM = Mrow[cur][W - 1]; }
                         else {
@@ -486,8 +492,13 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
 
 inline int dp_wave_nw(const aim_params_t &p)
 {
+    // A row takes ceil(nblocks / NW) strictly sequential steps (carry chain + a workgroup barrier each), so the
+    // wavefront count is chosen for the fewest steps, not as a power of two: READ_SIZE 10112 is 20 blocks of 512 cells
+    // = 3 steps with 8 wavefronts (the third 56 % empty) but exactly 2 with 10.
     const int nblocks = (p.read_size + kDpBlock - 1) / kDpBlock;
-    return nblocks <= 2 ? 1 : (nblocks <= 4 ? 2 : (nblocks <= 8 ? 4 : 8));
+    if (nblocks <= 8) return nblocks <= 2 ? 1 : (nblocks <= 4 ? 2 : 4);
+    if (const char *e = getenv("AIM_DPW_NW")) { const int f = atoi(e); if (f == 8 || f == 10) return f; }   // A/B runs
+    return (nblocks + 9) / 10 < (nblocks + 7) / 8 ? 10 : 8;
 }
 
 inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, bool cell8, uint32_t *grid, uint32_t *block,
@@ -530,7 +541,8 @@ inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, siz
         if (nw == 1) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 1>), 1);                               \
         else if (nw == 2) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 2>), 2);                          \
         else if (nw == 4) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 4>), 4);                          \
-        else AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 8>), 8);                                       \
+        else if (nw == 8) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 8>), 8);                          \
+        else AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 10>), 10);                                     \
     } while (0)
     if (p.algo == AIM_ALGO_NW) {
         if (bt) AIM_DPW_NW(AIM_ALGO_NW, true, false); else AIM_DPW_NW(AIM_ALGO_NW, false, false);
