@@ -71,10 +71,11 @@ struct Plan {
 };
 
 // Upper bound on the HBM scratch one plan may ask for (DP tables, WFA history/pools). AIM_SCRATCH_GB overrides. The
-// default is half of the device's free memory, read ONCE per process: every entry point re-plans (aim_scratch_bytes,
+// default is three quarters of the device's free memory, read ONCE per process: every entry point re-plans (aim_scratch_bytes,
 // then aim_align_device with the buffer the caller allocated in between), so the bound must not move between calls.
 // Plans are need-capped, so this only matters where the tables are huge: config 4 (l = 10 000, 613 MB per pair) runs
-// 128 pairs in 5 rounds under a 16 GB bound and in 1 round (4.4x faster) from 80 GB up.
+// 128 pairs in 5 rounds under a 16 GB bound and in 1 round (4.4x faster) from 80 GB up; a full chip of them (256 pairs,
+// one per CU) needs 157 GB, which is why the fraction is 3/4 and not 1/2.
 uint64_t scratch_budget_bytes()
 {
     if (const char *e = getenv("AIM_SCRATCH_GB")) {
@@ -88,7 +89,7 @@ uint64_t scratch_budget_bytes()
             (void)hipGetLastError();
             return (uint64_t)16 << 30;                       // no device (CPU-only host): planning queries still answer
         }
-        return std::max<uint64_t>((uint64_t)free_b / 2, (uint64_t)1 << 28);
+        return std::max<uint64_t>((uint64_t)free_b / 4 * 3, (uint64_t)1 << 28);
     }();
     return cached;
 }

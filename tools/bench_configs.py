@@ -28,6 +28,7 @@ CONFIGS = {
     "swg_l100_e1_score": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict()),
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
+    "swg_l10000_e1_cigar_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict(backtrace=True)),
     "nw_l1000_e5_cigar": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
 }
 
