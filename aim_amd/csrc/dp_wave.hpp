@@ -69,6 +69,12 @@ __host__ __device__ inline bool dp_wave_exact_ok(const aim_params_t &p, bool swg
     return hi < 32000 && lo > -32000 && p.max_score < 32000;
 }
 
+#ifdef AIM_DPW_STAMPS   // diagnostic builds only: s_memtime per phase, summed by thread 0, dumped into the pair's ops row
+#define AIM_DPW_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); dpw_sum[i] += t_ - dpw_last; dpw_last = t_; } while (0)
+#else
+#define AIM_DPW_STAMP(i) do { } while (0)
+#endif
 // ALGO: AIM_ALGO_NW or AIM_ALGO_SWG.  CELL8: SWG with int8 cells (literal path only).
 template <int ALGO, bool BT, bool CELL8, int NW>
 __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
@@ -185,11 +191,17 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 if (SWG) { TM[at] = (int16_t)(O + h * E); TI[at] = (int16_t)(O + h * E); TD[at] = (int16_t)MAXS; }
                 else TM[at] = (int16_t)(h * GI);
             }
+#ifdef AIM_DPW_STAMPS
+            unsigned long long dpw_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dpw_last;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dpw_last) :: "memory");
+#endif
             DpCell B;                                  // boundary cell of the current row (flat[W*h])
             const int nblocks = (Rr + kDpBlock - 1) / kDpBlock;
             const int nsteps = (nblocks + NW - 1) / NW;
             for (int h = 1; h <= tlen; ++h) {
+                AIM_DPW_STAMP(7);                      // tail phase / loop overhead of the previous row
                 __syncthreads();                       // previous row (and its tail / boundary cell) is complete in LDS
+                AIM_DPW_STAMP(0);                      // row-start barrier
                 const int nxt = cur ^ 1;
                 const int tch = gT[h - 1];
                 if (h == 1 || !has_tail) {
@@ -257,13 +269,16 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                         }
                         lane_min = min(lane_min, G[t]);
                     }
+                    AIM_DPW_STAMP(1);                  // LDS row reads + A/I/G of 8 cells
                     int total;
                     const int lane_pre = wave_excl_scan_min(lane_min, lane, &total);
+                    AIM_DPW_STAMP(2);                  // wave scan
                     int *wts = wt + (step & 1) * NW;
                     if (NW > 1) {
                         if (lane == 0) wts[wv] = total;
                         __syncthreads();
                     }
+                    AIM_DPW_STAMP(3);                  // carry barrier
                     int before = carry;                // minimum over everything left of this wave's block
                     if (NW > 1) {
 #pragma unroll
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                         Mo[t] = min(A[t], Do[t]);
                         pre = min(pre, G[t]);
                     }
+                    AIM_DPW_STAMP(4);                  // carry reads + M/D of 8 cells
                     if (full) {
                         auto pack8 = [](const int (&x)[kDpK]) {
                             uint4 r;
@@ -324,8 +340,10 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                         }
                     }
                 }
+                AIM_DPW_STAMP(5);                      // pack + LDS/HBM stores (last step)
                 if (has_tail) {
                     __syncthreads();                   // the whole regular part of row h is in LDS
+                    AIM_DPW_STAMP(6);                  // tail barrier
                   if (wv == 0) {
                     // cells v = W .. plen, sequentially (wave-uniform, first wavefront only), with the aliased inputs
                     DpCell up = {(int)tailM[0], 0, (int)tailM[1]};
@@ -370,6 +388,9 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 cur = nxt;
             }
             __syncthreads();
+#ifdef AIM_DPW_STAMPS
+            if (tid == 0) { unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ops); for (int i = 0; i < 8; ++i) dbg[i] = dpw_sum[i]; }
+#endif
             if (has_tail) score = sc_sh[0];
             else score = (plen >= 1 && tlen >= 1) ? (int)Mrow[cur][plen] : 0;
             if (plen == 0 || tlen == 0) score = 0;
@@ -492,13 +513,24 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
 
 inline int dp_wave_nw(const aim_params_t &p)
 {
-    // A row takes ceil(nblocks / NW) strictly sequential steps (carry chain + a workgroup barrier each), so the
-    // wavefront count is chosen for the fewest steps, not as a power of two: READ_SIZE 10112 is 20 blocks of 512 cells
-    // = 3 steps with 8 wavefronts (the third 56 % empty) but exactly 2 with 10.
+    // A row is ceil(nblocks / NW) sequential steps, each ending in a workgroup barrier, and block b is taken by wavefront
+    // b % NW. ASSUMING wavefronts are placed round-robin on the CU's 4 SIMDs (w % 4; not verified, but the measured
+    // ordering below is what this model predicts), the barrier waits for the busiest SIMD. So above 8 blocks the wavefront
+    // count is chosen for the fewest blocks per row on the busiest SIMD, then the fewest steps -- not as a power of two.
+    // READ_SIZE 10112 = 20 blocks: 8 wavefronts 3 steps, 10 wavefronts 2 steps but 6/4 blocks per SIMD, 12 wavefronts
+    // 2 steps and 5 per SIMD. Measured on config 4 (three interleaved rounds): 54.3 / 52.3 / 49.1 ms.
     const int nblocks = (p.read_size + kDpBlock - 1) / kDpBlock;
     if (nblocks <= 8) return nblocks <= 2 ? 1 : (nblocks <= 4 ? 2 : 4);
-    if (const char *e = getenv("AIM_DPW_NW")) { const int f = atoi(e); if (f == 8 || f == 10) return f; }   // A/B runs
-    return (nblocks + 9) / 10 < (nblocks + 7) / 8 ? 10 : 8;
+    if (const char *e = getenv("AIM_DPW_NW")) { const int f = atoi(e); if (f == 8 || f == 10 || f == 12) return f; }   // A/B runs
+    int best = 8, best_busy = 1 << 30, best_steps = 1 << 30;
+    for (int nw : {8, 10, 12}) {
+        int per_simd[4] = {0, 0, 0, 0};
+        for (int b = 0; b < nblocks; ++b) ++per_simd[(b % nw) % 4];
+        const int busy = std::max(std::max(per_simd[0], per_simd[1]), std::max(per_simd[2], per_simd[3]));
+        const int steps = (nblocks + nw - 1) / nw;
+        if (busy < best_busy || (busy == best_busy && steps < best_steps)) { best = nw; best_busy = busy; best_steps = steps; }
+    }
+    return best;
 }
 
 inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, bool cell8, uint32_t *grid, uint32_t *block,
@@ -542,7 +574,8 @@ inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, siz
         else if (nw == 2) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 2>), 2);                          \
         else if (nw == 4) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 4>), 4);                          \
         else if (nw == 8) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 8>), 8);                          \
-        else AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 10>), 10);                                     \
+        else if (nw == 10) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 10>), 10);                       \
+        else AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 12>), 12);                                     \
     } while (0)
     if (p.algo == AIM_ALGO_NW) {
         if (bt) AIM_DPW_NW(AIM_ALGO_NW, true, false); else AIM_DPW_NW(AIM_ALGO_NW, false, false);
