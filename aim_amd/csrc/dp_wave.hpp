@@ -213,6 +213,28 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 if (tid == 0) { Mrow[nxt][0] = (int16_t)B.M; if (SWG) Irow[nxt][0] = (int16_t)B.I; }
                 int carry = SWG ? min(B.D, B.M + O) : B.M;     // G[0]
                 const size_t trow = (size_t)h * S + 7;
+                // First tail cell (h, W) of a row before the last -- the only tail cell of such a row that is ever used
+                // (it is row h+1's boundary). Its inputs are this row's boundary (uniform), cell (h, W-1) and the previous
+                // row's cell (W-1): all in the registers of the lane that computes cell W-1, so that lane produces it and
+                // publishes the boundary; no extra barrier, no serial phase on the first wavefront (which the stamps put at
+                // 21 % of a tailed pair's row). The next row-start barrier publishes Bl; every thread read this row's Bl
+                // before its first step barrier.
+                auto first_tail_cell = [&](int upM, int upD, int diagM) {
+                    const int pch = ldsP[W - 1];
+                    DpCell c;
+                    if (SWG) {
+                        c.D = min(upM + OE, upD + E);
+                        c.I = min(B.M + OE, B.I + E);
+                        c.M = min(diagM + ((pch == tch) ? MATCH : MISMATCH), min(c.I, c.D));
+                    } else {
+                        c.I = c.D = 0;
+                        c.M = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(B.M + GI, upM + GD));
+                    }
+                    Bl[0] = c.M; Bl[1] = c.I; Bl[2] = c.D;
+                    const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical home of flat[W*h + W]
+                    TM[tdst] = (int16_t)c.M;
+                    if (SWG) { TI[tdst] = (int16_t)c.I; TD[tdst] = (int16_t)c.D; }
+                };
                 for (int step = 0; step < nsteps; ++step) {
                     const int base = 1 + (step * NW + wv) * kDpBlock;   // may lie past Rr: the wave still joins the barrier
                     const int v0 = base + lane * kDpK;
@@ -322,7 +344,10 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                             *reinterpret_cast<uint4 *>(&TD[trow + v0]) = pd;
 #endif
                         }
-                        if (v0 + kDpK - 1 == Rr) { tailM[0] = (int16_t)Mo[kDpK - 1]; tailM[1] = (int16_t)Do[kDpK - 1]; }
+                        if (v0 + kDpK - 1 == Rr) {
+                            tailM[0] = (int16_t)Mo[kDpK - 1]; tailM[1] = (int16_t)Do[kDpK - 1];
+                            if (has_tail && h < tlen) first_tail_cell(Mo[kDpK - 1], Do[kDpK - 1], lm[kDpK]);
+                        }
                     } else {
 #pragma unroll
                         for (int t = 0; t < kDpK; ++t) {
@@ -335,13 +360,16 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                                     TI[trow + v] = (int16_t)Iv[t];
                                     TD[trow + v] = (int16_t)Do[t];
                                 }
-                                if (v == Rr) { tailM[0] = (int16_t)Mo[t]; tailM[1] = (int16_t)Do[t]; }
+                                if (v == Rr) {
+                                    tailM[0] = (int16_t)Mo[t]; tailM[1] = (int16_t)Do[t];
+                                    if (has_tail && h < tlen) first_tail_cell(Mo[t], Do[t], lm[t + 1]);
+                                }
                             }
                         }
                     }
                 }
                 AIM_DPW_STAMP(5);                      // pack + LDS/HBM stores (last step)
-                if (has_tail) {
+                if (has_tail && h == tlen) {           // the last row's tail survives in the table: walk it (rows before: above)
                     __syncthreads();                   // the whole regular part of row h is in LDS
                     AIM_DPW_STAMP(6);                  // tail barrier
                   if (wv == 0) {
