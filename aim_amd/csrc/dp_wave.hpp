@@ -239,6 +239,10 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                     const int base = 1 + (step * NW + wv) * kDpBlock;   // may lie past Rr: the wave still joins the barrier
                     const int v0 = base + lane * kDpK;
                     const bool full = v0 + kDpK - 1 <= Rr;   // whole 8-cell group inside the row: 16-B vector traffic
+                    // v * gap for the 8 cells of this lane: ONE full-rate 24-bit multiply per step (v < 2^24, gap small) and
+                    // additions; the per-cell 32-bit multiplies this replaces are quarter-rate instructions
+                    const int GE = SWG ? E : GD;
+                    const int v0E = __mul24(v0, GE);
                     int A[kDpK], Iv[kDpK], G[kDpK];
                     int lane_min = kDpInf;
                     int16_t lm[kDpK + 1], li[kDpK];
@@ -279,11 +283,11 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                                 const int ins = min(leftM + OE, (int)li[t] + E);
                                 Iv[t] = ins;
                                 A[t] = min(diagM + ((pch == tch) ? MATCH : MISMATCH), ins);
-                                G[t] = A[t] + OE - (v + 1) * E;
+                                G[t] = A[t] + OE - (v0E + (t + 1) * GE);
                             } else {
                                 Iv[t] = 0;
                                 A[t] = min(diagM + ((pch == tch) ? 0 : MISMATCH), leftM + GI);
-                                G[t] = A[t] - v * GD;
+                                G[t] = A[t] - (v0E + t * GE);
                             }
                         } else {
                             A[t] = Iv[t] = 0;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
 #pragma unroll
                     for (int t = 0; t < kDpK; ++t) {
                         const int v = v0 + t;
-                        Do[t] = pre + v * (SWG ? E : GD);
+                        Do[t] = pre + (v0E + t * GE);
                         Mo[t] = min(A[t], Do[t]);
                         pre = min(pre, G[t]);
                     }
