@@ -55,6 +55,12 @@ __device__ __forceinline__ int group_min(int v)
     return v;
 }
 
+#ifdef AIM_GROUP_STAMPS   // diagnostic builds only: s_memtime per phase of a score step, summed per wave, dumped behind the to-do region
+#define AIM_GSTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); gsum[i] += t_ - glast; glast = t_; } while (0)
+#else
+#define AIM_GSTAMP(i) do { } while (0)
+#endif
 template <int G, bool REDUCE, bool BT>
 __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 {
@@ -120,6 +126,10 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     auto dslot = [&](int s) { return Dw + (s & (c.ring_e - 1)) * c.wcap + kb; };
     auto fence = [&]() { asm volatile("" ::: "memory"); };   // same-wave LDS traffic is ordered; compiler fence only
 
+#ifdef AIM_GROUP_STAMPS
+    unsigned long long gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(glast) :: "memory");
+#endif
     uint32_t unit;
     bool have = xcd_unit(n_units, 0, &unit);
     aim_request_t rq_next;
@@ -218,7 +228,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             for (int j = g; j < (2 * rs) / 16; j += G) orow[j] = mm;
         }
         fence();
+        AIM_GSTAMP(0);   // staging, pack, pair setup
         for (;;) {
+            AIM_GSTAMP(5);   // loop back-edge
             if (!done) {
                 const bool live = (flags & GF_PRESENT) && !(flags & GF_MNULL);
                 int16_t *mrow = mrow_at(sm);               // already extended by the lanes that produced it
@@ -261,6 +273,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     final_score = score + 1;
                 }
             }
+            AIM_GSTAMP(1);   // reduce + descriptors + end test
             if (__ballot(!done) == 0ull) break;
             ++score;
             sm = sm + 1 == c.ring_m ? 0 : sm + 1;
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                 const bool i_e_null = (s_e < 0) || !(e_f & GF_PRESENT) || !(e_f & GF_HASI) || (e_f & GF_INULL);
                 const bool d_e_null = (s_e < 0) || !(e_f & GF_PRESENT) || !(e_f & GF_HASD) || (e_f & GF_DNULL);
                 const bool i_out_null = m_o_null && i_e_null, d_out_null = m_o_null && d_e_null;
+                AIM_GSTAMP(2);   // score++, source descriptors
                 if (m_sub_null && i_out_null && d_out_null) {
                     flags = 0; klo = 0; khi = -1;
                 } else {
@@ -332,13 +346,16 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         part = min(part, max(plen - (ext - k), tlen - ext));
                     }
                 }
+                AIM_GSTAMP(3);   // compute + extend loop
                 if (g == 0) {
                     int16_t *me = meta_at(sm);
                     me[0] = (int16_t)klo; me[1] = (int16_t)khi; me[2] = (int16_t)flags;
                 }
             }
             fence();
+            AIM_GSTAMP(4);   // descriptor store
         }
+        AIM_GSTAMP(6);   // exit
         int begin_offset = plen + tlen - 1, status = AIM_PAIR_OK;
         if (BT) {
             __syncthreads();   // the history stores of the whole wave have landed
@@ -442,7 +459,14 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         }
         have = nhave;
         unit = nunit;
+        AIM_GSTAMP(7);   // backtrace + result
     }
+#ifdef AIM_GROUP_STAMPS
+    if (lane == 0) {
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(a.scratch + 256) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 8; ++i) dbg[i] = gsum[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
