@@ -76,3 +76,25 @@ def test_launch_dry_run_command(built, capsys):
     out = capsys.readouterr().out
     assert "-DMAX_SCORE=5 -DREAD_SIZE=112 -DMATCH=0 -DMISMATCH=3 -DGAP_O=4 -DGAP_E=1 -DREDUCE -DBACKTRACE" in out
     assert "--algo wfa --max-score 5 --read-size 112" in out and "--nr-dpus 4" in out and "--backtrace --reduce" in out
+
+
+def test_gen_dataset_cli_round_trips_through_the_parser(tmp_path, built):
+    """python -m aim_amd.gen_dataset writes the reference input format; parsing it back (get_reads semantics) yields the
+    generator's pairs; chunking does not change the data; the oracle CLI aligns it."""
+    import subprocess, sys
+    import numpy as np
+    from aim_amd import engine
+    from conftest import ROOT
+    f1, f2 = tmp_path / "a.seq", tmp_path / "b.seq"
+    for f, chunk in ((f1, "1000"), (f2, "7")):
+        subprocess.run([sys.executable, "-m", "aim_amd.gen_dataset", "-n", "50", "-l", "100", "-e", "0.02", "-s", "7", "-o", str(f),
+                        "--chunk", chunk], check=True, cwd=ROOT)
+    assert f1.read_bytes() == f2.read_bytes()
+    data = f1.read_bytes()
+    assert data.count(b"\n") == 100 and data.startswith(b">")
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.02)
+    req, pat, txt = engine.parse_pairs(data, rs)
+    greq, gpat, gtxt = engine.gen_pairs(7, 0, 50, 100, 0.02, rs)
+    assert np.array_equal(req["pattern_len"], greq["pattern_len"]) and np.array_equal(req["text_len"], greq["text_len"])
+    assert np.array_equal(pat, gpat) and np.array_equal(txt, gtxt)
+    assert (req["pattern_len"] == 100).all() and (np.abs(req["text_len"].astype(int) - 100) <= 2).all()
