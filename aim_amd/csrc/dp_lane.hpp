@@ -19,6 +19,7 @@
 
 #include <type_traits>
 
+#include <cstdlib>
 #include "aim_device.hpp"
 
 namespace aim {
@@ -249,8 +250,11 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);                             // pattern image [dword][lane]
-    int16_t *RMa = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));  // M row, [(rs+1)][64]
-    int16_t *RIa = RMa + (rs + 1) * kWave;                                            // I row
+    // row buffers hold CELL-typed values (int8 cells are stored wrapped, exactly as the reference's dp_cell_t does), so
+    // they are CELL-typed: the int8 configuration (MAX_SCORE < 127, e.g. l=100 e=1 %) needs half the LDS, 7 instead of 4
+    // workgroups per CU -- this kernel scales with residency (NW: 4 / 6 / 7 per CU = 6.93 / 5.00 / 4.60 ms)
+    CELL *RMa = reinterpret_cast<CELL *>(imgP + (SEQ_LDS ? rsw * kWave : 0));        // M row, [(rs+1)][64]
+    CELL *RIa = RMa + (rs + 1) * kWave;                                              // I row
     // dp_cell_t {M, I, D} (SWG/DPU-WRAM/common/common.h:112-118): one packed word per cell and lane, [idx][lane]:
     // int8 cells -> uint32 (M | I<<8 | D<<16), int16 cells -> uint2 ({M | I<<16}, D): a single store per cell
     typedef typename std::conditional<sizeof(CELL) == 1, uint32_t, uint2>::type cellpack_t;
@@ -479,11 +483,19 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     *grid = g;
     *block = kWave;
     const size_t img = (size_t)(p.read_size >> 2) * kWave * 4;   // pattern image only
-    const size_t rows = (size_t)(p.algo == AIM_ALGO_NW ? 1 : 2) * (p.read_size + 1) * kWave * 2;
+    const size_t rows = p.algo == AIM_ALGO_NW ? (size_t)(p.read_size + 1) * kWave * 2
+                                              : (size_t)2 * (p.read_size + 1) * kWave * swg_cell_bytes(p);   // SWG: M and I rows, CELL-typed
     *seq_lds = img + rows <= 150 * 1024;
+    if (const char *e = getenv("AIM_DPL_SEQ_LDS")) *seq_lds = *seq_lds && atoi(e) != 0;   // experiments: 0 = pattern from global memory
     *lds = rows + (*seq_lds ? img : 0);
     if (*lds > 160 * 1024) return false;
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(12, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(12, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    if (const char *e = getenv("AIM_DPL_PER_CU")) {   // experiments: residency sweep (also lifts the 8-per-CU start value)
+        per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+        g = std::min<uint32_t>(256 * per_cu, need < 8u ? 8u : need);
+        while (g > 8 && per * g > budget) g -= 8;
+        *grid = g;
+    }
     if (g > 256 * per_cu) {
         g = 256 * per_cu;
         *grid = g;
