@@ -206,7 +206,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         pl->lds = aim::kMetaRing * sizeof(aim::WfMeta) + ring_bytes + (pl->seq_lds ? seq_bytes : 0);
         // persistent single-wave workgroups: exactly what is resident (4 waves/SIMD by VGPRs, 160 KiB LDS per CU);
         // a larger grid runs in uneven rounds
-        const uint32_t wg_per_cu = (uint32_t)std::min<size_t>(16, std::max<size_t>(1, (160 * 1024) / (pl->lds + 256)));
+        const uint32_t wg_per_cu = (uint32_t)std::min<size_t>(16, aim::lds_workgroups_per_cu(pl->lds));
         uint32_t grid = 256 * wg_per_cu;
         const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
         if (grid > need) grid = std::max(8u, need);

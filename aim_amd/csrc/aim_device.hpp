@@ -1,6 +1,7 @@
 // aim_device.hpp -- shared device-side definitions for the gfx950 alignment kernels.
 // CDNA4 only: 64-lane wavefronts are assumed everywhere.
 #pragma once
+#include <cstddef>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -45,6 +46,17 @@ __device__ __forceinline__ bool xcd_unit(uint32_t n_units, uint32_t it, uint32_t
     if (u >= n_units) return false;
     *unit = u;
     return true;
+}
+
+// Workgroups of `lds_bytes` of LDS that fit one CU. LDS (160 KB per CU on gfx950) is handed out in granules of 1 280 B
+// (160 KB / 128) -- measured, not taken from documentation: 12 808-B and 13 336-B workgroups fit 11 per CU and break into
+// two rounds at 12 (11 x 14 080 <= 163 840 < 12 x 14 080), 10 724-B workgroups fit 14 (14 x 11 520), DESIGN.md 4.2. A
+// byte-granular estimate over-counts by one in exactly the cases where that turns a persistent grid into two rounds.
+inline size_t lds_workgroups_per_cu(size_t lds_bytes)
+{
+    const size_t granule = 1280, total = 160 * 1024;
+    const size_t alloc = ((lds_bytes + granule - 1) / granule) * granule;
+    return alloc == 0 ? 64 : (total / alloc > 0 ? total / alloc : 1);
 }
 
 // Wave-wide minimum, result uniform.  DPP row operations + two row broadcasts (no LDS crossbar): the

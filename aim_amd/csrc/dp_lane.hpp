@@ -475,7 +475,7 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     per = (per + 255) & ~255ull;
     if (!(p.flags & AIM_FLAG_BACKTRACE)) per = 256;   // score-only: no table at all
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
-    uint32_t g = 256 * 8;
+    uint32_t g = 256 * 12;   // capped below by what LDS admits
     const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     while (g > 8 && per * g > budget) g -= 8;
@@ -489,9 +489,9 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     if (const char *e = getenv("AIM_DPL_SEQ_LDS")) *seq_lds = *seq_lds && atoi(e) != 0;   // experiments: 0 = pattern from global memory
     *lds = rows + (*seq_lds ? img : 0);
     if (*lds > 160 * 1024) return false;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(12, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(12, lds_workgroups_per_cu(*lds));
     if (const char *e = getenv("AIM_DPL_PER_CU")) {   // experiments: residency sweep (also lifts the 8-per-CU start value)
-        per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+        per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), lds_workgroups_per_cu(*lds));
         g = std::min<uint32_t>(256 * per_cu, need < 8u ? 8u : need);
         while (g > 8 && per * g > budget) g -= 8;
         *grid = g;

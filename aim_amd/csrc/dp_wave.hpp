@@ -579,7 +579,7 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     const uint64_t rowcap = (rs + 31) & ~7ull;
     *lds = ((rs + 31) & ~15ull) + (size_t)((swg ? 4 : 2) * rowcap + 64) * 2 + 256;
     if (*lds > 160 * 1024) return false;
-    const uint32_t per_cu = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(16, 32 / nw), std::max<uint64_t>(1, (160 * 1024) / (*lds + 256)));
+    const uint32_t per_cu = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(16, 32 / nw), (uint64_t)lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;

@@ -458,7 +458,7 @@ inline bool wfa_diag_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c, 
     c->rows_per_wave = 1;
     const size_t rows_bytes = (size_t)2 * (((size_t)p.read_size + 15) / 16) * 16 + 8;
     *lds = rows_bytes + (size_t)((ring_m * c->wcap * 2 + ring_m * 8 + 3) / 4 + 2 * c->np) * 4 + 64;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(12, std::max<size_t>(1, (160 * 1024) / (*lds + 256)));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(12, lds_workgroups_per_cu(*lds));
     if (const char *e = getenv("AIM_DIAG_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
     uint32_t gr = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;

@@ -22,9 +22,6 @@
 #include "aim_device.hpp"
 #include "wfa_lane.hpp"
 
-#ifndef AIM_GROUP_WGS_PER_CU
-#define AIM_GROUP_WGS_PER_CU 8   // persistent single-wave workgroups per CU (cap; LDS may allow fewer)
-#endif
 
 namespace aim {
 
@@ -506,7 +503,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
         // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s): 3 per CU 1.53x (l=1000 e=5%), 4 per CU
         // 1.51x (l=400 e=10%); 6 per CU 1.02x / 0.89x / 0.77x; 8 per CU 0.71x / 0.66x. 5 per CU is not measured.
         const size_t wg = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8 + (size_t)(kWave / g) * dw * 4 + 64;
-        if ((160 * 1024) / (wg + 256) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
+        if (lds_workgroups_per_cu(wg) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
     }
     if (const char *e = getenv("AIM_GROUP_G")) {   // experiments: force the lanes per pair if the plan is feasible at all
         const int fg = atoi(e);
@@ -516,10 +513,12 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     c->rows_per_wave = kWave / g;
     const size_t rows_bytes = g == 64 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
-    const size_t lds_fit = std::max<size_t>(1, (160 * 1024) / (*lds + 256));
-    // the cap of 8 was measured on the G <= 16 plans; with a wavefront per pair the kernel still gains from residency up
-    // to what LDS admits (cfg3: 8 -> 10 per CU = 1.15x), so G = 64 takes everything that fits
-    uint32_t per_cu = g == 64 ? (uint32_t)std::min<size_t>(16, lds_fit) : (uint32_t)std::min<size_t>(AIM_GROUP_WGS_PER_CU, lds_fit);
+    const size_t lds_fit = lds_workgroups_per_cu(*lds);
+    // Every plan takes what really fits, up to 16 single-wave workgroups per CU. An earlier cap of 8 for G <= 16 predated
+    // the fused score step and the correct LDS granule; sweep on one box (ms at 8 -> best per CU): l=100 e=2% 0.671 -> 0.553
+    // (11), e=5% 3.85 -> 2.82 (16), e=10% 6.17 -> 4.10 (14), l=250 e=5% 4.23 -> 3.53 (11), l=150 e=2% 1.94 -> 1.28 (16),
+    // l=100 e=5% CIGAR 2.29 -> 1.73 (16); G = 64 (cfg3): 11 / 12 / 13 / 14 per CU = 7.81 / 7.10 / 7.42 / 7.06 ms.
+    uint32_t per_cu = (uint32_t)std::min<size_t>(16, lds_fit);
     if (const char *e = getenv("AIM_GROUP_PER_CU")) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), lds_fit);   // residency sweeps
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
     uint32_t gr = 256 * per_cu;
