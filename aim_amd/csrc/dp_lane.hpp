@@ -70,16 +70,29 @@ __device__ __forceinline__ int flat_to_slab(int f, int W, int S, int plen, int t
     return S * hq + vq;
 }
 
-template <bool BT, bool SEQ_LDS>
+// Can any int16 store of the NW recurrence wrap? All costs non-negative and every cell bounded by a gap-only path:
+// (2*READ_SIZE + 4) * max(gap_i, gap_d) + 2 * mismatch < 32000 (the bound dp_wave_exact_ok uses). If not, the reference's
+// (int16) casts on every intermediate are identities and nw_lane_kernel<.., NOWRAP = true> computes in int without them
+// (3-4 sign-extension instructions per cell); storage stays int16 either way.
+__host__ __device__ inline bool nw_lane_nowrap(const aim_params_t &p)
+{
+    if (p.gap_i < 0 || p.gap_d < 0 || p.mismatch < 0) return false;
+    const long g = p.gap_i > p.gap_d ? p.gap_i : p.gap_d;
+    return (2L * p.read_size + 4) * g + 2L * p.mismatch < 32000;
+}
+
+template <bool BT, bool SEQ_LDS, bool NOWRAP>
 __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef int16_t cell_t;   // NW_W16, NW/DPU-WRAM/common/common.h:87-97
+    // NW_W16 (NW/DPU-WRAM/common/common.h:87-97): cells are int16. cell_t is the type the arithmetic runs in -- int16_t
+    // with the reference's casts, or int when nw_lane_nowrap() proved them identities; LDS rows and the table are int16.
+    typedef typename std::conditional<NOWRAP, int, int16_t>::type cell_t;
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);                             // pattern image [dword][lane]
     int16_t *R = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));    // [(rs+1)][64]
-    cell_t *tb = BT ? reinterpret_cast<cell_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
+    int16_t *tb = BT ? reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
     // HBM table slab: 8 consecutive slab indices of a lane form one 16-B unit, units lane-interleaved. With S a multiple
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
                         const cell_t ins = (cell_t)(od + GAP_I);
                         const cell_t mm = (cell_t)(dgc + ((pch == tch) ? 0 : MISMATCH));
                         const cell_t m = min(mm, min(ins, del));
-                        RW(v0 + j) = m;
+                        RW(v0 + j) = (int16_t)m;
                         olds[j] = m;          // olds[j] is consumed (dgc below reads the old value first): reuse as the output
                         up = m;
                         dgc = od;
@@ -514,8 +527,11 @@ inline void dp_lane_launch(const aim_params_t &p, uint32_t grid, size_t lds, boo
         hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWave), lds, s, ka);                                                  \
     } while (0)
     if (p.algo == AIM_ALGO_NW) {
-        if (bt) { if (seq_lds) AIM_DP_LAUNCH((nw_lane_kernel<true, true>)); else AIM_DP_LAUNCH((nw_lane_kernel<true, false>)); }
-        else    { if (seq_lds) AIM_DP_LAUNCH((nw_lane_kernel<false, true>)); else AIM_DP_LAUNCH((nw_lane_kernel<false, false>)); }
+        const bool nowrap = nw_lane_nowrap(p);
+#define AIM_NW_LAUNCH(BTV, SLV) do { if (nowrap) AIM_DP_LAUNCH((nw_lane_kernel<BTV, SLV, true>)); else AIM_DP_LAUNCH((nw_lane_kernel<BTV, SLV, false>)); } while (0)
+        if (bt) { if (seq_lds) AIM_NW_LAUNCH(true, true); else AIM_NW_LAUNCH(true, false); }
+        else    { if (seq_lds) AIM_NW_LAUNCH(false, true); else AIM_NW_LAUNCH(false, false); }
+#undef AIM_NW_LAUNCH
     } else if (swg_cell_bytes(p) == 1) {
         if (bt) { if (seq_lds) AIM_DP_LAUNCH((swg_lane_kernel<int8_t, true, true>)); else AIM_DP_LAUNCH((swg_lane_kernel<int8_t, true, false>)); }
         else    { if (seq_lds) AIM_DP_LAUNCH((swg_lane_kernel<int8_t, false, true>)); else AIM_DP_LAUNCH((swg_lane_kernel<int8_t, false, false>)); }
