@@ -21,7 +21,6 @@
 #include "wfa_wave.hpp"
 #include "wfa_lane.hpp"
 #include "wfa_group.hpp"
-#include "wfa_diag.hpp"
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
 
@@ -49,7 +48,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_WFA_DIAG = 5 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4 };
 
 struct Plan {
     KernelId kid;
@@ -136,22 +135,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         const bool no_group = getenv("AIM_NO_GROUP") && getenv("AIM_NO_GROUP")[0] == '1';
         bool group_ok = !lane_ok && !force_wave_kernel() && !pl->no_lane && !no_group &&
                         aim::wfa_group_plan(p, n_pairs, &gc, &gg, &ggrid, &glds, &ghist) && ghist <= budget / 2;
-        // fixed-diagonal kernel: opt-in only (AIM_FORCE_DIAG=1). On config 3 it measured slower than wfa_group_kernel
-        // at G=64 (4.4e6 vs 5.4e6 pairs/s score-only, ~755 vs ~483 instructions per score step).
-        bool diag_ok = false;
-        {
-            aim::GroupCfg dc;
-            uint32_t dgrid = 0;
-            size_t dlds = 0, dhist = 0;
-            const bool force_diag = getenv("AIM_FORCE_DIAG") && getenv("AIM_FORCE_DIAG")[0] == '1';
-            if (!lane_ok && !force_wave_kernel() && !pl->no_lane && force_diag &&
-                aim::wfa_diag_plan(p, n_pairs, &dc, &dgrid, &dlds, &dhist) && dhist <= budget / 2) {
-                diag_ok = true;
-                group_ok = false;
-                gc = dc; ggrid = dgrid; glds = dlds; ghist = dhist; gg = 64;
-            }
-        }
-        if (lane_ok || group_ok || diag_ok) {
+        if (lane_ok || group_ok) {
             // fast path + the general kernel in to-do mode behind it (its plan goes into *pl first)
             Plan fb;
             memset(&fb, 0, sizeof fb);
@@ -165,7 +149,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
                 pl->kid = K_WFA_LANE;
                 aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
             } else {
-                pl->kid = diag_ok ? K_WFA_DIAG : K_WFA_GROUP;
+                pl->kid = K_WFA_GROUP;
                 pl->gcfg = gc;
                 pl->group_g = gg;
                 pl->grid = ggrid;
@@ -297,13 +281,11 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         else launch_wfa_wave<false, false>(pl, ka, stream);
         break;
     case K_WFA_LANE:
-    case K_WFA_GROUP:
-    case K_WFA_DIAG: {
+    case K_WFA_GROUP: {
         // [to-do region | general kernel scratch]: count zeroed per launch, fast kernel, then the drain
         HIP_TRY(hipMemsetAsync(d_scratch, 0, 64, stream));
         ka.scratch_per_wave = pl.todo_bytes;   // (diagnostic builds park their stamps behind the to-do region)
         if (pl.kid == K_WFA_LANE) aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
-        else if (pl.kid == K_WFA_DIAG) aim::wfa_diag_launch(p, pl.gcfg, pl.grid, pl.lds, ka, stream);
         else aim::wfa_group_launch(p, pl.group_g, pl.gcfg, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         aim::KArgs kb = ka;
@@ -553,7 +535,7 @@ int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback
     Plan pl;
     int rc = make_plan(set->params, set->max_pairs, &pl);
     if (rc) return rc;
-    if ((pl.kid != K_WFA_LANE && pl.kid != K_WFA_GROUP && pl.kid != K_WFA_DIAG) || d.n_pairs == 0) return AIM_OK;
+    if ((pl.kid != K_WFA_LANE && pl.kid != K_WFA_GROUP) || d.n_pairs == 0) return AIM_OK;
     HIP_TRY(hipSetDevice(d.dev));
     HIP_TRY(hipMemcpy(n_fallback, d.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return AIM_OK;
@@ -614,7 +596,6 @@ const char *aim_kernel_name(const aim_params_t *params)
     case K_WFA_WAVE: return "wfa_wave_kernel";
     case K_WFA_LANE: return "wfa_lane_kernel";
     case K_WFA_GROUP: return "wfa_group_kernel";
-    case K_WFA_DIAG: return "wfa_diag_kernel";
     case K_DP_LANE: return p_is_nw(params) ? "nw_lane_kernel" : "swg_lane_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
     }

@@ -28,7 +28,7 @@ namespace aim {
 struct GroupCfg {
     int kbias;        // MAX_SCORE + 1: slot index of diagonal k is k + kbias
     int wcap;         // 2*MAX_SCORE + 3 entries per ring row
-    int ring_m;       // rows of the M / descriptor ring: max(x, o+e) + 1 (wfa_diag_kernel: a power of two above it)
+    int ring_m;       // rows of the M / descriptor ring: max(x, o+e) + 1
     int ring_e;       // power of two > e
     int np;           // packed dwords per sequence (READ_SIZE/16 rounded up) + 1 pad
     int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)

@@ -553,35 +553,6 @@ def test_host_cli_parser_quirks_match_oracle_cli(gpu, sample_bytes, tmp_path):
                                                           ((n // d + 7) // 8) * 8 * d)
 
 
-def test_wfa_diag_kernel_coverage(gpu, monkeypatch):
-    """The fixed-diagonal, register-resident kernel (forced onto short reads too): every slot count, reduce on/off,
-    CIGAR on/off, mismatch/gap-open variations (gap_e must be 1), non-ACGT fallback, MAX_SCORE cap."""
-    from aim_amd import capi, engine
-    import ctypes as C
-    monkeypatch.setenv("AIM_FORCE_DIAG", "1")
-    lib = capi.load()
-    cases = [(100, 0.02, {}, None), (100, 0.10, {}, None), (250, 0.08, {}, None), (400, 0.10, {}, None), (1000, 0.05, {}, None),
-             (100, 0.05, dict(mismatch=2, gap_o=3, gap_e=1), None), (150, 0.05, dict(mismatch=6, gap_o=2, gap_e=1), None),
-             (300, 0.05, {}, 20)]
-    for l, e, cost, ms_override in cases:
-        ms, rs = engine.launcher_sizes("wfa", l, e, **cost)
-        if ms_override is not None:
-            ms = ms_override
-        n = 600 if l < 500 else 200
-        req, pat, txt = engine.gen_pairs(77 + l, 0, n, l, e, rs)
-        pat[3, 1] = ord("N")
-        for red, bt in ((True, True), (False, True), (True, False), (False, False)):
-            params = engine.make_params("wfa", ms, rs, reduce=red, backtrace=bt, **cost)
-            assert lib.aim_kernel_name(C.byref(params)) == b"wfa_diag_kernel", (l, e, ms, rs)
-            with engine.DeviceSet(1) as ds:
-                ds.align(params, req, pat, txt)
-                assert ds.fallback_pairs(0) == 1
-            _compare("wfa", params, req, pat, txt)
-    # gap_e != 1 is not eligible
-    p2 = engine.make_params("wfa", 30, 112, gap_e=2)
-    assert lib.aim_kernel_name(C.byref(p2)) != b"wfa_diag_kernel"
-
-
 @pytest.mark.gpu
 def test_wfa_group_lanes_per_pair_plans_agree_with_oracle(gpu, monkeypatch):
     """wfa_group_plan's measured rule: the default plan and the forced AIM_GROUP_G = 16 / 64 plans of the
