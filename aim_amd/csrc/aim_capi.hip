@@ -210,7 +210,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         pl->scratch_total = (size_t)(per * grid);
         return AIM_OK;
     }
-    // NW / SWG long reads: one pair per wavefront, row-scan, canonical table in per-wave HBM scratch
+    // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
     const bool force_dpw = getenv("AIM_FORCE_DPWAVE") && getenv("AIM_FORCE_DPWAVE")[0] == '1';
     if (p.read_size > 320 || force_dpw) {
         pl->kid = K_DP_WAVE;

@@ -500,8 +500,9 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
         g = 64;
     } else {
         // A G <= 16 plan that LDS holds to fewer than 6 workgroups per CU loses to a wavefront per pair at up to 16
-        // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s): 3 per CU 1.53x (l=1000 e=5%), 4 per CU
-        // 1.51x (l=400 e=10%); 6 per CU 1.02x / 0.89x / 0.77x; 8 per CU 0.71x / 0.66x. 5 per CU is not measured.
+        // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s, each plan at its real LDS fit): 3 per CU
+        // 1.56x (l=1000 e=5%), 4 per CU 1.55x (l=400 e=10%); 6 per CU 1.07x / 0.91x / 0.79x; 11 per CU 0.57x; 16 per CU
+        // 0.48x. 5 per CU is not measured.
         const size_t wg = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8 + (size_t)(kWave / g) * dw * 4 + 64;
         if (lds_workgroups_per_cu(wg) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
     }

@@ -136,7 +136,10 @@ int aim_host_free(void *ptr);
  * One alignment launch over buffers that already live in HBM (same layouts as
  * above).  Used by the benchmark and by callers that manage device memory
  * themselves.  hip_stream is a hipStream_t (NULL = default stream); the call
- * only enqueues work.  d_scratch must hold aim_scratch_bytes() bytes.
+ * only enqueues work.  d_scratch must hold aim_scratch_bytes() bytes.  Scratch is need-capped; for table-heavy
+ * configurations (full-DP CIGAR at long reads) it is bounded by AIM_SCRATCH_GB, default 3/4 of the device's free
+ * memory read once per process, and a smaller bound only means fewer pairs in flight (more rounds), never an error
+ * unless not even one workgroup's table fits (AIM_ENOMEM).
  * d_patterns / d_texts must be 16-byte aligned and carry >= 16 bytes of
  * addressable slack after the last row (the kernels read whole 16-byte chunks). */
 size_t aim_scratch_bytes(const aim_params_t *params, uint32_t n_pairs);
