@@ -305,7 +305,7 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         aim::dp_lane_launch(p, pl.grid, pl.lds, pl.seq_lds, ka, stream);
         break;
     case K_DP_WAVE:
-        aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.lds, ka, stream);
+        aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     }
     HIP_TRY(hipGetLastError());

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
     }
 }
 
-inline int dp_wave_nw(const aim_params_t &p)
+inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs)
 {
     // A row is ceil(nblocks / NW) sequential steps, each ending in a workgroup barrier, and block b is taken by wavefront
     // b % NW. ASSUMING wavefronts are placed round-robin on the CU's 4 SIMDs (w % 4; not verified, but the measured
@@ -552,8 +552,16 @@ inline int dp_wave_nw(const aim_params_t &p)
     // READ_SIZE 10112 = 20 blocks: 8 wavefronts 3 steps, 10 wavefronts 2 steps but 6/4 blocks per SIMD, 12 wavefronts
     // 2 steps and 5 per SIMD. Measured on config 4 (three interleaved rounds): 54.3 / 52.3 / 49.1 ms.
     const int nblocks = (p.read_size + kDpBlock - 1) / kDpBlock;
+    if (const char *e = getenv("AIM_DPW_NW")) {   // A/B runs
+        const int f = atoi(e);
+        if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10 || f == 12) return f;
+    }
+    // Up to 4 blocks per row and enough pairs to give every CU 8 of them: one wavefront per pair -- no cross-wavefront
+    // synchronisation at all and twice the pairs resident beats two cooperating wavefronts (READ_SIZE 1064, 4096 pairs,
+    // 1 / 2 / 4 wavefronts: NW 4.80 / 5.85 / 10.4 ms, SWG 10.1 / 10.5 / 14.8 ms). With few pairs the wavefronts of a pair are the
+    // only parallelism there is (config 4: LDS admits one pair per CU whatever their number).
+    if (nblocks <= 4 && n_pairs >= 256u * 8u) return 1;
     if (nblocks <= 8) return nblocks <= 2 ? 1 : (nblocks <= 4 ? 2 : 4);
-    if (const char *e = getenv("AIM_DPW_NW")) { const int f = atoi(e); if (f == 8 || f == 10 || f == 12) return f; }   // A/B runs
     int best = 8, best_busy = 1 << 30, best_steps = 1 << 30;
     for (int nw : {8, 10, 12}) {
         int per_simd[4] = {0, 0, 0, 0};
@@ -573,13 +581,13 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     uint64_t per = 3 * S * (rs + 3) * 2;   // three int16 planes (NW uses the first)
     per = (per + 255) & ~255ull;
     (void)cell8;
-    const int nw = dp_wave_nw(p);
+    const int nw = dp_wave_nw(p, n_pairs);
     *block = (uint32_t)(kWave * nw);
     const bool swg = p.algo == AIM_ALGO_SWG;
     const uint64_t rowcap = (rs + 31) & ~7ull;
     *lds = ((rs + 31) & ~15ull) + (size_t)((swg ? 4 : 2) * rowcap + 64) * 2 + 256;
     if (*lds > 160 * 1024) return false;
-    const uint32_t per_cu = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(16, 32 / nw), (uint64_t)lds_workgroups_per_cu(*lds));
+    const uint32_t per_cu = (uint32_t)std::min<uint64_t>(32 / nw, (uint64_t)lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
@@ -591,10 +599,10 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     return true;
 }
 
-inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-    const int nw = dp_wave_nw(p);
+    const int nw = (int)(block / kWave);   // the plan's choice (it depends on the number of pairs)
 #define AIM_DPW(KERNEL, NWV)                                                                          \
     do {                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
