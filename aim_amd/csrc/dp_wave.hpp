@@ -556,12 +556,17 @@ inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs)
         const int f = atoi(e);
         if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10 || f == 12) return f;
     }
-    // Up to 4 blocks per row and enough pairs to give every CU 8 of them: one wavefront per pair -- no cross-wavefront
-    // synchronisation at all and twice the pairs resident beats two cooperating wavefronts (READ_SIZE 1064, 4096 pairs,
-    // 1 / 2 / 4 wavefronts: NW 4.80 / 5.85 / 10.4 ms, SWG 10.1 / 10.5 / 14.8 ms). With few pairs the wavefronts of a pair are the
-    // only parallelism there is (config 4: LDS admits one pair per CU whatever their number).
-    if (nblocks <= 4 && n_pairs >= 256u * 8u) return 1;
-    if (nblocks <= 8) return nblocks <= 2 ? 1 : (nblocks <= 4 ? 2 : 4);
+    // Up to 8 blocks per row: just enough wavefronts per pair to put ~4096 wavefronts (4 per SIMD) on the chip, never more
+    // than the row has blocks. Fewer wavefronts per pair mean less (at 1: no) cross-wavefront synchronisation and more pairs
+    // resident; with few pairs the wavefronts of a pair are the only parallelism there is. Measured, kernel ms at 1 / 2 / 4
+    // wavefronts (tools/dpw_nw_probe.py): READ_SIZE 1064 NW 4096 pairs 4.85 / 5.85 / 10.4, 1024 pairs 2.60 / 2.37 / -, 512 pairs
+    // 2.49 / 2.09 / 2.38; READ_SIZE 2048, 2048 pairs NW 9.66 / 9.46 / 11.2, SWG 17.2 / 15.9 / 17.1; READ_SIZE 3072, 2048 pairs
+    // NW 19.1 / 18.8 / 24.0, SWG 38.9 / 34.3 / 37.6 (8 wavefronts 32.8 / 45.6).
+    if (nblocks <= 8) {
+        const uint32_t target = n_pairs ? (4096u + n_pairs - 1) / n_pairs : 4u;
+        const int cap = (int)std::min<uint32_t>(target, (uint32_t)nblocks);
+        return cap >= 4 ? 4 : (cap >= 2 ? 2 : 1);
+    }
     int best = 8, best_busy = 1 << 30, best_steps = 1 << 30;
     for (int nw : {8, 10, 12}) {
         int per_simd[4] = {0, 0, 0, 0};
