@@ -579,3 +579,29 @@ def test_wfa_group_lanes_per_pair_plans_agree_with_oracle(gpu, monkeypatch):
                     assert ds.fallback_pairs(0) == 1
                 _compare("wfa", params, req, pat, txt)
     monkeypatch.delenv("AIM_GROUP_G", raising=False)
+
+
+@pytest.mark.gpu
+def test_dp_wave_every_wavefront_count_agrees_with_oracle(gpu, monkeypatch):
+    """dp_wave_nw picks 1 / 2 / 4 wavefronts per pair from the row length and the number of pairs (8 / 10 / 12 for very
+    long rows): every count is forced here (AIM_DPW_NW) on long-read NW and SWG with CIGAR, pairs with plen > tlen, = and <
+    (tail cell, boundary publishing, tiled traceback), and the default choice for few and for many pairs."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    lib = capi.load()
+    for algo, l, e in (("nw", 1000, 0.05), ("swg", 1000, 0.05), ("nw", 2500, 0.02)):
+        ms, rs = engine.launcher_sizes(algo, l, e)
+        params = engine.make_params(algo, ms, rs, backtrace=True)
+        assert lib.aim_kernel_name(C.byref(params)) == b"dp_wave_kernel"
+        req, pat, txt = engine.gen_pairs(4321 + l, 0, 96, l, e, rs)
+        d = req["pattern_len"].astype(int) - req["text_len"].astype(int)
+        assert (d > 0).any() and (d < 0).any()
+        for nw in ("1", "2", "4"):
+            monkeypatch.setenv("AIM_DPW_NW", nw)
+            _compare(algo, params, req, pat, txt)
+        monkeypatch.delenv("AIM_DPW_NW", raising=False)
+        _compare(algo, params, req, pat, txt)                      # few pairs: the default takes several wavefronts per pair
+    ms, rs = engine.launcher_sizes("nw", 1000, 0.05)
+    params = engine.make_params("nw", ms, rs, backtrace=True)
+    req, pat, txt = engine.gen_pairs(99, 0, 4200, 1000, 0.05, rs)   # > 4096 pairs: the default is one wavefront per pair
+    _compare("nw", params, req, pat, txt)
