@@ -117,6 +117,10 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
     assert G(250, 0.10)[0] == 16                # 6 per CU at G = 16 stays (measured break-even)
     assert G(100, 0.10)[0] == 16 and G(100, 0.02)[0] <= 16
     assert G(1000, 0.05, AIM_GROUP_G="16")[0] == 16 and G(100, 0.10, AIM_GROUP_G="64")[0] == 64
+    # residency comes from the 1280-B LDS granule (aim_device.hpp: lds_workgroups_per_cu), capped at 16: a byte-granular
+    # estimate would say 12 for the 12.8-KB and 13.3-KB workgroups, which measurably breaks into two rounds
+    assert G(100, 0.02)[2] == 11 and G(250, 0.05)[2] == 11
+    assert G(100, 0.05)[2] == 16 and G(100, 0.10)[2] == 16 and G(1000, 0.05)[2] == 14
 
 
 def test_scratch_bound_default_and_override(built):
