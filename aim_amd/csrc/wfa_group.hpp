@@ -517,7 +517,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     const size_t lds_fit = lds_workgroups_per_cu(*lds);
     // Every plan takes what really fits, up to 16 single-wave workgroups per CU. An earlier cap of 8 for G <= 16 predated
     // the fused score step and the correct LDS granule; sweep on one box (ms at 8 -> best per CU): l=100 e=2% 0.671 -> 0.553
-    // (11), e=5% 3.85 -> 2.82 (14), e=10% 6.17 -> 4.10 (14), l=250 e=5% 4.23 -> 3.53 (11), l=150 e=2% 1.94 -> 1.28 (16),
+    // (11), e=5% 3.85 -> 2.82 (14), e=10% 6.17 -> 4.10 (16), l=250 e=5% 4.23 -> 3.53 (11), l=150 e=2% 1.94 -> 1.28 (16),
     // l=100 e=5% CIGAR 2.29 -> 1.73 (14); G = 64 (cfg3): 11 / 12 / 13 / 14 per CU = 7.81 / 7.10 / 7.42 / 7.06 ms.
     uint32_t per_cu = (uint32_t)std::min<size_t>(16, lds_fit);
     if (const char *e = getenv("AIM_GROUP_PER_CU")) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), lds_fit);   // residency sweeps
