@@ -514,6 +514,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     c->rows_per_wave = kWave / g;
     const size_t rows_bytes = g == 64 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
+    if (*lds > 64 * 1024) return false;   // beyond the dynamic-LDS limit of a plain launch (only a forced AIM_GROUP_G gets here)
     const size_t lds_fit = lds_workgroups_per_cu(*lds);
     // Every plan takes what really fits, up to 16 single-wave workgroups per CU. An earlier cap of 8 for G <= 16 predated
     // the fused score step and the correct LDS granule; sweep on one box (ms at 8 -> best per CU): l=100 e=2% 0.671 -> 0.553

@@ -292,6 +292,12 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         bool done = false;
 #pragma unroll
         for (int s = 0; s <= MAXS; ++s) {
+            // runtime MAX_SCORE below the template cap: the reference leaves its loop as "exceeded" when the score passes
+            // MAX_SCORE and never tests the end condition there (wfa.c:368-376). The test must precede the skip of absent
+            // scores: placed only at the end of the body it was never reached when MAX_SCORE itself has no wavefront, and a
+            // pair whose score is exactly MAX_SCORE+1 was then aligned and backtraced instead of reported as exceeded
+            // (same score either way, so only CIGAR output showed it; found by tools/fuzz_parity.py).
+            if (s > ms_run) break;
             if (!SH.present[s]) continue;
             if (s > 0) {
                 const int ss = s - X, so = s - O - E, se = s - E;

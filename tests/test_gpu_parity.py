@@ -605,3 +605,21 @@ def test_dp_wave_every_wavefront_count_agrees_with_oracle(gpu, monkeypatch):
     params = engine.make_params("nw", ms, rs, backtrace=True)
     req, pat, txt = engine.gen_pairs(99, 0, 4200, 1000, 0.05, rs)   # > 4096 pairs: the default is one wavefront per pair
     _compare("nw", params, req, pat, txt)
+
+
+@pytest.mark.gpu
+def test_wfa_lane_runtime_max_score_below_shape_with_cigar(gpu):
+    """wfa_lane_kernel is compiled for MAX_SCORE <= 5; a smaller run-time MAX_SCORE whose own score has no wavefront (2 and
+    4 with penalties 3/4/1) used to let a pair scoring exactly MAX_SCORE+1 be aligned and backtraced instead of reported
+    as exceeded (wfa.c:368-376): same score, different begin_offset/CIGAR. Found by tools/fuzz_parity.py."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    lib = capi.load()
+    req, pat, txt = engine.gen_pairs(12345, 0, 512, 100, 0.01, 112)
+    for ms in (1, 2, 3, 4, 5):
+        for bt in (True, False):
+            params = engine.make_params("wfa", ms, 112, backtrace=bt, reduce=True)
+            assert lib.aim_kernel_name(C.byref(params)) == b"wfa_lane_kernel"
+            res, _, ores = _compare("wfa", params, req, pat, txt)
+            if ms < 5:
+                assert (res["score"] == ms + 1).any()   # the cap is exercised (at 5 nothing in this set exceeds it)
