@@ -424,6 +424,11 @@ int aim_set_configure(aim_set_t *set, const aim_params_t *params, uint32_t max_p
         if (params->flags & AIM_FLAG_BACKTRACE) HIP_TRY(hipMalloc((void **)&d.d_ops, (size_t)max_pairs * 2 * rs + 64));
         d.scratch_bytes = pl.scratch_total;
         if (pl.scratch_total) HIP_TRY(hipMalloc(&d.d_scratch, pl.scratch_total));
+        // Debugging aid: AIM_DEBUG_POISON_SCRATCH=<0..255> fills the scratch with that byte. Results must not depend on it
+        // (every scratch byte a launch reads must have been written by that launch); see tools/poison_probe.py.
+        if (pl.scratch_total) {
+            if (const char *e = getenv("AIM_DEBUG_POISON_SCRATCH")) HIP_TRY(hipMemset(d.d_scratch, atoi(e) & 0xff, pl.scratch_total));
+        }
         d.n_pairs = 0;
         d.pushed = d.launched = false;
     }

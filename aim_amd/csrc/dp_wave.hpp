@@ -448,7 +448,11 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
             // (the row buffers are dead by now) and the walk reads from it until it leaves: a refill every >= 7 steps
             // instead of an HBM round trip per step (decomposition: the walk was 27 % / 20 % of NW / SWG at l = 1000).
             // Steps on the boundary column (C == 0) and the literal path keep the per-step reads.
+#ifdef AIM_DPW_NO_TILE
+            const bool use_tile = false;     // diagnostic builds: per-step reads only
+#else
             const bool use_tile = !literal && (size_t)(SWG ? 4 : 2) * rowcap * 2 >= (size_t)(SWG ? 3 : 1) * 1024;
+#endif
             int16_t *tileM = rowbuf, *tileI = rowbuf + 512, *tileD = rowbuf + 1024;   // [8 rows][8 units][8 cells]
             int tR = -1, tC0 = 0;                                                       // rows tR-7..tR, columns tC0..tC0+63
             auto refill = [&](int R, int C) {                                           // C >= 1
