@@ -427,7 +427,13 @@ int aim_set_configure(aim_set_t *set, const aim_params_t *params, uint32_t max_p
         // Debugging aid: AIM_DEBUG_POISON_SCRATCH=<0..255> fills the scratch with that byte. Results must not depend on it
         // (every scratch byte a launch reads must have been written by that launch); see tools/poison_probe.py.
         if (pl.scratch_total) {
-            if (const char *e = getenv("AIM_DEBUG_POISON_SCRATCH")) HIP_TRY(hipMemset(d.d_scratch, atoi(e) & 0xff, pl.scratch_total));
+            if (const char *e = getenv("AIM_DEBUG_POISON_SCRATCH")) {
+                // on the set's own stream and completed here: the launches run on a non-blocking stream that does not
+                // synchronise with the null stream (a null-stream hipMemset raced with the first launch and produced
+                // two false alarms before this was understood)
+                HIP_TRY(hipMemsetAsync(d.d_scratch, atoi(e) & 0xff, pl.scratch_total, d.stream));
+                HIP_TRY(hipStreamSynchronize(d.stream));
+            }
         }
         d.n_pairs = 0;
         d.pushed = d.launched = false;
