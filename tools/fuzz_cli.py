@@ -14,14 +14,15 @@ from aim_amd import engine
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=120)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--focus", choices=["all", "dplong"], default="all", help="'dplong': long-read NW/SWG with CIGAR (the family of the one unexplained difference)")
 a = ap.parse_args()
 rng = random.Random(a.seed)
 cli = os.path.join(ROOT, "oracle", "oracle_cli")
 t0, cases, skipped = time.time(), 0, 0
 with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None) as td:
     while time.time() - t0 < a.seconds:
-        algo = rng.choice(["wfa", "wfa", "nw", "swg"])
-        l = rng.choice([20, 64, 100, 100, 150, 300, 700])
+        algo = rng.choice(["nw", "nw", "swg"]) if a.focus == "dplong" else rng.choice(["wfa", "wfa", "nw", "swg"])
+        l = rng.choice([300, 700, 700]) if a.focus == "dplong" else rng.choice([20, 64, 100, 100, 150, 300, 700])
         e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.1])
         pairs = rng.choice([9, 40, 200, 1000, 3000]) if l <= 150 else rng.choice([9, 40, 200])
         cost = {}
@@ -45,7 +46,7 @@ with tempfile.TemporaryDirectory(dir=os.path.join(ROOT, "gpurun_out") if os.path
         d = rng.choice([1, 1, 2, 3, 4, 8])
         n = rng.choice([pairs, pairs // 2 + 1, pairs * 2, d, d + 1, 1])
         flags = []
-        if rng.random() < 0.6: flags.append("-b")
+        if a.focus == "dplong" or rng.random() < 0.6: flags.append("-b")
         if algo == "wfa" and rng.random() < 0.6: flags.append("-r")
         cflags = []
         for k, v in cost.items(): cflags += ["-" + k, str(v)]
