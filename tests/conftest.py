@@ -48,3 +48,20 @@ def ref_digests():
 
 def md5(b):
     return hashlib.md5(b).hexdigest()
+
+
+def judge_cases():
+    """The 14 wider reference digests the round-1 judge recorded (tests/golden/judge_r01_cases.json)."""
+    return json.load(open(os.path.join(GOLDEN, "judge_r01_cases.json")))["cases"]
+
+
+def judge_case_input(case):
+    """Regenerate a judge case's input file exactly as `python -m aim_amd.gen_dataset -n N -l L -e E -s SEED` writes it."""
+    from aim_amd import engine
+    g = case["gen"]
+    edits = int(-(-g["l"] * g["e"] // 1))
+    row = (g["l"] + edits + 1 + 7) // 8 * 8
+    req, pat, txt = engine.gen_pairs(g["s"], 0, g["n"], g["l"], g["e"], row)
+    data = engine.pairs_to_text(req, pat, txt)
+    assert hashlib.md5(data).hexdigest() == case["input_md5"], "generator drifted from the judge's input for " + case["name"]
+    return data

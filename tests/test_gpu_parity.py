@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import md5
+from conftest import judge_case_input, judge_cases, md5
 
 pytestmark = pytest.mark.gpu
 
@@ -79,6 +79,19 @@ def test_sample_file_matches_reference_digest(gpu, sample_bytes, ref_digests, ke
     res, ops = engine.align(params, req, pat, txt)
     out = engine.format_output(res, ops, kw.get("backtrace", False))
     assert md5(out) == ref_digests[key]
+
+
+@pytest.mark.parametrize("case", judge_cases(), ids=lambda c: c["name"])
+def test_judge_r01_reference_digests_through_hip(gpu, case):
+    """The 14 wider reference digests of judge_r01_cases.json, through aim_set_* on the GPU."""
+    from aim_amd import engine
+    data = judge_case_input(case)
+    req, pat, txt = engine.parse_pairs(data, case["read_size"])
+    cost = {k: case[k] for k in ("mismatch", "gap_o", "gap_e") if k in case}
+    params = engine.make_params(case["algo"], case["max_score"], case["read_size"], backtrace=case["backtrace"],
+                                reduce=case.get("reduce", False), swg_w16=case.get("swg_cell_bytes", 0) == 2, **cost)
+    res, ops = engine.align(params, req, pat, txt)
+    assert md5(engine.format_output(res, ops, case["backtrace"])) == case["output_md5"]
 
 
 def test_sample_file_wave_kernel_too(gpu, sample_bytes, ref_digests, monkeypatch):

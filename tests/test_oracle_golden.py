@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, md5
+from conftest import ROOT, judge_case_input, judge_cases, md5
 
 
 def _run(oracle_mod, engine, data, algo, max_score, backtrace, reduce=False, swg_cell_bytes=0, threads=4):
@@ -75,3 +75,19 @@ def test_wfa_wram_equals_mram_style_variants(built, sample_bytes):
     a, _ = _run(oracle, engine, sample_bytes, "wfa", 5, True, False)
     b, _ = _run(oracle, engine, sample_bytes, "wfa", 5, False, True)
     assert np.array_equal(a["score"], b["score"])
+
+
+@pytest.mark.parametrize("case", judge_cases(), ids=lambda c: c["name"])
+def test_oracle_reproduces_judge_r01_reference_digests(built, case):
+    """Wider reference output digests (aliasing, int8 wrap, reduce firing, long reads, MAX_SCORE overflow, custom
+    penalties) recorded by the round-1 judge from the reference under a UPMEM shim (judge_r01_cases.json)."""
+    from aim_amd import engine
+    from oracle import oracle
+    data = judge_case_input(case)
+    req, pat, txt = engine.parse_pairs(data, case["read_size"])
+    cost = {k: case[k] for k in ("mismatch", "gap_o", "gap_e") if k in case}
+    p = oracle.params(case["algo"], case["max_score"], case["read_size"], backtrace=case["backtrace"],
+                      reduce=case.get("reduce", False), swg_cell_bytes=case.get("swg_cell_bytes", 0), **cost)
+    res, ops, worst = oracle.align_batch(p, req["pattern_len"], req["text_len"], pat, txt, nthreads=4)
+    assert worst == 0 and len(res) == case["gen"]["n"]
+    assert md5(oracle.format_output(res, ops, case["backtrace"])) == case["output_md5"]
