@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("AIM_LIB") or os.path.join(_HERE, "libaim_hip.so")   #
 AIM_OK, AIM_EINVAL, AIM_ENODEV, AIM_ENOMEM, AIM_ESTATE, AIM_EALIGN = 0, -1, -2, -3, -4, -5
 ALGO_NW, ALGO_SWG, ALGO_WFA = 0, 1, 2
 ALGO_BY_NAME = {"nw": ALGO_NW, "swg": ALGO_SWG, "wfa": ALGO_WFA}
-FLAG_BACKTRACE, FLAG_REDUCE, FLAG_SWG_W16 = 1, 2, 4
+FLAG_BACKTRACE, FLAG_REDUCE, FLAG_SWG_W16, FLAG_REQ8, FLAG_RES8 = 1, 2, 4, 8, 16
 PAIR_OK, PAIR_WFA_NO_LINK, PAIR_SWG_NO_OP, PAIR_NOMEM = 0, 1, 2, 3
 
 
@@ -30,7 +30,10 @@ class Params(C.Structure):
 REQUEST_DTYPE = np.dtype([("pattern_len", "<i4"), ("text_len", "<i4"), ("padding", "<i4"), ("idx", "<u4")])
 RESULT_DTYPE = np.dtype([("max_operations", "<i4"), ("begin_offset", "<i4"), ("end_offset", "<i4"),
                          ("score", "<i4"), ("status", "<i4"), ("idx", "<u4")])
+REQUEST8_DTYPE = np.dtype([("pattern_len", "<i2"), ("text_len", "<i2"), ("idx", "<u4")])     # AIM_FLAG_REQ8
+RESULT8_DTYPE = np.dtype([("idx", "<u4"), ("score", "<i4")])                                 # AIM_FLAG_RES8
 assert REQUEST_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 24
+assert REQUEST8_DTYPE.itemsize == 8 and RESULT8_DTYPE.itemsize == 8
 
 # every symbol include/aim_hip.h declares: name -> (restype, argtypes)
 _VP, _U32, _I32 = C.c_void_p, C.c_uint32, C.c_int32
@@ -46,11 +49,13 @@ SYMBOLS = {
     "aim_set_pull": (C.c_int, [_VP, _U32, _VP, _VP]),
     "aim_set_timers": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "aim_set_fallback_pairs": (C.c_int, [_VP, _U32, C.POINTER(_U32)]),
+    "aim_set_plan_describe": (C.c_int, [_VP, _U32, C.c_char_p, C.c_size_t]),
     "aim_set_free": (C.c_int, [_VP]),
     "aim_host_alloc": (C.c_int, [C.POINTER(_VP), C.c_size_t]),
     "aim_host_free": (C.c_int, [_VP]),
     "aim_scratch_bytes": (C.c_size_t, [C.POINTER(Params), _U32]),
     "aim_align_device": (C.c_int, [C.POINTER(Params), _U32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _VP]),
+    "aim_plan_describe": (C.c_int, [C.POINTER(Params), _U32, C.c_char_p, C.c_size_t]),
     "aim_kernel_name": (C.c_char_p, [C.POINTER(Params)]),
     "aim_launcher_sizes": (C.c_int, [_I32, _I32, C.c_double, _I32, _I32, _I32, _I32, C.POINTER(_I32), C.POINTER(_I32)]),
     "aim_cigar_format": (C.c_int, [_VP, _I32, _I32, _VP, _I32]),

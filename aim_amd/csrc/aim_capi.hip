@@ -23,6 +23,7 @@
 #include "wfa_group.hpp"
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
+#include "batch_io.hpp"
 
 namespace {
 
@@ -69,28 +70,67 @@ struct Plan {
     int group_g;
 };
 
-// Upper bound on the HBM scratch one plan may ask for (DP tables, WFA history/pools). AIM_SCRATCH_GB overrides. The
-// default is three quarters of the device's free memory, read ONCE per process: every entry point re-plans (aim_scratch_bytes,
-// then aim_align_device with the buffer the caller allocated in between), so the bound must not move between calls.
-// Plans are need-capped, so this only matters where the tables are huge: config 4 (l = 10 000, 613 MB per pair) runs
-// 128 pairs in 5 rounds under a 16 GB bound and in 1 round (4.4x faster) from 80 GB up; a full chip of them (256 pairs,
-// one per CU) needs 157 GB, which is why the fraction is 3/4 and not 1/2.
-uint64_t scratch_budget_bytes()
+// The AIM_* environment variables, read HERE and nowhere else (see aim::Knobs, aim_device.hpp).
+int env_int(const char *name, int unset)
 {
-    if (const char *e = getenv("AIM_SCRATCH_GB")) {
-        double gb = atof(e);
-        if (gb < 0.25) gb = 0.25;
-        return (uint64_t)(gb * (double)(1ull << 30));
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : unset;
+}
+bool env_flag(const char *name)
+{
+    const char *e = getenv(name);
+    return e && e[0] == '1';
+}
+aim::Knobs read_knobs()
+{
+    aim::Knobs k;
+    if (const char *e = getenv("AIM_SCRATCH_GB")) k.scratch_gb = std::max(0.25, atof(e));
+    k.force_wave = env_flag("AIM_FORCE_WAVE");
+    k.no_group = env_flag("AIM_NO_GROUP");
+    k.no_lane_ext = env_flag("AIM_NO_LANE_EXT");
+    k.wfa_no_ring = env_flag("AIM_WFA_NO_RING");
+    k.wfa_slotw = env_int("AIM_WFA_SLOTW", -1);
+    k.force_dpwave = env_flag("AIM_FORCE_DPWAVE");
+    k.dpw_nw = env_int("AIM_DPW_NW", -1);
+    k.dpl_seq_lds = env_int("AIM_DPL_SEQ_LDS", -1);
+    k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
+    k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
+    k.group_g = env_int("AIM_GROUP_G", -1);
+    k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
+    k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
+    k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
+    k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;
+    return k;
+}
+
+// Upper bound on the HBM scratch one plan may ask for (DP tables, WFA history/pools). AIM_SCRATCH_GB overrides. Plans
+// are need-capped, so the bound only matters where the tables are huge: config 4 (l = 10 000, 613 MB per pair) runs 128
+// pairs in 5 rounds under a 16 GB bound and in 1 round (4.4x faster) from 80 GB up; a full chip of them (256 pairs, one
+// per CU) needs 157 GB, which is why the default is 3/4 of the free memory and not 1/2.
+//  * device sets: the bound is taken per device inside aim_set_configure, AFTER the set's fixed buffers are allocated,
+//    and frozen in the set together with the plan;
+//  * stateless entry points (aim_scratch_bytes, then aim_align_device with the buffer the caller allocated in between):
+//    the bound must not move between the two calls, so it is read once per process and device.
+uint64_t budget_from_free(size_t free_b) { return std::max<uint64_t>((uint64_t)free_b / 4 * 3, (uint64_t)1 << 28); }
+
+uint64_t stateless_budget_bytes(const aim::Knobs &kn)
+{
+    if (kn.scratch_gb >= 0) return (uint64_t)(kn.scratch_gb * (double)(1ull << 30));
+    static uint64_t cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return (uint64_t)16 << 30;                           // no device (CPU-only host): planning queries still answer
     }
-    static const uint64_t cached = [] {
+    if (!cached[dev]) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b == 0) {
             (void)hipGetLastError();
-            return (uint64_t)16 << 30;                       // no device (CPU-only host): planning queries still answer
+            return (uint64_t)16 << 30;
         }
-        return std::max<uint64_t>((uint64_t)free_b / 4 * 3, (uint64_t)1 << 28);
-    }();
-    return cached;
+        cached[dev] = budget_from_free(free_b);
+    }
+    return cached[dev];
 }
 
 int validate_params(const aim_params_t &p)
@@ -106,6 +146,8 @@ int validate_params(const aim_params_t &p)
         if (p.match > 0 || p.mismatch <= 0 || p.gap_o <= 0 || p.gap_e <= 0)
             return fail(AIM_EINVAL, "Wrong affine gap penalties must be  m <= 0 and g, a, x > 0");
     }
+    if ((p.flags & AIM_FLAG_RES8) && (p.flags & AIM_FLAG_BACKTRACE))
+        return fail(AIM_EINVAL, "AIM_FLAG_RES8 (idx, score results) cannot be combined with AIM_FLAG_BACKTRACE");
     if (p.algo == AIM_ALGO_WFA && p.read_size >= 16376)
         return fail(AIM_EINVAL, "WFA offsets are int16 (common.h:98-100): read_size must be < 16376");
     if (p.algo != AIM_ALGO_WFA && p.read_size >= 32760)
@@ -115,49 +157,44 @@ int validate_params(const aim_params_t &p)
 
 inline bool p_is_nw(const aim_params_t *p) { return p->algo == AIM_ALGO_NW; }
 
-bool force_wave_kernel()
-{
-    const char *e = getenv("AIM_FORCE_WAVE");
-    return e && e[0] == '1';
-}
-
-int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
+int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uint64_t budget, Plan *pl)
 {
     int rc = AIM_OK;
-    const uint64_t budget = scratch_budget_bytes();
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     if (p.algo == AIM_ALGO_WFA) {
-        const bool lane_ok = !force_wave_kernel() && !pl->no_lane && aim::wfa_lane_supported(p);
+        const bool lane_ok = !kn.force_wave && !pl->no_lane && aim::wfa_lane_supported(p);
         aim::GroupCfg gc;
         int gg = 0;
         uint32_t ggrid = 0;
         size_t glds = 0, ghist = 0;
-        const bool no_group = getenv("AIM_NO_GROUP") && getenv("AIM_NO_GROUP")[0] == '1';
-        bool group_ok = !lane_ok && !force_wave_kernel() && !pl->no_lane && !no_group &&
-                        aim::wfa_group_plan(p, n_pairs, &gc, &gg, &ggrid, &glds, &ghist) && ghist <= budget / 2;
-        if (lane_ok || group_ok) {
+        bool group_ok = !lane_ok && !kn.force_wave && !pl->no_lane && !kn.no_group &&
+                        aim::wfa_group_plan(p, n_pairs, kn, &gc, &gg, &ggrid, &glds, &ghist) && ghist <= budget / 2;
+        if (lane_ok) {
+            // one pair per lane, everything in registers; no scratch, no second kernel (pairs with bytes outside A/C/G/T take
+            // the kernel's own raw-byte path)
+            pl->kid = K_WFA_LANE;
+            aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+            pl->scratch_total = 256;   // unused; aim_scratch_bytes() keeps 0 for "invalid configuration"
+            return AIM_OK;
+        }
+        if (group_ok) {
             // fast path + the general kernel in to-do mode behind it (its plan goes into *pl first)
             Plan fb;
             memset(&fb, 0, sizeof fb);
             fb.no_lane = true;
-            rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), &fb);
+            rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), kn, budget, &fb);
             if (rc) return rc;
             *pl = fb;
             pl->fb_grid = fb.grid;
             pl->fb_lds = fb.lds;
-            if (lane_ok) {
-                pl->kid = K_WFA_LANE;
-                aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
-            } else {
-                pl->kid = K_WFA_GROUP;
-                pl->gcfg = gc;
-                pl->group_g = gg;
-                pl->grid = ggrid;
-                pl->block = 64;
-                pl->lds = glds;
-            }
+            pl->kid = K_WFA_GROUP;
+            pl->gcfg = gc;
+            pl->group_g = gg;
+            pl->grid = ggrid;
+            pl->block = 64;
+            pl->lds = glds;
             pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
-            pl->hist_bytes = lane_ok ? 0 : ghist;
+            pl->hist_bytes = ghist;
             pl->scratch_total = pl->todo_bytes + pl->hist_bytes + fb.scratch_total;
             return AIM_OK;
         }
@@ -168,19 +205,20 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         uint64_t cap;
         if (bt) {
             cap = full;
-        } else {
+        } else {   // score-only: the pool is a ring that must hold the live window (scores s-R .. s) plus the one being built
             const uint64_t R = (uint64_t)std::max(p.mismatch, p.gap_o + p.gap_e);
             cap = std::min(full, (R + 2) * 3 * (2 * ms + 3));
         }
+        const uint64_t cap_min = bt ? 0 : cap;   // below this a score-only ring would overwrite wavefronts still in use
         pl->meta_cap = (uint32_t)(ms + 2);
         // LDS ring for the live window of wavefronts: max(x, o+e)+1 slots of slot_w diagonals (M, I, D)
         {
             const uint32_t R = (uint32_t)std::max(p.mismatch, p.gap_o + p.gap_e);
             uint32_t w = 16;
             while (w < 2 * (uint32_t)ms + 3 && w < 128) w *= 2;   // 128: keeps 16 workgroups resident per CU at l = 1000 (measured +9 % over 256)
-            if (const char *e = getenv("AIM_WFA_SLOTW")) w = (uint32_t)std::max(16, atoi(e)) & ~15u;
+            if (kn.wfa_slotw >= 0) w = (uint32_t)std::max(16, kn.wfa_slotw) & ~15u;
             while (w > 16 && (uint64_t)(R + 1) * 3 * w * 2 > 24 * 1024) w /= 2;
-            const bool ring_ok = (uint64_t)(R + 1) * 3 * w * 2 <= 24 * 1024 && !(getenv("AIM_WFA_NO_RING") && getenv("AIM_WFA_NO_RING")[0] == '1');
+            const bool ring_ok = (uint64_t)(R + 1) * 3 * w * 2 <= 24 * 1024 && !kn.wfa_no_ring;
             pl->ring_slots = ring_ok ? R + 1 : 0;
             pl->slot_w = ring_ok ? w : 0;
         }
@@ -197,12 +235,22 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         uint64_t per = (uint64_t)pl->meta_cap * sizeof(aim::WfMeta) + cap * sizeof(int16_t);
         per = (per + 255) & ~255ull;
         while (grid > 512 && per * grid > budget) grid = ((grid / 2) + 7u) & ~7u;
-        if (per * grid > budget) {   // shrink the pool; overflow then reports AIM_PAIR_NOMEM like the DPU arena
+        if (per * grid > budget) {
             const uint64_t meta_b = (uint64_t)pl->meta_cap * sizeof(aim::WfMeta);
-            uint64_t avail = budget / grid;
-            if (avail < meta_b + 4096) return fail(AIM_ENOMEM, "scratch budget too small for max_score %d", p.max_score);
-            cap = (avail - meta_b - 256) / sizeof(int16_t);
-            per = (meta_b + cap * sizeof(int16_t) + 255) & ~255ull;
+            if (bt) {
+                // With BACKTRACE the pool is a bump arena like the DPU's (allocate_new_score, wfa.c:143-183): a smaller one
+                // is legal and a pair that outgrows it reports AIM_PAIR_NOMEM (dpu_allocator_wram.c:19-23 "out of memory").
+                uint64_t avail = budget / grid;
+                if (avail < meta_b + 4096) return fail(AIM_ENOMEM, "scratch budget too small for max_score %d", p.max_score);
+                cap = (avail - meta_b - 256) / sizeof(int16_t);
+                per = (meta_b + cap * sizeof(int16_t) + 255) & ~255ull;
+            } else {
+                // Score-only: the pool is a ring and must keep its full live window (a shrunken ring silently overwrites
+                // wavefronts score-x / score-o-e / score-e still read). Fewer workgroups instead, down to one per XCD.
+                while (grid > 8 && per * grid > budget) grid -= 8;
+                if (per * grid > budget || cap < cap_min)
+                    return fail(AIM_ENOMEM, "scratch budget too small for the live window of max_score %d", p.max_score);
+            }
         }
         pl->grid = grid;
         pl->pool_cap = (uint32_t)std::min<uint64_t>(cap, 0x7fffffffu);
@@ -211,28 +259,57 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
         return AIM_OK;
     }
     // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
-    const bool force_dpw = getenv("AIM_FORCE_DPWAVE") && getenv("AIM_FORCE_DPWAVE")[0] == '1';
-    if (p.read_size > 320 || force_dpw) {
+    if (p.read_size > 320 || kn.force_dpwave) {
         pl->kid = K_DP_WAVE;
         const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
-        return aim::dp_wave_plan(p, n_pairs, budget, cell8, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total)
+        return aim::dp_wave_plan(p, n_pairs, budget, kn, cell8, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total)
                    ? AIM_OK
                    : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
     }
     // NW / SWG short reads: one pair per lane, flat DP table in per-wave HBM scratch
     pl->kid = K_DP_LANE;
-    return aim::dp_lane_plan(p, n_pairs, budget, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total,
+    return aim::dp_lane_plan(p, n_pairs, budget, kn, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total,
                              &pl->seq_lds)
                ? AIM_OK
                : fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
 }
 
-int make_plan(const aim_params_t &p, uint32_t n_pairs, Plan *pl)
+const char *kernel_name(const Plan &pl, const aim_params_t &p)
+{
+    switch (pl.kid) {
+    case K_WFA_WAVE: return "wfa_wave_kernel";
+    case K_WFA_LANE: return "wfa_lane_kernel";
+    case K_WFA_GROUP: return "wfa_group_kernel";
+    case K_DP_LANE: return p_is_nw(&p) ? "nw_lane_kernel" : "swg_lane_kernel";
+    case K_DP_WAVE: return "dp_wave_kernel";
+    }
+    return "";
+}
+
+// One line that identifies a plan completely: kernel, lanes / wavefronts per pair, grid, block, LDS, scratch.
+int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint64_t budget, char *out, size_t cap)
+{
+    char extra[96] = "";
+    if (pl.kid == K_WFA_GROUP) snprintf(extra, sizeof extra, " G=%d hist=%zu fb_grid=%u", pl.group_g, pl.hist_bytes, pl.fb_grid);
+    else if (pl.kid == K_DP_WAVE) snprintf(extra, sizeof extra, " wavefronts_per_pair=%u", pl.block / 64);
+    else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
+    else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
+    return snprintf(out, cap, "%s n=%u grid=%u block=%u lds=%zu scratch=%zu budget=%llu%s", kernel_name(pl, p), n_pairs, pl.grid,
+                    pl.block, pl.lds, pl.scratch_total, (unsigned long long)budget, extra);
+}
+
+int make_plan(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uint64_t budget, Plan *pl)
 {
     int rc = validate_params(p);
     if (rc) return rc;
     memset(pl, 0, sizeof *pl);
-    return make_plan_inner(p, n_pairs, pl);
+    rc = make_plan_inner(p, n_pairs, kn, budget, pl);
+    if (rc == AIM_OK && kn.plan_debug) {
+        char line[384];
+        describe_plan(*pl, p, n_pairs, budget, line, sizeof line);
+        fprintf(stderr, "[aim plan] %s\n", line);
+    }
+    return rc;
 }
 
 template <bool BT, bool RED>
@@ -244,13 +321,11 @@ void launch_wfa_wave(const Plan &pl, const aim::KArgs &ka, hipStream_t s)
         hipLaunchKernelGGL((aim::wfa_wave_kernel<BT, RED, false>), dim3(pl.grid), dim3(64), pl.lds, s, ka);
 }
 
-int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, const char *d_pat,
-           const char *d_txt, aim_result_t *d_res, char *d_ops, void *d_scratch, size_t scratch_bytes,
+// Enqueue one alignment launch that follows plan `pl` (made for >= n_pairs pairs under the caller's knobs and budget).
+int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t n_pairs, const void *d_req,
+           const char *d_pat, const char *d_txt, void *d_res, char *d_ops, void *d_scratch, size_t scratch_bytes,
            hipStream_t stream)
 {
-    Plan pl;
-    int rc = make_plan(p, n_pairs, &pl);
-    if (rc) return rc;
     if (n_pairs == 0) return AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const bool red = p.flags & AIM_FLAG_REDUCE;
@@ -261,10 +336,10 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
     aim::KArgs ka;
     ka.p = p;
     ka.n_pairs = n_pairs;
-    ka.req = d_req;
+    ka.req = static_cast<const aim_request_t *>(d_req);
     ka.patterns = d_pat;
     ka.texts = d_txt;
-    ka.res = d_res;
+    ka.res = static_cast<aim_result_t *>(d_res);
     ka.ops = d_ops;
     ka.scratch = (char *)d_scratch;
     ka.scratch_per_wave = pl.scratch_per_wg;
@@ -273,6 +348,8 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
     ka.ring_slots = pl.ring_slots;
     ka.slot_w = pl.slot_w;
     ka.todo = nullptr;
+    ka.dbg_poison_lds = kn.poison_lds >= 0 ? (0x100u | (uint32_t)(kn.poison_lds & 0xff)) : 0u;
+    ka.dbg_lds_bytes = (uint32_t)pl.lds;
     switch (pl.kid) {
     case K_WFA_WAVE:
         if (bt && red) launch_wfa_wave<true, true>(pl, ka, stream);
@@ -281,12 +358,13 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         else launch_wfa_wave<false, false>(pl, ka, stream);
         break;
     case K_WFA_LANE:
+        aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
+        break;
     case K_WFA_GROUP: {
-        // [to-do region | general kernel scratch]: count zeroed per launch, fast kernel, then the drain
+        // [to-do region | history slabs | general kernel scratch]: count zeroed per launch, fast kernel, then the drain
         HIP_TRY(hipMemsetAsync(d_scratch, 0, 64, stream));
         ka.scratch_per_wave = pl.todo_bytes;   // (diagnostic builds park their stamps behind the to-do region)
-        if (pl.kid == K_WFA_LANE) aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
-        else aim::wfa_group_launch(p, pl.group_g, pl.gcfg, pl.grid, pl.lds, ka, stream);
+        aim::wfa_group_launch(p, pl.group_g, pl.gcfg, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         aim::KArgs kb = ka;
         kb.todo = reinterpret_cast<const uint32_t *>(d_scratch);
@@ -295,6 +373,7 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
         Plan fb = pl;
         fb.grid = pl.fb_grid;
         fb.lds = pl.fb_lds;
+        kb.dbg_lds_bytes = (uint32_t)fb.lds;
         if (bt && red) launch_wfa_wave<true, true>(fb, kb, stream);
         else if (bt) launch_wfa_wave<true, false>(fb, kb, stream);
         else if (red) launch_wfa_wave<false, true>(fb, kb, stream);
@@ -317,39 +396,103 @@ int launch(const aim_params_t &p, uint32_t n_pairs, const aim_request_t *d_req, 
 // ---------------------------------------------------------------------------
 // device set
 // ---------------------------------------------------------------------------
-struct aim_device_ctx {
-    int dev = -1;
+// One buffer set + stream: what a batch needs from H2D to D2H. Slot 0 also serves aim_set_push / launch / pull.
+struct aim_slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // h2d b/e, kernel b/e, d2h b/e
-    aim_request_t *d_req = nullptr;
+    void *d_req = nullptr;   // aim_request_t[] or aim_request8_t[] (AIM_FLAG_REQ8)
     char *d_pat = nullptr, *d_txt = nullptr, *d_ops = nullptr;
-    aim_result_t *d_res = nullptr;
+    void *d_res = nullptr;   // aim_result_t[] or aim_result8_t[] (AIM_FLAG_RES8)
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    uint32_t *d_packP = nullptr, *d_packT = nullptr;                 // packed input rows
+    uint32_t *d_rawidx = nullptr;                                    // side list of raw pairs
+    char *d_rawP = nullptr, *d_rawT = nullptr;
+    aim_cigar_t *d_cig = nullptr;                                    // compact CIGAR
+    uint32_t *d_runs = nullptr, *d_cursor = nullptr, *h_cursor = nullptr;
     uint32_t n_pairs = 0;
-    bool pushed = false, launched = false;
+    bool pushed = false, launched = false, submitted = false;
+    Plan plan_last;          // the plan the last launch followed (the configure-time plan re-made for the pushed pair count)
+    aim_batch_io_t io;       // the batch in flight (aim_set_submit .. aim_set_wait)
+};
+
+struct aim_device_ctx {
+    int dev = -1;
+    std::vector<aim_slot> slots;
+    Plan plan;               // made at configure time for max_pairs under the set's knobs and this device's budget
+    uint64_t budget = 0;     // scratch bound of one slot of this device, frozen at configure time
 };
 
 struct aim_set {
     std::vector<aim_device_ctx> devs;
     aim_params_t params;
-    uint32_t max_pairs = 0;
+    uint32_t max_pairs = 0, max_raw = 0, max_runs = 0;
     bool configured = false;
+    aim::Knobs knobs;        // AIM_* switches as read by the last aim_set_configure; launches never re-read the environment
     float h2d_ms = 0.f, kernel_ms = 0.f, d2h_ms = 0.f;
 };
 
 namespace {
+inline size_t req_size(const aim_params_t &p) { return (p.flags & AIM_FLAG_REQ8) ? sizeof(aim_request8_t) : sizeof(aim_request_t); }
+inline size_t res_size(const aim_params_t &p) { return (p.flags & AIM_FLAG_RES8) ? sizeof(aim_result8_t) : sizeof(aim_result_t); }
+
+void free_slot(aim_slot &s)
+{
+    void *bufs[] = {s.d_req, s.d_pat, s.d_txt, s.d_ops, s.d_res, s.d_scratch, s.d_packP, s.d_packT, s.d_rawidx, s.d_rawP, s.d_rawT,
+                    s.d_cig, s.d_runs, s.d_cursor};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (s.h_cursor) (void)hipHostFree(s.h_cursor);
+    for (auto &e : s.ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = aim_slot();
+}
+
 void free_device_buffers(aim_device_ctx &d)
 {
     if (d.dev < 0) return;
     (void)hipSetDevice(d.dev);
-    if (d.d_req) (void)hipFree(d.d_req);
-    if (d.d_pat) (void)hipFree(d.d_pat);
-    if (d.d_txt) (void)hipFree(d.d_txt);
-    if (d.d_ops) (void)hipFree(d.d_ops);
-    if (d.d_res) (void)hipFree(d.d_res);
-    if (d.d_scratch) (void)hipFree(d.d_scratch);
-    d.d_req = nullptr; d.d_pat = d.d_txt = d.d_ops = nullptr; d.d_res = nullptr; d.d_scratch = nullptr;
+    for (auto &s : d.slots) free_slot(s);
+    d.slots.clear();
+}
+
+int check_lengths(const aim_params_t &p, uint32_t n_pairs, const void *requests)
+{
+    const int rs = p.read_size;
+    const bool req8 = p.flags & AIM_FLAG_REQ8;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        const int pl = req8 ? static_cast<const aim_request8_t *>(requests)[i].pattern_len
+                            : static_cast<const aim_request_t *>(requests)[i].pattern_len;
+        const int tl = req8 ? static_cast<const aim_request8_t *>(requests)[i].text_len
+                            : static_cast<const aim_request_t *>(requests)[i].text_len;
+        if (pl < 0 || tl < 0 || pl > rs || tl > rs)
+            return fail(AIM_EINVAL, "READ LENGTH less than length of the input reads (pair %u)", i);  // host.c:119-123
+    }
+    return AIM_OK;
+}
+
+int status_error(uint32_t idx, int status)
+{
+    return fail(AIM_EALIGN, "pair idx %u stopped with status %d (%s)", idx, status,
+                status == AIM_PAIR_WFA_NO_LINK ? "Backtrace error: No link found during backtrace"
+                : status == AIM_PAIR_SWG_NO_OP ? "SWG backtrace. No backtrace operation found"
+                                               : "out of memory");
+}
+
+// the configure-time plan re-made for this batch's pair count (smaller grids for smaller batches) under the SAME frozen
+// knobs and budget; should that ever need more scratch than configure allocated, the configure-time plan itself is
+// followed (every kernel tolerates a grid larger than its work)
+int launch_on_slot(aim_set *set, aim_device_ctx &d, aim_slot &s)
+{
+    Plan pl;
+    aim::Knobs quiet = set->knobs;
+    quiet.plan_debug = false;   // the configure-time plan was printed; per-launch re-plans are not
+    int rc = s.n_pairs ? make_plan(set->params, s.n_pairs, quiet, d.budget, &pl) : AIM_OK;
+    if (rc || !s.n_pairs || pl.scratch_total > s.scratch_bytes) pl = d.plan;
+    s.plan_last = pl;
+    return launch(pl, set->knobs, set->params, s.n_pairs, s.d_req, s.d_pat, s.d_txt, s.d_res, s.d_ops, s.d_scratch,
+                  s.scratch_bytes, s.stream);
 }
 }  // namespace
 
@@ -385,11 +528,8 @@ int aim_set_alloc(uint32_t nr_devices, const int *device_ids, aim_set_t **out)
             aim_set_free(s);
             return fail(AIM_ENODEV, "device %d not present (%d devices)", id, have);
         }
-        aim_device_ctx &d = s->devs[i];
-        d.dev = id;
+        s->devs[i].dev = id;
         hipError_t e = hipSetDevice(id);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
-        for (int k = 0; k < 6 && e == hipSuccess; ++k) e = hipEventCreate(&d.ev[k]);
         if (e != hipSuccess) {
             aim_set_free(s);
             return fail(AIM_ENODEV, "device %d setup failed: %s", id, hipGetErrorString(e));
@@ -406,69 +546,143 @@ int aim_set_nr_devices(const aim_set_t *set, uint32_t *nr)
     return AIM_OK;
 }
 
-int aim_set_configure(aim_set_t *set, const aim_params_t *params, uint32_t max_pairs)
+int aim_set_configure_slots(aim_set_t *set, const aim_params_t *params, uint32_t max_pairs, uint32_t slots, uint32_t max_raw,
+                            uint32_t max_runs)
 {
-    if (!set || !params || max_pairs == 0) return fail(AIM_EINVAL, "bad arguments");
-    Plan pl;
-    int rc = make_plan(*params, max_pairs, &pl);
+    if (!set || !params || max_pairs == 0 || slots == 0 || slots > 4) return fail(AIM_EINVAL, "bad arguments");
+    int rc = validate_params(*params);
     if (rc) return rc;
+    if (max_runs && !(params->flags & AIM_FLAG_BACKTRACE)) return fail(AIM_EINVAL, "compact CIGAR output needs AIM_FLAG_BACKTRACE");
+    const aim::Knobs kn = read_knobs();
+    // From here on the set is unconfigured until every device succeeded: a failure half-way must not leave the old
+    // max_pairs / params describing buffers that were already freed or re-sized.
+    set->configured = false;
+    set->max_pairs = 0;
+    for (auto &d : set->devs) free_device_buffers(d);
     const size_t rs = (size_t)params->read_size;
-    for (auto &d : set->devs) {
-        free_device_buffers(d);
-        HIP_TRY(hipSetDevice(d.dev));
+    const size_t rowdw = aim::packed_row_dwords(params->read_size);
+    auto configure_slot = [&](aim_device_ctx &d, aim_slot &s) -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (auto &e : s.ev) HIP_TRY(hipEventCreate(&e));
         // the MRAM plan of host.c:215-241, in HBM (+64 B tail slack on the sequence arrays)
-        HIP_TRY(hipMalloc((void **)&d.d_req, (size_t)max_pairs * sizeof(aim_request_t)));
-        HIP_TRY(hipMalloc((void **)&d.d_res, (size_t)max_pairs * sizeof(aim_result_t)));
-        HIP_TRY(hipMalloc((void **)&d.d_pat, (size_t)max_pairs * rs + 64));
-        HIP_TRY(hipMalloc((void **)&d.d_txt, (size_t)max_pairs * rs + 64));
-        if (params->flags & AIM_FLAG_BACKTRACE) HIP_TRY(hipMalloc((void **)&d.d_ops, (size_t)max_pairs * 2 * rs + 64));
-        d.scratch_bytes = pl.scratch_total;
-        if (pl.scratch_total) HIP_TRY(hipMalloc(&d.d_scratch, pl.scratch_total));
-        // Debugging aid: AIM_DEBUG_POISON_SCRATCH=<0..255> fills the scratch with that byte. Results must not depend on it
-        // (every scratch byte a launch reads must have been written by that launch); see tools/poison_probe.py.
-        if (pl.scratch_total) {
-            if (const char *e = getenv("AIM_DEBUG_POISON_SCRATCH")) {
-                // on the set's own stream and completed here: the launches run on a non-blocking stream that does not
-                // synchronise with the null stream (a null-stream hipMemset raced with the first launch and produced
-                // two false alarms before this was understood)
-                HIP_TRY(hipMemsetAsync(d.d_scratch, atoi(e) & 0xff, pl.scratch_total, d.stream));
-                HIP_TRY(hipStreamSynchronize(d.stream));
-            }
+        HIP_TRY(hipMalloc(&s.d_req, (size_t)max_pairs * req_size(*params)));
+        HIP_TRY(hipMalloc(&s.d_res, (size_t)max_pairs * res_size(*params)));
+        HIP_TRY(hipMalloc((void **)&s.d_pat, (size_t)max_pairs * rs + 64));
+        HIP_TRY(hipMalloc((void **)&s.d_txt, (size_t)max_pairs * rs + 64));
+        if (params->flags & AIM_FLAG_BACKTRACE) HIP_TRY(hipMalloc((void **)&s.d_ops, (size_t)max_pairs * 2 * rs + 64));
+        if (max_raw) {
+            HIP_TRY(hipMalloc((void **)&s.d_packP, (size_t)max_pairs * rowdw * 4 + 64));
+            HIP_TRY(hipMalloc((void **)&s.d_packT, (size_t)max_pairs * rowdw * 4 + 64));
+            HIP_TRY(hipMalloc((void **)&s.d_rawidx, (size_t)max_raw * 4));
+            HIP_TRY(hipMalloc((void **)&s.d_rawP, (size_t)max_raw * rs));
+            HIP_TRY(hipMalloc((void **)&s.d_rawT, (size_t)max_raw * rs));
         }
-        d.n_pairs = 0;
-        d.pushed = d.launched = false;
+        if (max_runs) {
+            HIP_TRY(hipMalloc((void **)&s.d_cig, (size_t)max_pairs * sizeof(aim_cigar_t)));
+            HIP_TRY(hipMalloc((void **)&s.d_runs, (size_t)max_runs * 4));
+            HIP_TRY(hipMalloc((void **)&s.d_cursor, 64));
+            HIP_TRY(hipHostMalloc((void **)&s.h_cursor, 64, hipHostMallocDefault));
+        }
+        return AIM_OK;
+    };
+    auto configure_device = [&](aim_device_ctx &d) -> int {
+        HIP_TRY(hipSetDevice(d.dev));
+        d.slots.resize(slots);
+        for (auto &s : d.slots) {
+            int src = configure_slot(d, s);
+            if (src) return src;
+        }
+        // scratch bound of one slot of THIS device, after the fixed buffers exist; halved and re-planned if the allocation
+        // still fails
+        if (kn.scratch_gb >= 0) {
+            d.budget = (uint64_t)(kn.scratch_gb * (double)(1ull << 30)) / slots;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            d.budget = budget_from_free(free_b / slots);
+        }
+        for (int attempt = 0;; ++attempt) {
+            int prc = make_plan(*params, max_pairs, kn, d.budget, &d.plan);
+            if (prc) return prc;
+            hipError_t e = hipSuccess;
+            for (auto &s : d.slots) {
+                s.scratch_bytes = d.plan.scratch_total;
+                if (d.plan.scratch_total && (e = hipMalloc(&s.d_scratch, d.plan.scratch_total)) != hipSuccess) break;
+            }
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+            for (auto &s : d.slots) {
+                if (s.d_scratch) (void)hipFree(s.d_scratch);
+                s.d_scratch = nullptr;
+            }
+            if (e != hipErrorOutOfMemory || attempt >= 6 || d.budget <= ((uint64_t)1 << 28))
+                return fail(e == hipErrorOutOfMemory ? AIM_ENOMEM : AIM_ENODEV, "hipMalloc(scratch, %zu bytes) failed: %s",
+                            d.plan.scratch_total, hipGetErrorString(e));
+            d.budget /= 2;
+        }
+        for (auto &s : d.slots) {
+            // Debugging aid: AIM_DEBUG_POISON_SCRATCH=<0..255> fills the scratch with that byte. Results must not depend on
+            // it (every scratch byte a launch reads must have been written by that launch); see tools/poison_probe.py. On
+            // the slot's own stream and completed here: launches run on non-blocking streams that do not synchronise with
+            // the null stream.
+            if (d.plan.scratch_total && kn.poison_scratch >= 0) {
+                HIP_TRY(hipMemsetAsync(s.d_scratch, kn.poison_scratch & 0xff, d.plan.scratch_total, s.stream));
+                HIP_TRY(hipStreamSynchronize(s.stream));
+            }
+            s.n_pairs = 0;
+            s.pushed = s.launched = s.submitted = false;
+            s.plan_last = d.plan;
+        }
+        return AIM_OK;
+    };
+    for (auto &d : set->devs) {
+        rc = configure_device(d);
+        if (rc) {
+            char keep[sizeof g_err];
+            memcpy(keep, g_err, sizeof keep);
+            for (auto &x : set->devs) free_device_buffers(x);   // nothing half-configured survives
+            memcpy(g_err, keep, sizeof keep);
+            return rc;
+        }
     }
     set->params = *params;
     set->max_pairs = max_pairs;
+    set->max_raw = max_raw;
+    set->max_runs = max_runs;
+    set->knobs = kn;
     set->configured = true;
     return AIM_OK;
 }
 
-int aim_set_push(aim_set_t *set, uint32_t device, uint32_t n_pairs, const aim_request_t *requests,
-                 const char *patterns, const char *texts)
+int aim_set_configure(aim_set_t *set, const aim_params_t *params, uint32_t max_pairs)
+{
+    return aim_set_configure_slots(set, params, max_pairs, 1, 0, 0);
+}
+
+int aim_set_push(aim_set_t *set, uint32_t device, uint32_t n_pairs, const void *requests, const char *patterns,
+                 const char *texts)
 {
     if (!set || device >= set->devs.size()) return fail(AIM_EINVAL, "bad device index");
     if (!set->configured) return fail(AIM_ESTATE, "aim_set_configure has not been called");
     if (n_pairs > set->max_pairs) return fail(AIM_EINVAL, "n_pairs %u exceeds configured capacity %u", n_pairs, set->max_pairs);
     if (n_pairs && (!requests || !patterns || !texts)) return fail(AIM_EINVAL, "null host buffer");
     aim_device_ctx &d = set->devs[device];
+    aim_slot &s = d.slots[0];
+    if (s.submitted) return fail(AIM_ESTATE, "slot 0 of device %d holds a submitted batch: aim_set_wait it first", d.dev);
     const size_t rs = (size_t)set->params.read_size;
-    for (uint32_t i = 0; i < n_pairs; ++i) {
-        if (requests[i].pattern_len < 0 || requests[i].text_len < 0 || requests[i].pattern_len > (int)rs ||
-            requests[i].text_len > (int)rs)
-            return fail(AIM_EINVAL, "READ LENGTH less than length of the input reads (pair %u)", i);  // host.c:119-123
-    }
+    int rc = check_lengths(set->params, n_pairs, requests);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(d.dev));
-    HIP_TRY(hipEventRecord(d.ev[0], d.stream));
+    HIP_TRY(hipEventRecord(s.ev[0], s.stream));
     if (n_pairs) {
-        HIP_TRY(hipMemcpyAsync(d.d_req, requests, (size_t)n_pairs * sizeof(aim_request_t), hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.d_pat, patterns, (size_t)n_pairs * rs, hipMemcpyHostToDevice, d.stream));
-        HIP_TRY(hipMemcpyAsync(d.d_txt, texts, (size_t)n_pairs * rs, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(s.d_req, requests, (size_t)n_pairs * req_size(set->params), hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.d_pat, patterns, (size_t)n_pairs * rs, hipMemcpyHostToDevice, s.stream));
+        HIP_TRY(hipMemcpyAsync(s.d_txt, texts, (size_t)n_pairs * rs, hipMemcpyHostToDevice, s.stream));
     }
-    HIP_TRY(hipEventRecord(d.ev[1], d.stream));
-    d.n_pairs = n_pairs;
-    d.pushed = true;
-    d.launched = false;
+    HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+    s.n_pairs = n_pairs;
+    s.pushed = true;
+    s.launched = false;
     return AIM_OK;
 }
 
@@ -476,55 +690,191 @@ int aim_set_launch(aim_set_t *set)
 {
     if (!set || !set->configured) return fail(AIM_ESTATE, "set is not configured");
     for (auto &d : set->devs) {
-        if (!d.pushed) return fail(AIM_ESTATE, "device %d has no pushed batch", d.dev);
+        aim_slot &s = d.slots[0];
+        if (!s.pushed) return fail(AIM_ESTATE, "device %d has no pushed batch", d.dev);
         HIP_TRY(hipSetDevice(d.dev));
-        HIP_TRY(hipEventRecord(d.ev[2], d.stream));
-        int rc = launch(set->params, d.n_pairs, d.d_req, d.d_pat, d.d_txt, d.d_res, d.d_ops, d.d_scratch,
-                        d.scratch_bytes, d.stream);
+        HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+        int rc = launch_on_slot(set, d, s);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(d.ev[3], d.stream));
+        HIP_TRY(hipEventRecord(s.ev[3], s.stream));
     }
     float worst_h2d = 0.f, worst_k = 0.f;
     for (auto &d : set->devs) {   // DPU_SYNCHRONOUS: wait for every device
+        aim_slot &s = d.slots[0];
         HIP_TRY(hipSetDevice(d.dev));
-        HIP_TRY(hipStreamSynchronize(d.stream));
+        HIP_TRY(hipStreamSynchronize(s.stream));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, d.ev[0], d.ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
         worst_h2d = std::max(worst_h2d, ms);
-        HIP_TRY(hipEventElapsedTime(&ms, d.ev[2], d.ev[3]));
+        HIP_TRY(hipEventElapsedTime(&ms, s.ev[2], s.ev[3]));
         worst_k = std::max(worst_k, ms);
-        d.launched = true;
+        s.launched = true;
     }
     set->h2d_ms += worst_h2d;
     set->kernel_ms += worst_k;
     return AIM_OK;
 }
 
-int aim_set_pull(aim_set_t *set, uint32_t device, aim_result_t *results, char *ops)
+int aim_set_pull(aim_set_t *set, uint32_t device, void *results, char *ops)
 {
     if (!set || device >= set->devs.size()) return fail(AIM_EINVAL, "bad device index");
+    if (!set->configured) return fail(AIM_ESTATE, "aim_set_configure has not been called");
     aim_device_ctx &d = set->devs[device];
-    if (!d.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
+    aim_slot &s = d.slots[0];
+    if (!s.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
     const bool bt = set->params.flags & AIM_FLAG_BACKTRACE;
-    if (d.n_pairs && (!results || (bt && !ops))) return fail(AIM_EINVAL, "null host buffer");
+    if (s.n_pairs && (!results || (bt && !ops))) return fail(AIM_EINVAL, "null host buffer");
     const size_t rs = (size_t)set->params.read_size;
     HIP_TRY(hipSetDevice(d.dev));
-    HIP_TRY(hipEventRecord(d.ev[4], d.stream));
-    if (d.n_pairs) {
-        HIP_TRY(hipMemcpyAsync(results, d.d_res, (size_t)d.n_pairs * sizeof(aim_result_t), hipMemcpyDeviceToHost, d.stream));
-        if (bt) HIP_TRY(hipMemcpyAsync(ops, d.d_ops, (size_t)d.n_pairs * 2 * rs, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+    if (s.n_pairs) {
+        HIP_TRY(hipMemcpyAsync(results, s.d_res, (size_t)s.n_pairs * res_size(set->params), hipMemcpyDeviceToHost, s.stream));
+        if (bt) HIP_TRY(hipMemcpyAsync(ops, s.d_ops, (size_t)s.n_pairs * 2 * rs, hipMemcpyDeviceToHost, s.stream));
     }
-    HIP_TRY(hipEventRecord(d.ev[5], d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream));
+    HIP_TRY(hipEventRecord(s.ev[5], s.stream));
+    HIP_TRY(hipStreamSynchronize(s.stream));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, d.ev[4], d.ev[5]));
+    HIP_TRY(hipEventElapsedTime(&ms, s.ev[4], s.ev[5]));
     set->d2h_ms += ms;
-    for (uint32_t i = 0; i < d.n_pairs; ++i)
-        if (results[i].status != AIM_PAIR_OK)
-            return fail(AIM_EALIGN, "pair idx %u stopped with status %d (%s)", results[i].idx, results[i].status,
-                        results[i].status == AIM_PAIR_WFA_NO_LINK ? "Backtrace error: No link found during backtrace"
-                        : results[i].status == AIM_PAIR_SWG_NO_OP ? "SWG backtrace. No backtrace operation found"
-                                                                   : "out of memory");
+    if (set->params.flags & AIM_FLAG_RES8) return AIM_OK;   // score-only: no status other than AIM_PAIR_OK exists
+    const aim_result_t *r = static_cast<const aim_result_t *>(results);
+    for (uint32_t i = 0; i < s.n_pairs; ++i)
+        if (r[i].status != AIM_PAIR_OK) return status_error(r[i].idx, r[i].status);
+    return AIM_OK;
+}
+
+int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_batch_io_t *io)
+{
+    if (!set || device >= set->devs.size() || !io) return fail(AIM_EINVAL, "bad arguments");
+    if (!set->configured) return fail(AIM_ESTATE, "aim_set_configure has not been called");
+    aim_device_ctx &d = set->devs[device];
+    if (slot >= d.slots.size()) return fail(AIM_EINVAL, "slot %u not configured (%zu slots)", slot, d.slots.size());
+    aim_slot &s = d.slots[slot];
+    if (s.submitted) return fail(AIM_ESTATE, "slot %u of device %d holds a batch: aim_set_wait it first", slot, d.dev);
+    const aim_params_t &p = set->params;
+    const uint32_t n = io->n_pairs;
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    const bool packed = io->packed_patterns || io->packed_texts;
+    if (n > set->max_pairs) return fail(AIM_EINVAL, "n_pairs %u exceeds configured capacity %u", n, set->max_pairs);
+    if (n && !io->requests) return fail(AIM_EINVAL, "null requests");
+    if (n && packed && (!io->packed_patterns || !io->packed_texts || !s.d_packP))
+        return fail(AIM_EINVAL, "packed batch needs both packed arrays and a set configured with max_raw_pairs > 0");
+    if (n && !packed && (!io->patterns || !io->texts)) return fail(AIM_EINVAL, "null sequence rows");
+    if (packed && io->n_raw > set->max_raw) return fail(AIM_EINVAL, "n_raw %u exceeds configured capacity %u", io->n_raw, set->max_raw);
+    if (packed && io->n_raw && (!io->raw_pairs || !io->raw_patterns || !io->raw_texts)) return fail(AIM_EINVAL, "null raw side list");
+    if (io->cigars && (!bt || !s.d_cig || !io->runs)) return fail(AIM_EINVAL, "compact CIGAR needs AIM_FLAG_BACKTRACE, max_runs > 0 and a run buffer");
+    if (n && !io->results && !io->cigars) return fail(AIM_EINVAL, "no output buffer");
+    if (io->ops && !bt) return fail(AIM_EINVAL, "ops requested without AIM_FLAG_BACKTRACE");
+    int rc = check_lengths(p, n, io->requests);
+    if (rc) return rc;
+    if (packed)
+        for (uint32_t j = 0; j < io->n_raw; ++j)
+            if (io->raw_pairs[j] >= n) return fail(AIM_EINVAL, "raw_pairs[%u] = %u is outside the batch", j, io->raw_pairs[j]);
+    const size_t rs = (size_t)p.read_size;
+    const size_t rowb = (size_t)aim::packed_row_dwords(p.read_size) * 4;
+    HIP_TRY(hipSetDevice(d.dev));
+    s.io = *io;
+    s.n_pairs = n;
+    HIP_TRY(hipEventRecord(s.ev[0], s.stream));
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(s.d_req, io->requests, (size_t)n * req_size(p), hipMemcpyHostToDevice, s.stream));
+        if (packed) {
+            HIP_TRY(hipMemcpyAsync(s.d_packP, io->packed_patterns, (size_t)n * rowb, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(hipMemcpyAsync(s.d_packT, io->packed_texts, (size_t)n * rowb, hipMemcpyHostToDevice, s.stream));
+            if (io->n_raw) {
+                HIP_TRY(hipMemcpyAsync(s.d_rawidx, io->raw_pairs, (size_t)io->n_raw * 4, hipMemcpyHostToDevice, s.stream));
+                HIP_TRY(hipMemcpyAsync(s.d_rawP, io->raw_patterns, (size_t)io->n_raw * rs, hipMemcpyHostToDevice, s.stream));
+                HIP_TRY(hipMemcpyAsync(s.d_rawT, io->raw_texts, (size_t)io->n_raw * rs, hipMemcpyHostToDevice, s.stream));
+            }
+        } else {
+            HIP_TRY(hipMemcpyAsync(s.d_pat, io->patterns, (size_t)n * rs, hipMemcpyHostToDevice, s.stream));
+            HIP_TRY(hipMemcpyAsync(s.d_txt, io->texts, (size_t)n * rs, hipMemcpyHostToDevice, s.stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+    HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+    if (n) {
+        aim::KArgs ka;
+        memset(&ka, 0, sizeof ka);
+        ka.p = p;
+        ka.n_pairs = n;
+        ka.req = static_cast<const aim_request_t *>(s.d_req);
+        ka.res = static_cast<aim_result_t *>(s.d_res);
+        ka.ops = s.d_ops;
+        if (packed) {   // expand into the reference's char[n][READ_SIZE] layout (batch_io.hpp), then run as usual
+            const uint64_t threads = (uint64_t)n * (rs / 8);
+            hipLaunchKernelGGL(aim::unpack_rows_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s.stream, ka, s.d_packP,
+                               s.d_packT, s.d_pat, s.d_txt);
+            if (io->n_raw) {
+                const uint64_t rt = (uint64_t)io->n_raw * (rs / 8);
+                hipLaunchKernelGGL(aim::scatter_raw_rows_kernel, dim3((unsigned)((rt + 255) / 256), 2), dim3(256), 0, s.stream, p.read_size,
+                                   io->n_raw, s.d_rawidx, s.d_rawP, s.d_rawT, s.d_pat, s.d_txt);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        rc = launch_on_slot(set, d, s);
+        if (rc) return rc;
+        if (io->cigars) {
+            HIP_TRY(hipMemsetAsync(s.d_cursor, 0, 4, s.stream));
+            hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((n + 63) / 64), dim3(64), 0, s.stream, ka, s.d_cig, s.d_runs,
+                               std::min(io->runs_cap, set->max_runs), s.d_cursor);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+    HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+    if (n) {
+        if (io->cigars) {
+            HIP_TRY(hipMemcpyAsync(s.h_cursor, s.d_cursor, 4, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipMemcpyAsync(io->cigars, s.d_cig, (size_t)n * sizeof(aim_cigar_t), hipMemcpyDeviceToHost, s.stream));
+        }
+        if (io->results) HIP_TRY(hipMemcpyAsync(io->results, s.d_res, (size_t)n * res_size(p), hipMemcpyDeviceToHost, s.stream));
+        if (io->ops) HIP_TRY(hipMemcpyAsync(io->ops, s.d_ops, (size_t)n * 2 * rs, hipMemcpyDeviceToHost, s.stream));
+    }
+    HIP_TRY(hipEventRecord(s.ev[5], s.stream));
+    s.submitted = true;
+    s.pushed = s.launched = false;
+    return AIM_OK;
+}
+
+int aim_set_wait(aim_set_t *set, uint32_t device, uint32_t slot, uint32_t *n_runs)
+{
+    if (!set || device >= set->devs.size()) return fail(AIM_EINVAL, "bad arguments");
+    if (!set->configured) return fail(AIM_ESTATE, "aim_set_configure has not been called");
+    aim_device_ctx &d = set->devs[device];
+    if (slot >= d.slots.size()) return fail(AIM_EINVAL, "slot %u not configured", slot);
+    aim_slot &s = d.slots[slot];
+    if (!s.submitted) return fail(AIM_ESTATE, "slot %u of device %d holds no batch", slot, d.dev);
+    HIP_TRY(hipSetDevice(d.dev));
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    s.submitted = false;
+    const aim_batch_io_t &io = s.io;
+    uint32_t runs = 0;
+    if (io.cigars && s.n_pairs) {   // the run count is only known now: fetch exactly that many
+        runs = std::min(std::min(*s.h_cursor, io.runs_cap), set->max_runs);
+        if (runs) {
+            HIP_TRY(hipMemcpyAsync(io.runs, s.d_runs, (size_t)runs * 4, hipMemcpyDeviceToHost, s.stream));
+            HIP_TRY(hipStreamSynchronize(s.stream));
+        }
+    }
+    if (n_runs) *n_runs = runs;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
+    set->h2d_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s.ev[2], s.ev[3]));
+    set->kernel_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, s.ev[4], s.ev[5]));
+    set->d2h_ms += ms;
+    if (io.cigars) {
+        for (uint32_t i = 0; i < s.n_pairs; ++i) {
+            if (io.cigars[i].status & AIM_CIGAR_OVERFLOW) return fail(AIM_ENOMEM, "run buffer too small (pair idx %u)", io.cigars[i].idx);
+            if (io.cigars[i].status != AIM_PAIR_OK) return status_error(io.cigars[i].idx, io.cigars[i].status);
+        }
+    } else if (io.results && !(set->params.flags & AIM_FLAG_RES8)) {
+        const aim_result_t *r = static_cast<const aim_result_t *>(io.results);
+        for (uint32_t i = 0; i < s.n_pairs; ++i)
+            if (r[i].status != AIM_PAIR_OK) return status_error(r[i].idx, r[i].status);
+    }
     return AIM_OK;
 }
 
@@ -540,29 +890,32 @@ int aim_set_timers(const aim_set_t *set, float *h2d_ms, float *kernel_ms, float 
 int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback)
 {
     if (!set || device >= set->devs.size() || !n_fallback) return fail(AIM_EINVAL, "bad arguments");
+    if (!set->configured) return fail(AIM_ESTATE, "aim_set_configure has not been called");
     aim_device_ctx &d = set->devs[device];
-    if (!d.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
+    aim_slot &s = d.slots[0];
+    if (!s.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
     *n_fallback = 0;
-    Plan pl;
-    int rc = make_plan(set->params, set->max_pairs, &pl);
-    if (rc) return rc;
-    if ((pl.kid != K_WFA_LANE && pl.kid != K_WFA_GROUP) || d.n_pairs == 0) return AIM_OK;
+    const Plan &pl = s.plan_last;   // the plan the launch actually followed, not a re-plan
+    if (pl.kid != K_WFA_GROUP || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
     HIP_TRY(hipSetDevice(d.dev));
-    HIP_TRY(hipMemcpy(n_fallback, d.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(n_fallback, s.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return AIM_OK;
+}
+
+int aim_set_plan_describe(const aim_set_t *set, uint32_t device, char *out, size_t cap)
+{
+    if (!set || device >= set->devs.size() || !out || cap == 0) return fail(AIM_EINVAL, "bad arguments");
+    if (!set->configured) return fail(AIM_ESTATE, "aim_set_configure has not been called");
+    const aim_device_ctx &d = set->devs[device];
+    const aim_slot &s = d.slots[0];
+    describe_plan(s.plan_last, set->params, s.launched ? s.n_pairs : set->max_pairs, d.budget, out, cap);
     return AIM_OK;
 }
 
 int aim_set_free(aim_set_t *set)
 {
     if (!set) return AIM_OK;
-    for (auto &d : set->devs) {
-        if (d.dev < 0) continue;
-        (void)hipSetDevice(d.dev);
-        free_device_buffers(d);
-        for (auto &e : d.ev)
-            if (e) (void)hipEventDestroy(e);
-        if (d.stream) (void)hipStreamDestroy(d.stream);
-    }
+    for (auto &d : set->devs) free_device_buffers(d);
     delete set;
     return AIM_OK;
 }
@@ -583,34 +936,46 @@ int aim_host_free(void *ptr)
 size_t aim_scratch_bytes(const aim_params_t *params, uint32_t n_pairs)
 {
     Plan pl;
-    if (!params || make_plan(*params, n_pairs, &pl)) return 0;
+    const aim::Knobs kn = read_knobs();
+    if (!params || make_plan(*params, n_pairs, kn, stateless_budget_bytes(kn), &pl)) return 0;
     return pl.scratch_total;
 }
 
-int aim_align_device(const aim_params_t *params, uint32_t n_pairs, const aim_request_t *d_requests,
-                     const char *d_patterns, const char *d_texts, aim_result_t *d_results, char *d_ops,
+int aim_align_device(const aim_params_t *params, uint32_t n_pairs, const void *d_requests,
+                     const char *d_patterns, const char *d_texts, void *d_results, char *d_ops,
                      void *d_scratch, size_t scratch_bytes, void *hip_stream)
 {
     if (!params) return fail(AIM_EINVAL, "params is NULL");
     int n = 0;
     int rc = aim_device_count(&n);
     if (rc) return rc;
-    return launch(*params, n_pairs, d_requests, d_patterns, d_texts, d_results, d_ops, d_scratch, scratch_bytes,
+    const aim::Knobs kn = read_knobs();
+    Plan pl;
+    rc = make_plan(*params, n_pairs, kn, stateless_budget_bytes(kn), &pl);
+    if (rc) return rc;
+    return launch(pl, kn, *params, n_pairs, d_requests, d_patterns, d_texts, d_results, d_ops, d_scratch, scratch_bytes,
                   (hipStream_t)hip_stream);
+}
+
+int aim_plan_describe(const aim_params_t *params, uint32_t n_pairs, char *out, size_t cap)
+{
+    if (!params || !out || cap == 0) return fail(AIM_EINVAL, "bad arguments");
+    const aim::Knobs kn = read_knobs();
+    const uint64_t budget = stateless_budget_bytes(kn);
+    Plan pl;
+    int rc = make_plan(*params, n_pairs, kn, budget, &pl);
+    if (rc) return rc;
+    describe_plan(pl, *params, n_pairs, budget, out, cap);
+    return AIM_OK;
 }
 
 const char *aim_kernel_name(const aim_params_t *params)
 {
     Plan pl;
-    if (!params || make_plan(*params, 1u << 20, &pl)) return "";
-    switch (pl.kid) {
-    case K_WFA_WAVE: return "wfa_wave_kernel";
-    case K_WFA_LANE: return "wfa_lane_kernel";
-    case K_WFA_GROUP: return "wfa_group_kernel";
-    case K_DP_LANE: return p_is_nw(params) ? "nw_lane_kernel" : "swg_lane_kernel";
-    case K_DP_WAVE: return "dp_wave_kernel";
-    }
-    return "";
+    aim::Knobs kn = read_knobs();
+    kn.plan_debug = false;
+    if (!params || make_plan(*params, 1u << 20, kn, stateless_budget_bytes(kn), &pl)) return "";
+    return kernel_name(pl, *params);
 }
 
 // ---------------------------------------------------------------------------
@@ -649,6 +1014,48 @@ int aim_cigar_format(const char *ops, int32_t begin_offset, int32_t end_offset, 
         }
     }
     n += snprintf(out + n, (size_t)(cap - n), "%d%c\n", run, last_op);
+    if (n >= cap) return fail(AIM_EINVAL, "cigar buffer too small");
+    return n;
+}
+
+int aim_pack_sequence(const char *seq, int32_t len, int32_t read_size, uint32_t *row)
+{
+    if (!seq || !row || len < 0 || len > read_size) return fail(AIM_EINVAL, "bad arguments");
+    const uint32_t dw = aim::packed_row_dwords(read_size);
+    uint32_t bad = 0;
+    int i = 0;
+    for (uint32_t w = 0; w < dw; ++w) {
+        uint32_t v = 0;
+        const int lim = std::min(len, (int)(w + 1) * 16);
+        for (int sh = 0; i < lim; ++i, sh += 2) {
+            const unsigned char c = (unsigned char)seq[i];
+            const uint32_t code = (c >> 1) & 3u;
+            bad |= (uint32_t)(c ^ (unsigned char)"ACTG"[code]);
+            v |= code << sh;
+        }
+        row[w] = v;
+    }
+    return bad == 0;
+}
+
+int aim_cigar_format_runs(const uint32_t *runs, uint32_t n_runs, char *out, int32_t cap)
+{
+    if (!runs || !out || cap < 4 || n_runs == 0) return fail(AIM_EINVAL, "bad arguments");
+    int n = 0;
+    uint32_t run = runs[0] >> 8;
+    char last_op = (char)(runs[0] & 0xff);
+    for (uint32_t i = 1; i < n_runs; ++i) {
+        const char op = (char)(runs[i] & 0xff);
+        if (op == last_op) {
+            run += runs[i] >> 8;
+        } else {
+            n += snprintf(out + n, (size_t)(cap - n), "%u%c", run, last_op);
+            if (n >= cap - 1) return fail(AIM_EINVAL, "cigar buffer too small");
+            last_op = op;
+            run = runs[i] >> 8;
+        }
+    }
+    n += snprintf(out + n, (size_t)(cap - n), "%u%c\n", run, last_op);
     if (n >= cap) return fail(AIM_EINVAL, "cigar buffer too small");
     return n;
 }

@@ -28,6 +28,65 @@ struct KArgs {
     uint32_t ring_slots;  // WFA wave kernel: LDS offset ring, slots (0 = none) ...
     uint32_t slot_w;      // ... and diagonals per slot
     const uint32_t *todo; // nullptr: units are pairs 0..n_pairs-1; else {count @0, pair ids @16..} written by wfa_lane
+    uint32_t dbg_poison_lds;    // debugging aid (AIM_DEBUG_POISON_LDS): 0 = off, else 0x100 | byte every workgroup fills its
+    uint32_t dbg_lds_bytes;     // dynamic LDS with at kernel entry (results must not depend on it)
+};
+
+// Request / result access for both wire layouts (aim_hip.h: AIM_FLAG_REQ8 / AIM_FLAG_RES8). The flag tests are wave-uniform.
+__device__ __forceinline__ aim_request_t load_request(const KArgs &a, uint32_t pair)
+{
+    if (a.p.flags & AIM_FLAG_REQ8) {
+        const aim_request8_t q = reinterpret_cast<const aim_request8_t *>(a.req)[pair];
+        aim_request_t r;
+        r.pattern_len = q.pattern_len; r.text_len = q.text_len; r.padding = 0; r.idx = q.idx;
+        return r;
+    }
+    return a.req[pair];
+}
+__device__ __forceinline__ void store_result(const KArgs &a, uint32_t pair, const aim_result_t &r)
+{
+    if (a.p.flags & AIM_FLAG_RES8) {
+        aim_result8_t q;
+        q.idx = r.idx; q.score = r.score;
+        reinterpret_cast<aim_result8_t *>(a.res)[pair] = q;
+    } else {
+        a.res[pair] = r;
+    }
+}
+
+// Debugging aid shared by all kernels: fill the workgroup's dynamic LDS with a chosen byte before anything else runs.
+// A kernel whose results depend on what LDS held at entry changes its output under this switch (tools/soak_dp_wave.py).
+__device__ __forceinline__ void debug_poison_lds(const KArgs &a, char *smem)
+{
+    if (a.dbg_poison_lds) {   // wave-uniform, false in production
+        const uint32_t w = (a.dbg_poison_lds & 0xffu) * 0x01010101u;
+        uint32_t *s4 = reinterpret_cast<uint32_t *>(smem);
+        for (uint32_t i = threadIdx.x; i < a.dbg_lds_bytes / 4; i += blockDim.x) s4[i] = w;
+        __syncthreads();
+    }
+}
+
+// Run-time knobs (the AIM_* environment variables). They are experiment / debugging switches, not configuration: every
+// one of them leaves results bit-identical. They are read in ONE place (read_knobs, aim_capi.hip) into this struct --
+// once per aim_set_configure (frozen in the set together with the plan) and once per stateless entry point -- and the
+// planners below only ever see the struct, so plan selection cannot change between a set's configure and its launches.
+struct Knobs {
+    double scratch_gb = -1.0;     // AIM_SCRATCH_GB      upper bound on plan scratch (default: 3/4 of free device memory)
+    bool force_wave = false;      // AIM_FORCE_WAVE=1    WFA: general one-pair-per-wavefront kernel only
+    bool no_group = false;        // AIM_NO_GROUP=1      WFA: skip wfa_group_kernel
+    bool no_lane_ext = false;     // AIM_NO_LANE_EXT=1   WFA: only the (3,4,1) MAX_SCORE<=5 lane shapes (round-1 behaviour)
+    bool wfa_no_ring = false;     // AIM_WFA_NO_RING=1   wfa_wave: no LDS offset ring
+    int wfa_slotw = -1;           // AIM_WFA_SLOTW       wfa_wave: diagonals per ring slot
+    bool force_dpwave = false;    // AIM_FORCE_DPWAVE=1  NW/SWG: row-scan kernel also for short reads
+    int dpw_nw = -1;              // AIM_DPW_NW          dp_wave: wavefronts per pair
+    int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: 0 = pattern from global memory
+    int dpl_per_cu = -1;          // AIM_DPL_PER_CU      dp_lane: residency sweep
+    int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs
+    int group_g = -1;             // AIM_GROUP_G         wfa_group: lanes per pair
+    int group_per_cu = -1;        // AIM_GROUP_PER_CU    wfa_group: residency sweep
+    int poison_scratch = -1;      // AIM_DEBUG_POISON_SCRATCH  fill scratch with this byte at configure
+    int poison_lds = -1;          // AIM_DEBUG_POISON_LDS      fill dynamic LDS with this byte at kernel entry
+    bool plan_debug = false;      // AIM_PLAN_DEBUG=1    print the chosen plan to stderr
 };
 
 // XCD-aware work distribution: workgroups are dealt round-robin over the 8 XCDs

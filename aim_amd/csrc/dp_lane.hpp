@@ -85,6 +85,7 @@ template <bool BT, bool SEQ_LDS, bool NOWRAP>
 __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
     // NW_W16 (NW/DPU-WRAM/common/common.h:87-97): cells are int16. cell_t is the type the arithmetic runs in -- int16_t
     // with the reference's casts, or int when nw_lane_nowrap() proved them identities; LDS rows and the table are int16.
     typedef typename std::conditional<NOWRAP, int, int16_t>::type cell_t;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         if (SEQ_LDS) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
         __syncthreads();
         if (!active) continue;
-        const aim_request_t rq = a.req[pair];
+        const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const uint32_t *gP32 = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
         const uint32_t *gT32 = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         r.score = (int)score;
         r.status = AIM_PAIR_OK;
         r.idx = rq.idx;
-        a.res[pair] = r;
+        store_result(a, pair, r);
     }
 #undef TB
 #undef TBI
@@ -260,6 +261,7 @@ template <typename CELL, bool BT, bool SEQ_LDS>
 __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);                             // pattern image [dword][lane]
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         if (SEQ_LDS) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
         __syncthreads();
         if (!active) continue;
-        const aim_request_t rq = a.req[pair];
+        const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const uint32_t *gP32 = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
         const uint32_t *gT32 = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         r.score = score;
         r.status = status;
         r.idx = rq.idx;
-        a.res[pair] = r;
+        store_result(a, pair, r);
     }
 #undef RM
 #undef RI
@@ -477,7 +479,7 @@ inline int swg_cell_bytes(const aim_params_t &p)
 }
 
 // Returns false when even the smallest grid does not fit the scratch budget.
-inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, uint32_t *grid, uint32_t *block,
+inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, const Knobs &kn, uint32_t *grid, uint32_t *block,
                          size_t *lds, uint64_t *scratch_per_wg, size_t *scratch_total, bool *seq_lds)
 {
     const uint64_t rs = (uint64_t)p.read_size;
@@ -499,12 +501,12 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     const size_t rows = p.algo == AIM_ALGO_NW ? (size_t)(p.read_size + 1) * kWave * 2
                                               : (size_t)2 * (p.read_size + 1) * kWave * swg_cell_bytes(p);   // SWG: M and I rows, CELL-typed
     *seq_lds = img + rows <= 150 * 1024;
-    if (const char *e = getenv("AIM_DPL_SEQ_LDS")) *seq_lds = *seq_lds && atoi(e) != 0;   // experiments: 0 = pattern from global memory
+    if (kn.dpl_seq_lds >= 0) *seq_lds = *seq_lds && kn.dpl_seq_lds != 0;   // experiments: 0 = pattern from global memory
     *lds = rows + (*seq_lds ? img : 0);
     if (*lds > 160 * 1024) return false;
     uint32_t per_cu = (uint32_t)std::min<size_t>(12, lds_workgroups_per_cu(*lds));
-    if (const char *e = getenv("AIM_DPL_PER_CU")) {   // experiments: residency sweep (also lifts the 8-per-CU start value)
-        per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), lds_workgroups_per_cu(*lds));
+    if (kn.dpl_per_cu >= 0) {   // experiments: residency sweep (also lifts the 8-per-CU start value)
+        per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.dpl_per_cu), lds_workgroups_per_cu(*lds));
         g = std::min<uint32_t>(256 * per_cu, need < 8u ? 8u : need);
         while (g > 8 && per * g > budget) g -= 8;
         *grid = g;

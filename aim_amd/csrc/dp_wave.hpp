@@ -80,6 +80,7 @@ template <int ALGO, bool BT, bool CELL8, int NW>
 __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
     constexpr bool SWG = (ALGO == AIM_ALGO_SWG);
     constexpr int NT = kWave * NW;
     const int tid = threadIdx.x;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
     for (uint32_t it = 0;; ++it) {
         uint32_t pair;
         if (!xcd_unit(a.n_pairs, it, &pair)) break;
-        const aim_request_t rq = a.req[pair];
+        const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
         const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 }
             }
             if (tid == 0) sc_sh[0] = score;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SWG's ops prefill by all threads completes before the traceback patches it
             __syncthreads();
             score = sc_sh[0];
         } else {
@@ -198,6 +200,13 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
             DpCell B;                                  // boundary cell of the current row (flat[W*h])
             const int nblocks = (Rr + kDpBlock - 1) / kDpBlock;
             const int nsteps = (nblocks + NW - 1) / NW;
+            // Cross-wavefront GLOBAL-memory dependency 1 of 2 (write after write): the row-init stores just above put h*GI at
+            // TM[h*S+7] from whatever thread owns h; first_tail_cell (below) later overwrites TM[(h+1)*S+7] from the lane that
+            // computes cell W-1, usually a different wavefront. __syncthreads() compiles to "s_waitcnt lgkmcnt(0); s_barrier"
+            // here (non-tgsplit mode: the compiler relies on the CU keeping the vector-memory stream of one workgroup in
+            // order), so the order of the two stores was implicit. Made explicit: every row-init store has COMPLETED (vmcnt
+            // counts stores on gfx9) before any wavefront passes the first row-start barrier. Once per pair.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int h = 1; h <= tlen; ++h) {
                 AIM_DPW_STAMP(7);                      // tail phase / loop overhead of the previous row
                 __syncthreads();                       // previous row (and its tail / boundary cell) is complete in LDS
@@ -419,6 +428,11 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 }
                 cur = nxt;
             }
+            // Cross-wavefront GLOBAL-memory dependency 2 of 2 (read after write, and write after write on ops): the table
+            // planes are stored by every wavefront (and SWG's 'M' prefill of the ops row by every thread), the traceback
+            // below reads the table and patches ops from the FIRST wavefront only. As above the barrier alone orders LDS,
+            // not outstanding global stores, so each wavefront drains its stores before it arrives. Once per pair.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #ifdef AIM_DPW_STAMPS
             if (tid == 0) { unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ops); for (int i = 0; i < 8; ++i) dbg[i] = dpw_sum[i]; }
@@ -542,12 +556,12 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
             r.score = score;
             r.status = status;
             r.idx = rq.idx;
-            a.res[pair] = r;
+            store_result(a, pair, r);
         }
     }
 }
 
-inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs)
+inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn)
 {
     // A row is ceil(nblocks / NW) sequential steps, each ending in a workgroup barrier, and block b is taken by wavefront
     // b % NW. ASSUMING wavefronts are placed round-robin on the CU's 4 SIMDs (w % 4; not verified, but the measured
@@ -556,8 +570,8 @@ inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs)
     // READ_SIZE 10112 = 20 blocks: 8 wavefronts 3 steps, 10 wavefronts 2 steps but 6/4 blocks per SIMD, 12 wavefronts
     // 2 steps and 5 per SIMD. Measured on config 4 (three interleaved rounds): 54.3 / 52.3 / 49.1 ms.
     const int nblocks = (p.read_size + kDpBlock - 1) / kDpBlock;
-    if (const char *e = getenv("AIM_DPW_NW")) {   // A/B runs
-        const int f = atoi(e);
+    if (kn.dpw_nw >= 0) {   // A/B runs
+        const int f = kn.dpw_nw;
         if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10 || f == 12) return f;
     }
     // Up to 8 blocks per row: just enough wavefronts per pair to put ~4096 wavefronts (4 per SIMD) on the chip, never more
@@ -582,7 +596,7 @@ inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs)
     return best;
 }
 
-inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, bool cell8, uint32_t *grid, uint32_t *block,
+inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, const Knobs &kn, bool cell8, uint32_t *grid, uint32_t *block,
                          size_t *lds, uint64_t *scratch_per_wg, size_t *scratch_total)
 {
     const uint64_t rs = (uint64_t)p.read_size;
@@ -590,7 +604,7 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     uint64_t per = 3 * S * (rs + 3) * 2;   // three int16 planes (NW uses the first)
     per = (per + 255) & ~255ull;
     (void)cell8;
-    const int nw = dp_wave_nw(p, n_pairs);
+    const int nw = dp_wave_nw(p, n_pairs, kn);
     *block = (uint32_t)(kWave * nw);
     const bool swg = p.algo == AIM_ALGO_SWG;
     const uint64_t rowcap = (rs + 31) & ~7ull;

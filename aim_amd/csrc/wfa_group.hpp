@@ -62,6 +62,7 @@ template <int G, bool REDUCE, bool BT>
 __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
     constexpr int PPW = kWave / G;                       // pairs per wavefront
     const int lane = threadIdx.x;
     const int g = lane % G, q = lane / G;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     rq_next.pattern_len = rq_next.text_len = 0; rq_next.padding = 0; rq_next.idx = 0;
     if (have) {
         dma(unit);
-        if (unit * PPW + q < a.n_pairs) rq_next = a.req[unit * PPW + q];
+        if (unit * PPW + q < a.n_pairs) rq_next = load_request(a, unit * PPW + q);
     }
     for (uint32_t it = 0; have; ++it) {
         const uint32_t pair = unit * PPW + q;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         __syncthreads();
         if (nhave) {
             dma(nunit);
-            if (nunit * PPW + q < a.n_pairs) rq_next = a.req[nunit * PPW + q];
+            if (nunit * PPW + q < a.n_pairs) rq_next = load_request(a, nunit * PPW + q);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                 r.score = final_score;
                 r.status = status;
                 r.idx = rq.idx;
-                a.res[pair] = r;
+                store_result(a, pair, r);
             }
         }
         have = nhave;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c, int *G, uint32_t *grid, size_t *lds, size_t *hist_bytes)
+inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, GroupCfg *c, int *G, uint32_t *grid, size_t *lds, size_t *hist_bytes)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
     if (p.read_size > 2048 || p.max_score > 400) return false;
@@ -490,7 +491,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     int g = 32;
     for (size_t cap_kb : {12, 24, 48}) {
         size_t cap_bytes = cap_kb * 1024;
-        if (const char *e = getenv("AIM_GROUP_LDS_KB")) cap_bytes = (size_t)atoi(e) * 1024;
+        if (kn.group_lds_kb >= 0) cap_bytes = (size_t)kn.group_lds_kb * 1024;
         g = 1;
         while (g <= 16 && (size_t)(kWave / g) * dw * 4 > cap_bytes) g *= 2;
         if (g <= 16) break;
@@ -506,8 +507,8 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
         const size_t wg = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8 + (size_t)(kWave / g) * dw * 4 + 64;
         if (lds_workgroups_per_cu(wg) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
     }
-    if (const char *e = getenv("AIM_GROUP_G")) {   // experiments: force the lanes per pair if the plan is feasible at all
-        const int fg = atoi(e);
+    if (kn.group_g >= 0) {   // experiments: force the lanes per pair if the plan is feasible at all
+        const int fg = kn.group_g;
         if ((fg == 1 || fg == 2 || fg == 4 || fg == 8 || fg == 16 || fg == 64) && (size_t)(kWave / fg) * dw * 4 <= 48 * 1024) g = fg;
     }
     *G = g;
@@ -521,13 +522,13 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, GroupCfg *c,
     // (11), e=5% 3.85 -> 2.82 (14), e=10% 6.17 -> 4.10 (16), l=250 e=5% 4.23 -> 3.53 (11), l=150 e=2% 1.94 -> 1.28 (16),
     // l=100 e=5% CIGAR 2.29 -> 1.73 (14); G = 64 (cfg3): 11 / 12 / 13 / 14 per CU = 7.81 / 7.10 / 7.42 / 7.06 ms.
     uint32_t per_cu = (uint32_t)std::min<size_t>(16, lds_fit);
-    if (const char *e = getenv("AIM_GROUP_PER_CU")) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, atoi(e)), lds_fit);   // residency sweeps
+    if (kn.group_per_cu >= 0) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.group_per_cu), lds_fit);   // residency sweeps
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
     uint32_t gr = 256 * per_cu;
     const uint32_t need = ((n_units + 7u) / 8u) * 8u;
     if (gr > need) gr = need < 8u ? 8u : need;
     *grid = gr;
-    if (getenv("AIM_PLAN_DEBUG"))
+    if (kn.plan_debug)
         fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u\n", g, ring_m, ring_e,
                 c->wcap, dw * 4, *lds, lds_fit, per_cu, gr);
     c->hist_stride = (p.max_score + 2) * (3 * c->wcap + 4);

@@ -17,7 +17,9 @@
 //   bases) is a mismatch bit-vector; extending from pattern position v is "first set bit at or after v",
 //   clamped to min(plen, tlen - k).  No loop, no divergence, no memory access.
 // Pairs containing anything but A/C/G/T (the reference compares raw bytes, host.c:126-127) cannot be
-// packed; they are appended to a to-do list that the general kernel (wfa_wave.hpp) drains right after.
+// packed.  When a wavefront holds at least one such pair (wave-uniform test), its mismatch bit-vectors are
+// built from the RAW bytes instead (byte-wise P[v] != T[v+k], exact for any byte values) and everything
+// downstream is unchanged -- no to-do list, no second kernel, no counter to reset between launches.
 #pragma once
 
 #include "aim_device.hpp"
@@ -169,7 +171,39 @@ __device__ __forceinline__ uint32_t pack_row(const uint4 (&raw)[NP], int len, in
     return bad;
 }
 
-enum : uint32_t { LANE_TODO_COUNT = 0, LANE_TODO_LIST = 16 };   // dword offsets inside the to-do region
+enum : uint32_t { LANE_TODO_COUNT = 0, LANE_TODO_LIST = 16 };   // dword offsets inside the to-do region (wfa_group.hpp only)
+
+// Mismatch flags of diagonal k straight from the raw rows, for ANY byte values: bit 2i of out[j] is set
+// <=> P[16j+i] != T[16j+i+k] (the layout first_stop() scans; the packed path sets one or both bits of a pair).
+// Cold path: only run for wavefronts that hold a pair with a byte outside A/C/G/T.
+template <int NP>
+__device__ __forceinline__ void raw_diag(const uint4 (&rawP)[NP], const uint4 (&rawT)[NP], int k, uint32_t (&out)[NP])
+{
+    uint32_t pw[4 * NP], tw[4 * NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        pw[4 * j] = rawP[j].x; pw[4 * j + 1] = rawP[j].y; pw[4 * j + 2] = rawP[j].z; pw[4 * j + 3] = rawP[j].w;
+        tw[4 * j] = rawT[j].x; tw[4 * j + 1] = rawT[j].y; tw[4 * j + 2] = rawT[j].z; tw[4 * j + 3] = rawT[j].w;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        uint32_t b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int w = 4 * j + i;
+            const int o = 4 * w + k;                              // byte offset of T[4w + k]
+            const int wi = (o >= 0) ? (o >> 2) : -((-o + 3) >> 2);   // floor(o / 4)
+            const int sh = o - 4 * wi;                            // 0..3
+            const uint32_t lo = (wi >= 0 && wi < 4 * NP) ? tw[wi] : 0u;
+            const uint32_t hi = (wi + 1 >= 0 && wi + 1 < 4 * NP) ? tw[wi + 1] : 0u;
+            const uint32_t ts = sh ? __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh) : lo;
+            const uint32_t x = pw[w] ^ ts;
+            const uint32_t nz = ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;   // 1 per non-zero byte
+            b[i] = __builtin_amdgcn_udot4(nz, 0x40100401u, 0u, false);
+        }
+        out[j] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    }
+}
 
 
 template <int X, int O, int E, int MAXS, int RS, bool BT>
@@ -182,12 +216,12 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
     constexpr int NP = RS / 16;                 // packed dwords per sequence
     constexpr int KW = SH.kmax - SH.kmin + 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + kWave * (RS / 4);
     uint32_t *resL = rowsT + kWave * (RS / 4);          // 64 x aim_result_t (24 B) staged for a coalesced store
     const int lane = threadIdx.x;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
-    uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
     const int ms_run = a.p.max_score;           // runtime MAX_SCORE <= MAXS
 
     // static XCD slices (an atomic work ticket was measured 3.5x slower: one word serves ~88 tickets/us)
@@ -199,7 +233,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
     if (have) {
         dma_rows<RS, NCH>(rowsP, a.patterns, grp * kWave, a.n_pairs, lane);
         dma_rows<RS, NCH>(rowsT, a.texts, grp * kWave, a.n_pairs, lane);
-        if (grp * kWave + lane < a.n_pairs) rq_next = a.req[grp * kWave + lane];
+        if (grp * kWave + lane < a.n_pairs) rq_next = load_request(a, grp * kWave + lane);
     }
 #if AIM_LANE_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
@@ -231,7 +265,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         if (nhave) {
             dma_rows<RS, NCH>(rowsP, a.patterns, ngrp * kWave, a.n_pairs, lane);
             dma_rows<RS, NCH>(rowsT, a.texts, ngrp * kWave, a.n_pairs, lane);
-            if (ngrp * kWave + lane < a.n_pairs) rq_next = a.req[ngrp * kWave + lane];
+            if (ngrp * kWave + lane < a.n_pairs) rq_next = load_request(a, ngrp * kWave + lane);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the DMA issue ahead of the ALU work
         AIM_STAMP(3);                           // DMA issue
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
             if (active && (AIM_LANE_DIAG == 1 || x == 0x12345678u)) {
                 aim_result_t r;
                 r.max_operations = plen + tlen; r.begin_offset = 0; r.end_offset = 0; r.score = (int)x; r.status = 0; r.idx = rq.idx;
-                a.res[pair] = r;
+                store_result(a, pair, r);
             }
             have = nhave; grp = ngrp;
             continue;
@@ -264,7 +298,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
             if (active) {
                 aim_result_t r;
                 r.max_operations = plen + tlen; r.begin_offset = 0; r.end_offset = 0; r.score = (int)x; r.status = 0; r.idx = rq.idx;
-                a.res[pair] = r;
+                store_result(a, pair, r);
             }
             have = nhave; grp = ngrp;
             continue;
@@ -272,16 +306,22 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
 #endif
         // ---- mismatch bit-vectors per diagonal: bit pair v of dk[k] != 0  <=>  P[v] != T[v + k] ----
         uint32_t dk[KW][NP];
+        if (__ballot(active && bad != 0u) != 0ull) {
+            // some pair of this wavefront has a byte outside A/C/G/T ('N' in real reads): compare raw bytes (cold path)
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            const int k = SH.kmin + kk;
+            for (int kk = 0; kk < KW; ++kk) raw_diag<NP>(rawP, rawT, SH.kmin + kk, dk[kk]);
+        } else {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                uint32_t ts;
-                if (k == 0) ts = T[j];
-                else if (k > 0) ts = __builtin_amdgcn_alignbit(j + 1 < NP ? T[j + 1] : 0u, T[j], 2 * k);
-                else ts = __builtin_amdgcn_alignbit(T[j], j > 0 ? T[j - 1] : 0u, 32 + 2 * k);
-                dk[kk][j] = P[j] ^ ts;
+            for (int kk = 0; kk < KW; ++kk) {
+                const int k = SH.kmin + kk;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    uint32_t ts;
+                    if (k == 0) ts = T[j];
+                    else if (k > 0) ts = __builtin_amdgcn_alignbit(j + 1 < NP ? T[j + 1] : 0u, T[j], 2 * k);
+                    else ts = __builtin_amdgcn_alignbit(T[j], j > 0 ? T[j - 1] : 0u, 32 + 2 * k);
+                    dk[kk][j] = P[j] ^ ts;
+                }
             }
         }
         const int ak = tlen - plen;   // alignment_k
@@ -347,7 +387,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
                 if (k == ak) { m_end = off; end_in_range = true; }
             }
             if (!done && end_in_range && m_end >= tlen) { done = true; score = s; }
-            if (__ballot(!done && active && bad == 0u) == 0ull) break;   // every pair of this wave has finished
+            if (__ballot(!done && active) == 0ull) break;   // every pair of this wave has finished
             if (s + 1 > ms_run) break;                              // runtime MAX_SCORE below the template cap
         }
         if (!done) score = ms_run + 1;                              // wfa.c:368-376
@@ -355,7 +395,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
 
         int begin_offset = plen + tlen - 1;     // edit_cigar_allocate, wfa.c:57-67
         int status = AIM_PAIR_OK;
-        if (BT && active && bad == 0u) {
+        if (BT && active) {
             // memset(cigar->operations, 'M', 2*READ_SIZE) (wfa.c:465): full rows, constant data, no VGPR image.
             // Match runs of the backtrace then only move begin_offset; edit ops are patched in as bytes.
             char *ops = a.ops + (uint64_t)pair * (2 * RS);
@@ -465,10 +505,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
             }
         }
         if (active) {
-            if (bad != 0u) {   // non-ACGT byte inside a sequence: hand the pair to the general kernel
-                const uint32_t slot = atomicAdd(&todo[LANE_TODO_COUNT], 1u);
-                todo[LANE_TODO_LIST + slot] = pair;
-            } else {
+            {
                 aim_result_t r;
                 r.max_operations = plen + tlen;
                 r.begin_offset = begin_offset;
@@ -489,11 +526,11 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
                     rl[3] = (uint32_t)r.score; rl[4] = (uint32_t)r.status; rl[5] = (uint32_t)r.idx;
                 } else
 #endif
-                a.res[pair] = r;
+                store_result(a, pair, r);
             }
         }
 #if AIM_LANE_RES_STAGE
-        if (full_group) {   // wave-uniform; lanes handed to the to-do list leave a stale struct that the general kernel overwrites later
+        if (full_group) {   // wave-uniform
             typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const aim_u32x4 *src = reinterpret_cast<const aim_u32x4 *>(resL);

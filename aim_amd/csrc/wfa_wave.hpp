@@ -82,6 +82,7 @@ template <bool BT, bool REDUCE, bool SEQ_LDS>
 __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
     const int rsw = rs >> 2;                 // dwords per sequence row (read_size % 8 == 0)
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
         uint32_t pair;
         if (!xcd_unit(n_units, it, &pair)) break;   // past this block's slice: done
         if (a.todo) pair = a.todo[16 + pair];
-        const aim_request_t rq = a.req[pair];
+        const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
         const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
@@ -296,6 +297,14 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
                     break;
                 }
                 pool_used = 0;   // score-only: the pool is a ring sized for the live window
+                // The plan never hands a score-only wavefront less than the live window ((R+2) * 3 * (2*MAX_SCORE+3)
+                // entries, make_plan); a wavefront that still does not fit after the wrap would run over the next
+                // workgroup's scratch, so it is reported like the DPU arena's "out of memory" instead.
+                if ((uint32_t)(len * narr) > pool_cap) {
+                    status = AIM_PAIR_NOMEM;
+                    final_score = score;
+                    break;
+                }
             }
             cur.flags = WF_PRESENT | (i_out_null ? WF_INULL : WF_HASI) | (d_out_null ? WF_DNULL : WF_HASD) | (inlds ? WF_INLDS : 0);
             cur.klo = cur.lo = lo;
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
             r.score = final_score;
             r.status = status;
             r.idx = rq.idx;
-            a.res[pair] = r;
+            store_result(a, pair, r);
         }
     }
 }

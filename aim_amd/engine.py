@@ -12,8 +12,8 @@ import math
 import numpy as np
 
 from . import capi
-from .capi import (ALGO_BY_NAME, ALGO_NW, ALGO_SWG, ALGO_WFA, FLAG_BACKTRACE, FLAG_REDUCE, FLAG_SWG_W16,
-                   REQUEST_DTYPE, RESULT_DTYPE, Params)
+from .capi import (ALGO_BY_NAME, ALGO_NW, ALGO_SWG, ALGO_WFA, FLAG_BACKTRACE, FLAG_REDUCE, FLAG_REQ8, FLAG_RES8, FLAG_SWG_W16,
+                   REQUEST8_DTYPE, REQUEST_DTYPE, RESULT8_DTYPE, RESULT_DTYPE, Params)
 
 
 def round_up_8(x):
@@ -30,9 +30,10 @@ def launcher_sizes(algo, read_length, error, mismatch=3, gap_o=4, gap_e=1, gap=4
 
 
 def make_params(algo, max_score, read_size, match=0, mismatch=3, gap_o=4, gap_e=1, gap=4, backtrace=False,
-                reduce=False, swg_w16=False):
+                reduce=False, swg_w16=False, req8=False, res8=False):
     a = ALGO_BY_NAME[algo] if isinstance(algo, str) else algo
     flags = (FLAG_BACKTRACE if backtrace else 0) | (FLAG_REDUCE if reduce else 0) | (FLAG_SWG_W16 if swg_w16 else 0)
+    flags |= (FLAG_REQ8 if req8 else 0) | (FLAG_RES8 if res8 else 0)
     return Params(a, match, mismatch, gap_o, gap_e, gap, gap, max_score, read_size, flags)
 
 
@@ -52,6 +53,13 @@ def gen_pairs(seed, first_idx, n_pairs, length, error, read_size):
     capi.check(lib.aim_gen_pairs(seed, first_idx, n_pairs, length, float(error), read_size, capi.ptr(req),
                                  capi.ptr(pat), capi.ptr(txt)))
     return req, pat, txt
+
+
+def to_request8(req):
+    """aim_request_t[] -> aim_request8_t[] (the reference's own 8-byte WFA request_t; AIM_FLAG_REQ8)."""
+    out = np.zeros(len(req), dtype=REQUEST8_DTYPE)
+    out["pattern_len"], out["text_len"], out["idx"] = req["pattern_len"], req["text_len"], req["idx"]
+    return out
 
 
 def pairs_to_text(req, pat, txt):
@@ -141,6 +149,8 @@ class DeviceSet:
         self.max_pairs = max_pairs_per_device
 
     def push(self, device, req, pat, txt):
+        if (self.params.flags & FLAG_REQ8) and req.dtype != REQUEST8_DTYPE:
+            req = to_request8(req)
         req = np.ascontiguousarray(req)
         pat = np.ascontiguousarray(pat)
         txt = np.ascontiguousarray(txt)
@@ -156,7 +166,7 @@ class DeviceSet:
     def pull(self, device, check=True):
         n = self._n[device]
         rs = self.params.read_size
-        res = np.zeros(n, dtype=RESULT_DTYPE)
+        res = np.zeros(n, dtype=RESULT8_DTYPE if (self.params.flags & FLAG_RES8) else RESULT_DTYPE)
         ops = np.zeros((n, 2 * rs), dtype=np.uint8) if (self.params.flags & FLAG_BACKTRACE) else None
         rc = self.lib.aim_set_pull(self.handle, device, capi.ptr(res), capi.ptr(ops))
         if rc != capi.AIM_EALIGN or check:
@@ -167,6 +177,12 @@ class DeviceSet:
         n = C.c_uint32()
         capi.check(self.lib.aim_set_fallback_pairs(self.handle, device, C.byref(n)))
         return n.value
+
+    def plan_describe(self, device=0):
+        """The plan line of the last launch on `device` (aim_set_plan_describe)."""
+        buf = C.create_string_buffer(512)
+        capi.check(self.lib.aim_set_plan_describe(self.handle, device, buf, len(buf)))
+        return buf.value.decode()
 
     def timers(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def pmc_traffic(kernel, pairs):
+def pmc_traffic(kernel, pairs, io):
     """HBM bytes per launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2-corrected + WRITE_SIZE,
     separate passes; profiles/rNN/*_pmc_summary.json) when it was taken on this kernel and batch size."""
     import glob
@@ -35,7 +35,7 @@ def pmc_traffic(kernel, pairs):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("kernel", "").startswith(kernel) and d.get("pairs_per_launch") == pairs:
+        if d.get("kernel", "").startswith(kernel) and d.get("pairs_per_launch") == pairs and d.get("io", "default") == io:
             best = (d["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
     return best
 
@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--length", type=int, default=100)
     ap.add_argument("--error", type=float, default=0.01)
     ap.add_argument("--backtrace", action="store_true", help="also produce CIGAR ops (not the headline config)")
+    ap.add_argument("--io", choices=["compact", "default"], default="compact",
+                    help="wire layout of requests/results: 'compact' = the reference's own 8-B WFA request_t + 8-B {idx, score} "
+                         "results (AIM_FLAG_REQ8|RES8, score-only); 'default' = the 16-B / 24-B NW/SWG structs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-pairs", type=int, default=1 << 20, help="pairs re-checked against the CPU oracle after timing")
     args = ap.parse_args()
@@ -86,7 +89,10 @@ def main():
 
     n = args.pairs
     ms, rs = engine.launcher_sizes("wfa", args.length, args.error)
-    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=args.backtrace)
+    compact = args.io == "compact"
+    req8, res8 = compact, compact and not args.backtrace
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=args.backtrace, req8=req8, res8=res8)
+    res_dtype = capi.RESULT8_DTYPE if res8 else capi.RESULT_DTYPE
     # static contiguous split: rank r owns global pairs [r*n, (r+1)*n)  (host.c:191-209)
     req, pat, txt = engine.gen_pairs(42, shard.weak_first_index(n, rank), n, args.length, args.error, rs)
     alg_bytes = int(req["pattern_len"].astype(np.int64).sum() + req["text_len"].astype(np.int64).sum() + 16 * n)
@@ -97,8 +103,8 @@ def main():
         t[: a.nbytes].copy_(torch.from_numpy(a.view(np.uint8).reshape(-1)))
         return t
 
-    d_req, d_pat, d_txt = to_dev(req), to_dev(pat), to_dev(txt)
-    d_res = torch.zeros(n * capi.RESULT_DTYPE.itemsize + 64, dtype=torch.uint8, device=dev)
+    d_req, d_pat, d_txt = to_dev(engine.to_request8(req) if req8 else req), to_dev(pat), to_dev(txt)
+    d_res = torch.zeros(n * res_dtype.itemsize + 64, dtype=torch.uint8, device=dev)
     d_ops = torch.zeros(n * 2 * rs + 64, dtype=torch.uint8, device=dev) if args.backtrace else None
     scratch_bytes = lib.aim_scratch_bytes(C.byref(params), n)
     d_scratch = torch.zeros(max(scratch_bytes, 256), dtype=torch.uint8, device=dev)
@@ -134,7 +140,7 @@ def main():
 
     # final (idx, score) gather to every rank over RCCL/xGMI -- outside the timed region, reported separately
     gather_ms = None
-    res_host = np.frombuffer(d_res[: n * capi.RESULT_DTYPE.itemsize].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+    res_host = np.frombuffer(d_res[: n * res_dtype.itemsize].cpu().numpy().tobytes(), dtype=res_dtype)
     if world > 1:
         scores = torch.from_numpy(np.ascontiguousarray(res_host["score"])).to(dev)
         torch.cuda.synchronize(dev)
@@ -177,7 +183,9 @@ def main():
         value = total_pairs / elapsed
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         kname = lib.aim_kernel_name(C.byref(params)).decode()
-        traffic = pmc_traffic(kname, n) if not args.backtrace else None
+        plan_buf = C.create_string_buffer(512)
+        capi.check(lib.aim_plan_describe(C.byref(params), n, plan_buf, len(plan_buf)))
+        traffic = pmc_traffic(kname, n, args.io) if not args.backtrace else None
         line = {
             "metric": "aligned pairs/sec WFA-adaptive l=%d e=%g%%" % (args.length, args.error * 100),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,7 +194,10 @@ def main():
             "config": {"workload": "WFA-adaptive %s l=%d e=%g%% %d synthetic pairs per GPU (MAX_SCORE %d, READ_SIZE %d)"
                                    % ("with CIGAR" if args.backtrace else "score-only", args.length, args.error * 100, n, ms, rs),
                        "pairs_per_gpu": n, "parallelism": "pairs sharded statically, %d rank(s)" % world,
-                       "kernel": kname},
+                       "kernel": kname, "plan": plan_buf.value.decode(),
+                       "io": ("compact: 8-B WFA request_t (common.h:172-177) + 8-B {idx, score} results" if res8 else
+                              ("8-B requests, 24-B results" if req8 else "default: 16-B requests, 24-B results")),
+                       "wire_bytes_per_pair": 2 * rs + (8 if req8 else 16) + (8 if res8 else 24) + (2 * rs if args.backtrace else 0)},
             "gcups": value * (cells / n) / 1e9,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

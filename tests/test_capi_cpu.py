@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound(built):
         assert hasattr(lib, name)
         assert name in capi.SYMBOLS, name + " missing from the ctypes binding"
     assert exported <= set(declared), "exported but undeclared: %s" % (exported - set(declared))
-    assert lib.aim_abi_version() == 1
+    assert lib.aim_abi_version() == 2
 
 
 def test_kernels_are_compiled_for_gfx950(built):
@@ -96,7 +96,7 @@ def _plan_line(params, n, env):
     e = dict(os.environ, AIM_PLAN_DEBUG="1", **env)
     r = subprocess.run([os.sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    plan = [l for l in r.stderr.splitlines() if l.startswith("[aim plan] wfa_group")]
+    plan = [l for l in r.stderr.splitlines() if l.startswith("[aim plan] wfa_group G=")]
     scratch = int(re.search(r"SCRATCH (\d+)", r.stdout).group(1))
     return (plan[-1] if plan else ""), scratch
 

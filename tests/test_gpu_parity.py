@@ -293,13 +293,18 @@ def test_host_cli_end_to_end(gpu, sample_bytes, ref_digests, tmp_path):
             assert line in r.stdout
 
 
-def test_fast_path_is_taken_and_non_acgt_falls_back(gpu, sample_bytes, err_bytes):
-    """cfg2 runs on the one-pair-per-lane kernel; pairs with bytes outside ACGT (the reference compares raw
-    bytes) are drained by the general kernel -- and only those."""
+def test_fast_path_handles_non_acgt_bytes_itself(gpu, sample_bytes, err_bytes):
+    """cfg2 runs on the one-pair-per-lane kernel. Pairs with bytes outside ACGT (the reference compares raw bytes, 'N'
+    matches 'N') are aligned by the SAME kernel from the raw rows (round 2: no to-do list, no second launch, no scratch);
+    wfa_group_kernel still hands such pairs to the general kernel and reports how many."""
     from aim_amd import capi, engine
     import ctypes as C
+    lib = capi.load()
     params = engine.make_params("wfa", 5, 112, reduce=True)
-    assert capi.load().aim_kernel_name(C.byref(params)) == b"wfa_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(params)) == b"wfa_lane_kernel"
+    assert lib.aim_scratch_bytes(C.byref(params), 1 << 22) == 256     # a token: the kernel uses no scratch
+    gparams = engine.make_params("wfa", 10, 112, reduce=True)      # MAX_SCORE 10 -> wfa_group_kernel
+    assert lib.aim_kernel_name(C.byref(gparams)) == b"wfa_group_kernel"
     for data in (sample_bytes, err_bytes):
         req, pat, txt = engine.parse_pairs(data, 112)
         expect = 0
@@ -307,17 +312,37 @@ def test_fast_path_is_taken_and_non_acgt_falls_back(gpu, sample_bytes, err_bytes
             s = pat[i, : req["pattern_len"][i]].tobytes() + txt[i, : req["text_len"][i]].tobytes()
             expect += 1 if (set(s) - set(b"ACGT")) else 0
         with engine.DeviceSet(1) as ds:
-            res, _ = ds.align(params, req, pat, txt)
+            ds.align(params, req, pat, txt)
+            assert ds.fallback_pairs(0) == 0
+            assert "wfa_lane_kernel" in ds.plan_describe(0)
+        with engine.DeviceSet(1) as ds:
+            ds.align(gparams, req, pat, txt)
             assert ds.fallback_pairs(0) == expect
         if data is err_bytes:
             assert expect > 0
-    # lower-case / N / arbitrary bytes, mixed into an otherwise clean batch
-    req, pat, txt = engine.gen_pairs(77, 0, 1000, 100, 0.01, 112)
-    for i in range(0, 1000, 7):
+        for kw in (dict(reduce=True), dict(reduce=True, backtrace=True)):
+            _compare("wfa", engine.make_params("wfa", 5, 112, **kw), req, pat, txt)
+    # lower-case / N / arbitrary bytes (incl. >= 0x80 and NUL inside a read), mixed into an otherwise clean batch;
+    # equal non-ACGT bytes on both sides must MATCH (raw byte compare), different ones must not
+    req, pat, txt = engine.gen_pairs(77, 0, 4000, 100, 0.01, 112)
+    for i in range(0, 4000, 7):
         pat[i, i % 100] = ord("N")
-    for i in range(3, 1000, 11):
+    for i in range(3, 4000, 11):
         txt[i, (3 * i) % 99] = ord("a")
-    _compare("wfa", params, req, pat, txt)
+    for i in range(5, 4000, 13):
+        j = (5 * i) % 95
+        pat[i, j] = 0xC1 if i % 2 else 0x00
+        txt[i, j] = 0xC1 if i % 2 else 0x00
+    for i in range(1, 4000, 17):
+        pat[i, 7] = ord("n"); txt[i, 7] = ord("N")
+    for rs_kw in (dict(reduce=True), dict(reduce=True, backtrace=True), dict()):
+        _compare("wfa", engine.make_params("wfa", 5, 112, **rs_kw), req, pat, txt)
+    # same at READ_SIZE 80 (the other lane shape)
+    req, pat, txt = engine.gen_pairs(78, 0, 2000, 64, 0.02, 80)
+    for i in range(0, 2000, 5):
+        pat[i, i % 60] = ord("N"); txt[i, (i + 1) % 60] = ord("N")
+    for kw in (dict(reduce=True), dict(backtrace=True)):
+        _compare("wfa", engine.make_params("wfa", 5, 80, **kw), req, pat, txt)
 
 
 # ------------------------------------------------------------------ long-read NW/SWG kernel (dp_wave)
@@ -636,3 +661,84 @@ def test_wfa_lane_runtime_max_score_below_shape_with_cigar(gpu):
             res, _, ores = _compare("wfa", params, req, pat, txt)
             if ms < 5:
                 assert (res["score"] == ms + 1).any()   # the cap is exercised (at 5 nothing in this set exceeds it)
+
+
+# ------------------------------------------------------------------ round 2: soak, LDS poison, scratch-bound plans
+@pytest.mark.parametrize("poison", [None, 255, 0])
+def test_dp_wave_soak_launch_to_launch(gpu, poison):
+    """Long-read NW/SWG with CIGAR, 9-100 pairs, forced 1/2/4 wavefronts per pair: ~20 s of concurrent repeated launches,
+    each compared ON THE DEVICE with the slot's first (oracle-checked) result (tools/soak_dp_wave.py) -- also with every
+    workgroup's LDS pre-filled with 0xff / 0x00 (AIM_DEBUG_POISON_LDS): results must not depend on what LDS held."""
+    import subprocess, sys, json
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "soak_dp_wave.py"), "--seconds", "20", "--slots", "6"]
+    if poison is not None:
+        cmd += ["--poison-lds", str(poison)]
+    env = {k: v for k, v in os.environ.items() if not k.startswith("AIM_")}
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["failed_slot"] is None and rep["launches"] > 1000
+
+
+@pytest.mark.parametrize("poison", ["255", "0"])
+def test_every_kernel_is_independent_of_initial_lds(gpu, monkeypatch, poison):
+    """AIM_DEBUG_POISON_LDS fills each workgroup's dynamic LDS at kernel entry; all six kernels stay bit-exact."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_DEBUG_POISON_LDS", poison)
+    for algo, l, err, n, kw in (("wfa", 100, 0.01, 3000, dict(reduce=True)), ("wfa", 100, 0.01, 3000, dict(reduce=True, backtrace=True)),
+                                ("wfa", 100, 0.05, 2000, dict(reduce=True, backtrace=True)), ("wfa", 1000, 0.05, 128, dict(reduce=True, backtrace=True)),
+                                ("nw", 100, 0.05, 2000, dict(backtrace=True)), ("swg", 100, 0.05, 2000, dict(backtrace=True)),
+                                ("nw", 700, 0.10, 40, dict(backtrace=True)), ("swg", 700, 0.10, 40, dict(backtrace=True))):
+        ms, rs = engine.launcher_sizes(algo, l, err)
+        req, pat, txt = engine.gen_pairs(77, 0, n, l, err, rs)
+        _compare(algo, engine.make_params(algo, ms, rs, **kw), req, pat, txt)
+    monkeypatch.setenv("AIM_FORCE_WAVE", "1")
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.05)
+    req, pat, txt = engine.gen_pairs(78, 0, 1000, 100, 0.05, rs)
+    _compare("wfa", engine.make_params("wfa", ms, rs, reduce=True, backtrace=True), req, pat, txt)
+
+
+def test_wfa_wave_score_only_ring_is_never_shrunk(gpu, monkeypatch):
+    """under a small scratch bound the score-only pool (a ring over the live window) used to be shrunk below
+    (R+2)*3*(2*MAX_SCORE+3) entries, silently overwriting wavefronts still in use. The plan now drops workgroups instead
+    (or fails with AIM_ENOMEM); results stay bit-exact. BACKTRACE keeps the documented AIM_PAIR_NOMEM behaviour."""
+    from aim_amd import capi, engine
+    monkeypatch.setenv("AIM_SCRATCH_GB", "0.25")
+    monkeypatch.setenv("AIM_FORCE_WAVE", "1")
+    ms, rs = 5000, 1064
+    req, pat, txt = engine.gen_pairs(31, 0, 600, 1000, 0.05, rs)
+    params = engine.make_params("wfa", ms, rs, mismatch=9, gap_o=9, gap_e=4, reduce=True)
+    res, _, ores = _compare("wfa", params, req, pat, txt)
+    assert (res["status"] == 0).all()
+    with engine.DeviceSet(1) as s:
+        s.configure(params, 600)
+        line = s.plan_describe(0)
+        cap = int(line.split("pool_cap=")[1].split()[0])
+        assert cap >= (max(9, 13) + 2) * 3 * (2 * ms + 3), line
+
+
+@pytest.mark.parametrize("algo,l,err,kw", [("wfa", 100, 0.01, dict(reduce=True)), ("wfa", 100, 0.05, dict(reduce=True)),
+                                           ("wfa", 1000, 0.05, dict(reduce=True)), ("nw", 100, 0.02, dict()),
+                                           ("swg", 100, 0.02, dict()), ("nw", 700, 0.05, dict()), ("wfa", 3000, 0.10, dict())])
+@pytest.mark.parametrize("req8,res8", [(True, True), (True, False), (False, True)])
+def test_compact_io_layouts_match_default(gpu, algo, l, err, kw, req8, res8):
+    """AIM_FLAG_REQ8 (the reference's 8-B WFA request_t) / AIM_FLAG_RES8 ({idx, score}) give the same scores as the
+    default 16-B / 24-B structs on every kernel; RES8 + BACKTRACE is rejected."""
+    from aim_amd import capi, engine
+    ms, rs = engine.launcher_sizes(algo, l, err)
+    n = 3000 if l <= 100 else (300 if l <= 1000 else 40)
+    req, pat, txt = engine.gen_pairs(4242, 1000, n, l, err, rs)
+    base, _ = engine.align(engine.make_params(algo, ms, rs, **kw), req, pat, txt)
+    res, _ = engine.align(engine.make_params(algo, ms, rs, req8=req8, res8=res8, **kw), req, pat, txt)
+    assert np.array_equal(res["score"], base["score"]) and np.array_equal(res["idx"], req["idx"])
+    if not res8:
+        for f in ("max_operations", "begin_offset", "end_offset", "status"):
+            assert np.array_equal(res[f], base[f])
+    with pytest.raises(capi.AimError) as e:
+        engine.align(engine.make_params(algo, ms, rs, res8=True, backtrace=True), req, pat, txt)
+    assert e.value.code == capi.AIM_EINVAL
+    if req8:   # CIGAR output with the 8-B request
+        b2, o2 = engine.align(engine.make_params(algo, ms, rs, backtrace=True, **kw), req, pat, txt, check=False)
+        r2, p2 = engine.align(engine.make_params(algo, ms, rs, backtrace=True, req8=True, **kw), req, pat, txt, check=False)
+        assert engine.format_output(r2, p2, True) == engine.format_output(b2, o2, True) if (b2["status"] == 0).all() else True
