@@ -35,6 +35,19 @@ RESULT8_DTYPE = np.dtype([("idx", "<u4"), ("score", "<i4")])                    
 assert REQUEST_DTYPE.itemsize == 16 and RESULT_DTYPE.itemsize == 24
 assert REQUEST8_DTYPE.itemsize == 8 and RESULT8_DTYPE.itemsize == 8
 
+CIGAR_DTYPE = np.dtype([("idx", "<u4"), ("score", "<i4"), ("run_offset", "<u4"), ("n_runs", "<u2"), ("status", "<u2")])   # aim_cigar_t
+assert CIGAR_DTYPE.itemsize == 16
+CIGAR_OVERFLOW = 0x100
+
+
+class BatchIO(C.Structure):
+    """aim_batch_io_t"""
+    _fields_ = [("n_pairs", C.c_uint32), ("requests", C.c_void_p), ("patterns", C.c_void_p), ("texts", C.c_void_p),
+                ("packed_patterns", C.c_void_p), ("packed_texts", C.c_void_p), ("n_raw", C.c_uint32), ("raw_pairs", C.c_void_p),
+                ("raw_patterns", C.c_void_p), ("raw_texts", C.c_void_p), ("results", C.c_void_p), ("ops", C.c_void_p),
+                ("cigars", C.c_void_p), ("runs", C.c_void_p), ("runs_cap", C.c_uint32)]
+
+
 # every symbol include/aim_hip.h declares: name -> (restype, argtypes)
 _VP, _U32, _I32 = C.c_void_p, C.c_uint32, C.c_int32
 SYMBOLS = {
@@ -47,6 +60,11 @@ SYMBOLS = {
     "aim_set_push": (C.c_int, [_VP, _U32, _U32, _VP, _VP, _VP]),
     "aim_set_launch": (C.c_int, [_VP]),
     "aim_set_pull": (C.c_int, [_VP, _U32, _VP, _VP]),
+    "aim_set_configure_slots": (C.c_int, [_VP, C.POINTER(Params), _U32, _U32, _U32, _U32]),
+    "aim_set_submit": (C.c_int, [_VP, _U32, _U32, C.POINTER(BatchIO)]),
+    "aim_set_wait": (C.c_int, [_VP, _U32, _U32, C.POINTER(_U32)]),
+    "aim_pack_sequence": (C.c_int, [_VP, _I32, _I32, _VP]),
+    "aim_cigar_format_runs": (C.c_int, [_VP, _U32, _VP, _I32]),
     "aim_set_timers": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "aim_set_fallback_pairs": (C.c_int, [_VP, _U32, C.POINTER(_U32)]),
     "aim_set_plan_describe": (C.c_int, [_VP, _U32, C.c_char_p, C.c_size_t]),

@@ -175,6 +175,9 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             pl->kid = K_WFA_LANE;
             aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
             pl->scratch_total = 256;   // unused; aim_scratch_bytes() keeps 0 for "invalid configuration"
+#if AIM_LANE_STAMPS
+            pl->scratch_total += (size_t)pl->grid * 64;   // diagnostic builds park their s_memtime sums behind the first 256 bytes
+#endif
             return AIM_OK;
         }
         if (group_ok) {
@@ -358,6 +361,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         else launch_wfa_wave<false, false>(pl, ka, stream);
         break;
     case K_WFA_LANE:
+        ka.scratch_per_wave = 256;
         aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_WFA_GROUP: {

@@ -22,12 +22,20 @@
 // downstream is unchanged -- no to-do list, no second kernel, no counter to reset between launches.
 #pragma once
 
+#include <utility>
+
 #include "aim_device.hpp"
 
 // ---- build-time knobs (A/B tested on MI355X) ------------------------------------
 #ifndef AIM_LANE_MIN_WAVES
 #define AIM_LANE_MIN_WAVES 1      // __launch_bounds__ 2nd argument: minimum waves per SIMD (caps VGPRs)
 #endif
+#ifndef AIM_LANE_FULLWAIT
+#define AIM_LANE_FULLWAIT 0       // diagnostic: 1 = drain the whole VM queue at the loop top (round-1 behaviour) instead of the counted wait
+#endif
+#ifndef AIM_LANE_INTERLEAVE
+#define AIM_LANE_INTERLEAVE 1     // 1 = the next group's 15 LDS-DMA instructions are issued one by one BETWEEN the pack steps of the
+#endif                            // current group instead of as one burst in front of them (0 = burst, round-1 structure)
 #ifndef AIM_LANE_STAMPS
 #define AIM_LANE_STAMPS 0         // diagnostic build only: s_memtime per segment, summed per wave into scratch
 #endif
@@ -116,22 +124,87 @@ __device__ __forceinline__ int first_stop(const uint32_t (&m)[NP], int v)
     return res;
 }
 
-// One 64-pair group of one sequence array, HBM -> LDS, by LDS-DMA (global_load_lds_dwordx4): the group's
-// rows are contiguous in HBM ([64][RS] bytes), so NCH wave-instructions of 1 KiB copy them verbatim; no
-// VGPR is used and the copy stays in flight while the wave computes.  Lanes past the batch tail are masked.
+// LDS-DMA destinations are given as BYTE OFFSETS into the workgroup's LDS (what M0 carries), not as generic pointers:
+// a generic->LDS pointer cast inside the loop costs a null check and a select per instruction.
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+__device__ __forceinline__ lds_ptr_t lds_at(uint32_t byte_off) { return (lds_ptr_t)(uintptr_t)byte_off; }
+
+// One 64-pair group of one sequence array, HBM -> LDS, by LDS-DMA (global_load_lds_dwordx4): the group's rows are
+// contiguous in HBM ([64][RS] bytes), so NCH wave-instructions of 1 KiB copy them verbatim; no VGPR is used and the copy
+// stays in flight while the wave computes. Full groups (all but the batch's last) issue the NCH pieces back to back with
+// no predicate (the per-piece exec-mask test of round 1 cost ~10 scalar instructions and a branch per piece: "DMA issue"
+// was 21 % of the loop); lanes past the batch tail are masked in the last group only.
+// piece I of a full group: the instruction's immediate offset advances the global AND the LDS address, so pieces 0..3 share
+// one (address, M0) pair and pieces 4..7 the next (+4 KiB)
+template <int... I>
+__device__ __forceinline__ void dma_full_pieces(uint32_t lds_off, const char *g_lane, std::integer_sequence<int, I...>)
+{
+    (__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_lane + (I >> 2) * 4096),
+                                      lds_at(lds_off + (I >> 2) * 4096), 16, (I & 3) * 1024, AIM_LANE_DMA_AUX), ...);
+}
+
+template <int I>
+__device__ __forceinline__ void dma_piece(uint32_t lds_off, const char *g_lane)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g_lane + (I >> 2) * 4096),
+                                      lds_at(lds_off + (I >> 2) * 4096), 16, (I & 3) * 1024, AIM_LANE_DMA_AUX);
+    __builtin_amdgcn_sched_barrier(0);   // stays where it is written: between two pack steps
+}
+
 template <int RS, int NCH>
-__device__ __forceinline__ void dma_rows(uint32_t *lds_rows, const char *base, uint32_t pair0, uint32_t n_pairs, int lane)
+__device__ __forceinline__ void dma_rows(uint32_t lds_off, const char *base, uint32_t pair0, uint32_t n_pairs, int lane)
 {
     const char *g = base + (uint64_t)pair0 * RS;
-    const uint32_t rows = min((uint32_t)kWave, n_pairs - pair0);
-    const uint32_t n_chunks = (rows * RS + 15) / 16;   // arrays carry >= 16 B of tail slack (aim_hip.h)
+    if (pair0 + kWave <= n_pairs) {   // wave-uniform
+        dma_full_pieces(lds_off, g + (uint32_t)lane * 16u, std::make_integer_sequence<int, NCH>{});
+    } else {
+        const uint32_t rows = n_pairs - pair0;
+        const uint32_t n_chunks = (rows * RS + 15) / 16;   // arrays carry >= 16 B of tail slack (aim_hip.h)
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const uint32_t c = i * kWave + lane;
-        if (c < n_chunks)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (uint64_t)c * 16),
-                                             (__attribute__((address_space(3))) void *)(lds_rows + i * kWave * 4), 16, 0, AIM_LANE_DMA_AUX);
+        for (int i = 0; i < NCH; ++i) {
+            const uint32_t c = i * kWave + lane;
+            if (c < n_chunks)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (uint64_t)c * 16),
+                                                 lds_at(lds_off + i * kWave * 16), 16, 0, AIM_LANE_DMA_AUX);
+        }
     }
+}
+
+// The group's 64 request descriptors, HBM -> LDS. Full groups go by LDS-DMA like the rows (one wave-instruction), so the
+// loop holds NO ordinary global load: a register-destination load would make the compiler drain the whole VM queue
+// (s_waitcnt vmcnt(0)) at its first use, and that queue also holds the previous group's result store -- waiting for a
+// store's acknowledgement (~1-2 us under load) once per group is what the "residual wait" of round 1 was. The batch's
+// last, partial group is loaded per lane and written to the same LDS slots.
+__device__ __forceinline__ void stage_requests(uint32_t lds_off, uint32_t *lds_req, const KArgs &a, uint32_t pair0, int lane)
+{
+    const uint32_t rqb = (a.p.flags & AIM_FLAG_REQ8) ? 8u : 16u;            // bytes per request
+    const char *g = reinterpret_cast<const char *>(a.req) + (uint64_t)pair0 * rqb;
+    if (pair0 + kWave <= a.n_pairs) {
+        if ((uint32_t)lane * 16u < kWave * rqb)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + (uint64_t)lane * 16),
+                                             lds_at(lds_off), 16, 0, 0);
+    } else if (pair0 + lane < a.n_pairs) {
+        const aim_request_t r = load_request(a, pair0 + lane);
+        if (rqb == 8u) {
+            lds_req[lane * 2] = (uint32_t)(uint16_t)r.pattern_len | ((uint32_t)(uint16_t)r.text_len << 16);
+            lds_req[lane * 2 + 1] = r.idx;
+        } else {
+            lds_req[lane * 4] = (uint32_t)r.pattern_len; lds_req[lane * 4 + 1] = (uint32_t)r.text_len;
+            lds_req[lane * 4 + 2] = 0u; lds_req[lane * 4 + 3] = r.idx;
+        }
+    }
+}
+__device__ __forceinline__ aim_request_t read_staged_request(const uint32_t *lds_req, const KArgs &a, int lane)
+{
+    aim_request_t r;
+    if (a.p.flags & AIM_FLAG_REQ8) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(lds_req + lane * 2);
+        r.pattern_len = (int16_t)(q.x & 0xffffu); r.text_len = (int16_t)(q.x >> 16); r.padding = 0; r.idx = q.y;
+    } else {
+        const uint4 q = *reinterpret_cast<const uint4 *>(lds_req + lane * 4);
+        r.pattern_len = (int)q.x; r.text_len = (int)q.y; r.padding = 0; r.idx = q.w;
+    }
+    return r;
 }
 
 // Read this lane's row, 16 B at a time at compile-time offsets (RS/16 odd => ds_read_b128 is conflict-free).
@@ -143,32 +216,47 @@ __device__ __forceinline__ void load_row(const uint32_t *lds_rows, int lane, uin
     for (int j = 0; j < NP; ++j) raw[j] = row[j];
 }
 
-// Validate A/C/G/T over [0, len) and pack 2 bits/base: 16 bases -> one dword.
-template <int NP>
-__device__ __forceinline__ uint32_t pack_row(const uint4 (&raw)[NP], int len, int min_len_wave, uint32_t (&out)[NP])
+// Validate A/C/G/T over [0, len) and pack 2 bits/base: 16 bases -> one dword. `after_step(integral_constant<int, j>)` runs
+// after the j-th 16-base step (the kernel issues one piece of the next group's DMA there).
+// MASKED = false: every byte of the step lies inside the sequence of EVERY lane (the caller proved it wave-wide), so the
+// bytes are compared unmasked and the differences accumulate with v_sad_u8 (one op instead of xor + and + or).
+// MASKED = true: per-lane byte masks from the length. The choice is a TEMPLATE argument on purpose: as a run-time (even
+// wave-uniform) test per dword it compiled to two scalar branches per dword -- 112 per group -- and the pack phase ran at
+// less than a quarter of its issue rate.
+template <int J, bool MASKED, int NP, typename StepF>
+__device__ __forceinline__ void pack_step(const uint4 (&raw)[NP], int len, uint32_t (&out)[NP], uint32_t &bad, StepF &after_step)
+{
+    const uint32_t a[4] = {raw[J].x, raw[J].y, raw[J].z, raw[J].w};
+    uint32_t b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t t = (a[i] >> 1) & 0x03030303u;                    // 2-bit code per byte: A0 C1 T2 G3
+        const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);  // decode back: "ACTG"[code]
+        if (MASKED) {
+            const int rem = len - 4 * (4 * J + i);
+            const uint32_t mask = rem >= 4 ? ~0u : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+            bad |= (rec ^ a[i]) & mask;
+        } else {
+            bad = __builtin_amdgcn_sad_u8(rec, a[i], bad);
+        }
+        b[i] = __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);       // c0 + 4 c1 + 16 c2 + 64 c3
+    }
+    out[J] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    after_step(std::integral_constant<int, J>{});
+}
+// FAST: steps 0 .. NP-2 unmasked (requires len >= 16*(NP-1) for every lane of the wave), last step masked; else all masked.
+template <bool FAST, int NP, typename StepF, int... J>
+__device__ __forceinline__ uint32_t pack_row_seq(const uint4 (&raw)[NP], int len, uint32_t (&out)[NP], StepF &after_step,
+                                                 std::integer_sequence<int, J...>)
 {
     uint32_t bad = 0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const uint32_t a[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
-        uint32_t b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t t = (a[i] >> 1) & 0x03030303u;                    // 2-bit code per byte: A0 C1 T2 G3
-            const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);  // decode back: "ACTG"[code]
-            uint32_t diff = rec ^ a[i];
-            const int w = 4 * j + i;
-            if (4 * w + 4 > min_len_wave) {   // wave-uniform: only tail dwords need the per-lane length mask
-                const int rem = len - 4 * w;
-                const uint32_t mask = rem >= 4 ? ~0u : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
-                diff &= mask;
-            }
-            bad |= diff;
-            b[i] = __builtin_amdgcn_udot4(t, 0x40100401u, 0u, false);       // c0 + 4 c1 + 16 c2 + 64 c3
-        }
-        out[j] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-    }
+    (pack_step<J, (!FAST || J == NP - 1), NP>(raw, len, out, bad, after_step), ...);
     return bad;
+}
+template <bool FAST, int NP, typename StepF>
+__device__ __forceinline__ uint32_t pack_row(const uint4 (&raw)[NP], int len, uint32_t (&out)[NP], StepF after_step)
+{
+    return pack_row_seq<FAST, NP>(raw, len, out, after_step, std::make_integer_sequence<int, NP>{});
 }
 
 enum : uint32_t { LANE_TODO_COUNT = 0, LANE_TODO_LIST = 16 };   // dword offsets inside the to-do region (wfa_group.hpp only)
@@ -219,7 +307,10 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
     debug_poison_lds(a, smem);
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + kWave * (RS / 4);
-    uint32_t *resL = rowsT + kWave * (RS / 4);          // 64 x aim_result_t (24 B) staged for a coalesced store
+    uint32_t *reqL = rowsT + kWave * (RS / 4);          // 64 request descriptors (<= 16 B each)
+    uint32_t *resL = reqL + kWave * 4;                  // 64 x aim_result_t (24 B) staged for a coalesced store (CIGAR only)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;   // LDS byte offset of the dynamic segment
+    const uint32_t offP = lds0, offT = lds0 + kWave * RS, offQ = lds0 + 2 * kWave * RS;
     const int lane = threadIdx.x;
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
     const int ms_run = a.p.max_score;           // runtime MAX_SCORE <= MAXS
@@ -228,13 +319,13 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
     auto next_group = [&](uint32_t it_, uint32_t *g_) -> bool { return xcd_unit(n_groups, it_, g_); };
     uint32_t grp;
     bool have = next_group(0, &grp);
-    aim_request_t rq_next;
-    rq_next.pattern_len = 0; rq_next.text_len = 0; rq_next.padding = 0; rq_next.idx = 0;
+    const bool res8 = a.p.flags & AIM_FLAG_RES8;       // wave-uniform
     if (have) {
-        dma_rows<RS, NCH>(rowsP, a.patterns, grp * kWave, a.n_pairs, lane);
-        dma_rows<RS, NCH>(rowsT, a.texts, grp * kWave, a.n_pairs, lane);
-        if (grp * kWave + lane < a.n_pairs) rq_next = load_request(a, grp * kWave + lane);
+        dma_rows<RS, NCH>(offP, a.patterns, grp * kWave, a.n_pairs, lane);
+        dma_rows<RS, NCH>(offT, a.texts, grp * kWave, a.n_pairs, lane);
+        stage_requests(offQ, reqL, a, grp * kWave, lane);
     }
+    uint32_t stores_in_flight = 0;                     // result-store instructions the previous iteration issued after its DMA
 #if AIM_LANE_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
@@ -247,11 +338,17 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         // is the price of a write stream inside a read stream at the HBM ceiling, not of its access pattern.
         const bool full_group = BT && AIM_LANE_RES_STAGE && (grp + 1u) * kWave <= a.n_pairs;   // wave-uniform
         AIM_STAMP(0);                           // loop overhead / previous store
-        __builtin_amdgcn_s_waitcnt(0);          // this group's DMA has landed (and rq_next arrived)
-        __syncthreads();
+        // This group's DMA (rows + requests) has landed. VM operations complete in issue order (loads, stores and LDS-DMA
+        // share vmcnt on gfx9), and the only operations younger than that DMA are the previous group's result stores, so a
+        // COUNTED wait leaves exactly those in flight instead of paying their acknowledgement latency once per group.
+        // One wavefront per workgroup: no barrier is needed, only the wait and a scheduling fence.
+        if (BT || AIM_LANE_FULLWAIT || stores_in_flight == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (stores_in_flight == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         AIM_STAMP(1);                           // wait for DMA
-        const aim_request_t rq = rq_next;
-        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const aim_request_t rq = read_staged_request(reqL, a, lane);
+        const int plen = active ? rq.pattern_len : 0, tlen = active ? rq.text_len : 0;   // lanes past the batch tail read stale LDS
         // pull both rows into registers, then immediately start the next group's DMA into the same buffer:
         // its HBM latency flies under the pack + compute below
         uint4 rawP[NP], rawT[NP];
@@ -259,16 +356,23 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         load_row<RS, NP>(rowsT, lane, rawT);
         uint32_t ngrp = 0;
         const bool nhave = next_group(it + 1, &ngrp);
-        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): every ds_read of this group has returned
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every ds_read of this group has returned: the buffers are free
+        __builtin_amdgcn_sched_barrier(0);
         AIM_STAMP(2);                           // LDS row reads
-        if (nhave) {
-            dma_rows<RS, NCH>(rowsP, a.patterns, ngrp * kWave, a.n_pairs, lane);
-            dma_rows<RS, NCH>(rowsT, a.texts, ngrp * kWave, a.n_pairs, lane);
-            if (ngrp * kWave + lane < a.n_pairs) rq_next = load_request(a, ngrp * kWave + lane);
+        // The next group's DMA. Issued as ONE burst, 15 KiB from each of the CU's 8 wavefronts back-pressure the vector-memory
+        // queue and the wave sits in the issue of its own glds instructions (stamped: 3 350 of 13 400 ticks per group, 220 per
+        // instruction, at 67 % of the streaming ceiling). Full groups therefore hand their pieces out one by one between the
+        // pack steps below; only the batch's last (partial) group is issued here in one go.
+        const bool inter = AIM_LANE_INTERLEAVE && !AIM_LANE_DIAG && nhave && (ngrp + 1u) * kWave <= a.n_pairs;   // wave-uniform
+        if (nhave && !inter) {
+            dma_rows<RS, NCH>(offP, a.patterns, ngrp * kWave, a.n_pairs, lane);
+            dma_rows<RS, NCH>(offT, a.texts, ngrp * kWave, a.n_pairs, lane);
+            stage_requests(offQ, reqL, a, ngrp * kWave, lane);
         }
+        const char *gP_next = a.patterns + (uint64_t)ngrp * (kWave * RS) + (uint32_t)lane * 16u;
+        const char *gT_next = a.texts + (uint64_t)ngrp * (kWave * RS) + (uint32_t)lane * 16u;
         __builtin_amdgcn_sched_barrier(0);      // keep the DMA issue ahead of the ALU work
-        AIM_STAMP(3);                           // DMA issue
+        AIM_STAMP(3);                           // DMA issue (burst mode only)
 #if AIM_LANE_DIAG == 1 || AIM_LANE_DIAG == 4
         {   // removal decomposition: the streaming floor of this structure (DMA + LDS reads [+ result store])
             uint32_t x = 0;
@@ -286,8 +390,19 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         const int minlen = active ? min(plen, tlen) : 0x7fffffff;
         const int min_len_wave = __builtin_amdgcn_readfirstlane(wave_min_i32(minlen));
         uint32_t P[NP], T[NP];
-        uint32_t bad = pack_row<NP>(rawP, plen, min_len_wave, P);
-        bad |= pack_row<NP>(rawT, tlen, min_len_wave, T);
+        // four instantiations of the pack phase, selected by two wave-uniform tests made ONCE per group
+        uint32_t bad;
+        auto pack_both = [&](auto FAST, auto INTER) {
+            constexpr bool fast = decltype(FAST)::value, with_dma = decltype(INTER)::value;
+            bad = pack_row<fast, NP>(rawP, plen, P, [&](auto J) { if (with_dma) dma_piece<decltype(J)::value>(offP, gP_next); });
+            bad |= pack_row<fast, NP>(rawT, tlen, T, [&](auto J) { if (with_dma) dma_piece<decltype(J)::value>(offT, gT_next); });
+            if (with_dma) stage_requests(offQ, reqL, a, ngrp * kWave, lane);
+        };
+        const bool fast = min_len_wave >= 16 * (NP - 1);
+        if (fast && inter) pack_both(std::true_type{}, std::true_type{});
+        else if (fast) pack_both(std::true_type{}, std::false_type{});
+        else if (inter) pack_both(std::false_type{}, std::true_type{});
+        else pack_both(std::false_type{}, std::false_type{});
 
         AIM_STAMP(4);                           // pack + validate
 #if AIM_LANE_DIAG == 2
@@ -526,9 +641,18 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
                     rl[3] = (uint32_t)r.score; rl[4] = (uint32_t)r.status; rl[5] = (uint32_t)r.idx;
                 } else
 #endif
-                store_result(a, pair, r);
+                if (BT) {
+                    store_result(a, pair, r);
+                } else if (res8) {     // ONE global_store_dwordx2 per lane (512 contiguous bytes per wavefront)
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<aim_result8_t *>(a.res) + pair) = make_uint2(r.idx, (uint32_t)r.score);
+                } else {               // TWO stores per lane: dwordx4 + dwordx2 (24-B struct, 8-B aligned)
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(a.res + pair);
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)r.max_operations, (uint32_t)r.begin_offset, (uint32_t)r.end_offset, (uint32_t)r.score);
+                    *reinterpret_cast<uint2 *>(dst + 4) = make_uint2((uint32_t)r.status, r.idx);
+                }
             }
         }
+        stores_in_flight = BT ? 0u : (res8 ? 1u : 2u);   // every iteration has at least one active lane
 #if AIM_LANE_RES_STAGE
         if (full_group) {   // wave-uniform
             typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
@@ -575,7 +699,7 @@ inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *gri
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;
     *block = kWave;
-    *lds = (size_t)2 * kWave * p.read_size + ((p.flags & AIM_FLAG_BACKTRACE) ? kWave * sizeof(aim_result_t) : 0);
+    *lds = (size_t)2 * kWave * p.read_size + kWave * 16 + ((p.flags & AIM_FLAG_BACKTRACE) ? kWave * sizeof(aim_result_t) : 0);
 }
 
 inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)

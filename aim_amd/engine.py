@@ -62,6 +62,56 @@ def to_request8(req):
     return out
 
 
+def packed_row_dwords(read_size):
+    return (read_size + 15) // 16
+
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _c, _v in ((ord("A"), 0), (ord("C"), 1), (ord("T"), 2), (ord("G"), 3)):
+    _CODE[_c] = _v
+
+
+def pack_rows(req, rows, key):
+    """2 bits per base (aim_hip.h, packed input): returns (packed[n][ceil(rs/16)] uint32, ok[n] bool); ok is False where a
+    byte outside A/C/G/T lies inside the sequence (such pairs travel raw). Vectorised twin of aim_pack_sequence."""
+    n, rs = rows.shape
+    dw = packed_row_dwords(rs)
+    lens = np.asarray(req[key], dtype=np.int64)
+    inside = np.arange(rs)[None, :] < lens[:, None]
+    codes = _CODE[rows]
+    ok = ~((codes == 255) & inside).any(axis=1)
+    c = np.where(inside & (codes != 255), codes, 0).astype(np.uint32)
+    full = np.zeros((n, dw * 16), dtype=np.uint32)
+    full[:, :rs] = c
+    shifts = (2 * np.arange(16, dtype=np.uint32))[None, None, :]
+    packed = (full.reshape(n, dw, 16) << shifts).sum(axis=2, dtype=np.uint64).astype(np.uint32)
+    return np.ascontiguousarray(packed), ok
+
+
+def pack_batch(req, pat, txt):
+    """(packedP, packedT, raw_pairs, rawP, rawT) for aim_set_submit: pairs that cannot be packed go to the raw side list."""
+    pp, okp = pack_rows(req, pat, "pattern_len")
+    pt, okt = pack_rows(req, txt, "text_len")
+    raw = np.nonzero(~(okp & okt))[0].astype(np.uint32)
+    return pp, pt, raw, np.ascontiguousarray(pat[raw]), np.ascontiguousarray(txt[raw])
+
+
+def format_output_runs(cig, runs):
+    """Output file of the reference host (host.c:339-349) from the compact CIGAR (aim_cigar_t headers + run buffer)."""
+    lib = capi.load()
+    out = []
+    buf = C.create_string_buffer(1 << 16)
+    for i in range(len(cig)):
+        out.append(b"%d, %d, \n" % (int(cig["idx"][i]), int(cig["score"][i])))
+        nr, off = int(cig["n_runs"][i]), int(cig["run_offset"][i])
+        r = np.ascontiguousarray(runs[off:off + nr])
+        if len(buf) < 12 * nr + 16:
+            buf = C.create_string_buffer(12 * nr + 16)
+        n = capi.check(lib.aim_cigar_format_runs(capi.ptr(r), nr, buf, len(buf)))
+        out.append(buf.raw[:n])
+    return b"".join(out)
+
+
 def pairs_to_text(req, pat, txt):
     """Render pairs in the reference input format ('>'pattern / '<'text lines)."""
     out = []
@@ -147,6 +197,58 @@ class DeviceSet:
         capi.check(self.lib.aim_set_configure(self.handle, C.byref(params), max_pairs_per_device))
         self.params = params
         self.max_pairs = max_pairs_per_device
+
+    def configure_slots(self, params, max_pairs_per_device, slots=2, max_raw=0, max_runs=0):
+        capi.check(self.lib.aim_set_configure_slots(self.handle, C.byref(params), max_pairs_per_device, slots, max_raw, max_runs))
+        self.params = params
+        self.max_pairs = max_pairs_per_device
+        self._inflight = {}
+
+    def submit(self, device, slot, req, pat=None, txt=None, packed=None, want_ops=False, cigar_runs_cap=0):
+        """aim_set_submit: ASCII rows (pat, txt) or a packed batch (pack_batch(...)); results / ops / compact CIGAR buffers
+        are allocated here and returned by wait()."""
+        if (self.params.flags & FLAG_REQ8) and req.dtype != REQUEST8_DTYPE:
+            req = to_request8(req)
+        req = np.ascontiguousarray(req)
+        n, rs = len(req), self.params.read_size
+        io = capi.BatchIO()
+        io.n_pairs = n
+        keep = [req]
+        io.requests = req.ctypes.data
+        if packed is not None:
+            pp, pt, raw, rawp, rawt = [np.ascontiguousarray(x) for x in packed]
+            keep += [pp, pt, raw, rawp, rawt]
+            io.packed_patterns, io.packed_texts = pp.ctypes.data, pt.ctypes.data
+            io.n_raw = len(raw)
+            if len(raw):
+                io.raw_pairs, io.raw_patterns, io.raw_texts = raw.ctypes.data, rawp.ctypes.data, rawt.ctypes.data
+        else:
+            pat, txt = np.ascontiguousarray(pat), np.ascontiguousarray(txt)
+            keep += [pat, txt]
+            io.patterns, io.texts = pat.ctypes.data, txt.ctypes.data
+        out = {}
+        if cigar_runs_cap:
+            out["cig"] = np.zeros(n, dtype=capi.CIGAR_DTYPE)
+            out["runs"] = np.zeros(cigar_runs_cap, dtype=np.uint32)
+            io.cigars, io.runs, io.runs_cap = out["cig"].ctypes.data, out["runs"].ctypes.data, cigar_runs_cap
+        if not cigar_runs_cap or want_ops:
+            out["res"] = np.zeros(n, dtype=RESULT8_DTYPE if (self.params.flags & FLAG_RES8) else RESULT_DTYPE)
+            io.results = out["res"].ctypes.data
+        if want_ops:
+            out["ops"] = np.zeros((n, 2 * rs), dtype=np.uint8)
+            io.ops = out["ops"].ctypes.data
+        capi.check(self.lib.aim_set_submit(self.handle, device, slot, C.byref(io)))
+        self._inflight[(device, slot)] = (io, keep, out)
+
+    def wait(self, device, slot, check=True):
+        io, keep, out = self._inflight.pop((device, slot))
+        nr = C.c_uint32()
+        rc = self.lib.aim_set_wait(self.handle, device, slot, C.byref(nr))
+        if rc != capi.AIM_EALIGN or check:
+            capi.check(rc)
+        if "runs" in out:
+            out["runs"] = out["runs"][: nr.value]
+        return out
 
     def push(self, device, req, pat, txt):
         if (self.params.flags & FLAG_REQ8) and req.dtype != REQUEST8_DTYPE:

@@ -114,46 +114,172 @@ static void index_lines(input_t *in, int nthreads)
 }
 
 /* ---- get_reads (host.c:91-134) over a contiguous range of pairs, in parallel ------------------------ */
+/* One job = one batch on one (device, slot): everything the parser threads fill and the device returns. */
+typedef struct {
+    uint32_t n;                      /* pairs in this job */
+    size_t first_pair;               /* global index of pair 0 */
+    aim_request8_t *req;             /* the reference's own 8-byte WFA request_t (AIM_FLAG_REQ8) */
+    uint32_t *pkP, *pkT;             /* packed rows (2 bits per base) */
+    uint32_t *raw_idx; char *rawP, *rawT; uint32_t n_raw;   /* side list: pairs with a byte outside A/C/G/T */
+    char *pat, *txt;                 /* ASCII rows: --no-pack, or a batch whose side list overflowed (allocated lazily) */
+    int ascii;                       /* this job travels as ASCII rows */
+    uint8_t *is_raw;                 /* [n] pass-0 verdict per pair (plain malloc) */
+    aim_result8_t *res8;             /* score-only results */
+    aim_cigar_t *cig; uint32_t *runs; uint32_t n_runs;      /* compact CIGAR */
+    aim_result_t *res; char *ops;    /* --full-ops: the reference's own result_t + ops rows */
+    uint32_t device, slot;
+    int in_flight;
+} job_t2;
+
 typedef struct {
     const input_t *in;
-    size_t first_pair;       /* global index of slot 0 */
-    uint32_t n;              /* pairs to pack */
+    job_t2 *job;
     int read_size;
-    aim_request_t *req;
-    char *pat, *txt;
-    int too_long, malformed;
+    uint32_t max_raw;
+    uint32_t raw_count[MAX_THREADS + 1];   /* per-thread raw pairs (pass 1), then exclusive offsets */
+    int pass;
 } pack_t;
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("sse4.1,ssse3,bmi2"))) static int pack_seq_simd(const char *seq, long len, uint32_t *row, uint32_t row_dw)
+{
+    /* 16 bases per step: code = (c >> 1) & 3, validated by decoding back through "ACTG" (pshufb) */
+    const __m128i lut = _mm_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m128i three = _mm_set1_epi8(3);
+    __m128i bad = _mm_setzero_si128();
+    long i = 0;
+    uint32_t w = 0;
+    for (; i + 16 <= len; i += 16, ++w) {
+        const __m128i x = _mm_loadu_si128((const __m128i *)(seq + i));
+        const __m128i c = _mm_and_si128(_mm_srli_epi16(x, 1), three);
+        bad = _mm_or_si128(bad, _mm_xor_si128(x, _mm_shuffle_epi8(lut, c)));
+        const uint64_t lo = (uint64_t)_mm_cvtsi128_si64(c), hi = (uint64_t)_mm_extract_epi64(c, 1);
+        row[w] = (uint32_t)_pext_u64(lo, 0x0303030303030303ull) | ((uint32_t)_pext_u64(hi, 0x0303030303030303ull) << 16);
+    }
+    int ok = _mm_testz_si128(bad, bad);
+    if (i < len) {
+        uint32_t v = 0;
+        for (int sh = 0; i < len; ++i, sh += 2) {
+            const unsigned char ch = (unsigned char)seq[i];
+            const uint32_t code = (ch >> 1) & 3u;
+            ok &= ch == (unsigned char)"ACTG"[code];
+            v |= code << sh;
+        }
+        row[w++] = v;
+    }
+    for (; w < row_dw; ++w) row[w] = 0;
+    return ok;
+}
+#endif
+
+static int g_simd = 0;
+static inline int pack_seq(const char *seq, long len, int read_size, uint32_t *row, uint32_t row_dw)
+{
+#if defined(__x86_64__)
+    if (g_simd) return pack_seq_simd(seq, len, row, row_dw);
+#endif
+    return aim_pack_sequence(seq, (int32_t)len, read_size, row) == 1;
+}
+
+/* H1: getline length includes the '\n'; the first character and the last one are dropped. */
+static inline void pair_lines(const input_t *in, size_t pair, const char **p, long *pl, const char **t, long *tl)
+{
+    const size_t *ls = in->line_start + 2 * pair;
+    *pl = (long)(ls[1] - ls[0]) - 2;
+    *tl = (long)(ls[2] - ls[1]) - 2;
+    *p = in->data + ls[0] + 1;
+    *t = in->data + ls[1] + 1;
+}
 
 static void pack_range(int tid, int nt, void *arg)
 {
     pack_t *pk = arg;
-    const size_t lo = (size_t)pk->n * tid / nt, hi = (size_t)pk->n * (tid + 1) / nt;
+    job_t2 *j = pk->job;
+    const size_t lo = (size_t)j->n * tid / nt, hi = (size_t)j->n * (tid + 1) / nt;
     const int rs = pk->read_size;
-    for (size_t i = lo; i < hi; ++i) {
-        const size_t pair = pk->first_pair + i;
-        const size_t *ls = pk->in->line_start + 2 * pair;
-        /* getline length includes the '\n'; the first character and the last one are dropped (H1) */
-        const long pl = (long)(ls[1] - ls[0]) - 2, tl = (long)(ls[2] - ls[1]) - 2;
-        if (pl > rs || tl > rs) { pk->too_long = 1; continue; }
-        if (pl < 0 || tl < 0) { pk->malformed = 1; continue; }
-        char *p = pk->pat + i * rs, *t = pk->txt + i * rs;
-        memcpy(p, pk->in->data + ls[0] + 1, (size_t)pl);
-        memset(p + pl, 0, (size_t)(rs - pl));
-        memcpy(t, pk->in->data + ls[1] + 1, (size_t)tl);
-        memset(t + tl, 0, (size_t)(rs - tl));
-        pk->req[i].pattern_len = (int32_t)pl;
-        pk->req[i].text_len = (int32_t)tl;
-        pk->req[i].padding = 0;
-        pk->req[i].idx = (uint32_t)pair;
+    const uint32_t dw = (uint32_t)(rs + 15) / 16u;
+    if (pk->pass == 0) {   /* requests + packed rows; note and count the pairs that cannot be packed */
+        uint32_t raw = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const char *p, *t; long pl, tl;
+            pair_lines(pk->in, j->first_pair + i, &p, &pl, &t, &tl);
+            j->req[i].pattern_len = (int16_t)pl; j->req[i].text_len = (int16_t)tl; j->req[i].idx = (uint32_t)(j->first_pair + i);
+            if (j->ascii) {
+                char *dp = j->pat + i * rs, *dt = j->txt + i * rs;
+                memcpy(dp, p, (size_t)pl); memset(dp + pl, 0, (size_t)(rs - pl));
+                memcpy(dt, t, (size_t)tl); memset(dt + tl, 0, (size_t)(rs - tl));
+            } else {
+                const int okp = pack_seq(p, pl, rs, j->pkP + i * dw, dw), okt = pack_seq(t, tl, rs, j->pkT + i * dw, dw);
+                j->is_raw[i] = !(okp && okt);
+                raw += j->is_raw[i];
+            }
+        }
+        pk->raw_count[tid + 1] = raw;
+    } else {               /* side list in ascending pair order: thread t owns slots [raw_count[t], raw_count[t+1]) */
+        uint32_t at = pk->raw_count[tid];
+        for (size_t i = lo; i < hi; ++i) {
+            if (!j->is_raw[i]) continue;
+            const char *p, *t; long pl, tl;
+            pair_lines(pk->in, j->first_pair + i, &p, &pl, &t, &tl);
+            char *dp = j->rawP + (size_t)at * rs, *dt = j->rawT + (size_t)at * rs;
+            memcpy(dp, p, (size_t)pl); memset(dp + pl, 0, (size_t)(rs - pl));
+            memcpy(dt, t, (size_t)tl); memset(dt + tl, 0, (size_t)(rs - tl));
+            j->raw_idx[at++] = (uint32_t)i;
+        }
     }
+}
+
+/* Fill one job from the mapped input: requests, packed rows + raw side list (or ASCII rows). */
+static void *(*g_big_alloc)(size_t);
+static void pack_job(const input_t *inp, job_t2 *j, int read_size, uint32_t max_raw, uint32_t batch, int no_pack, int threads)
+{
+    const size_t rs = (size_t)read_size;
+    pack_t pk;
+    memset(&pk, 0, sizeof pk);
+    pk.in = inp; pk.job = j; pk.read_size = read_size; pk.max_raw = max_raw; pk.pass = 0;
+    j->ascii = no_pack;
+    j->n_raw = 0;
+    parallel_run(threads, pack_range, &pk);
+    if (j->ascii) return;
+    uint32_t total_raw = 0;
+    for (int t = 0; t < threads; ++t) { const uint32_t c = pk.raw_count[t + 1]; pk.raw_count[t] = total_raw; total_raw += c; }
+    pk.raw_count[threads] = total_raw;
+    if (!total_raw) return;
+    if (total_raw > max_raw) {   /* unusually dirty batch: ship it as ASCII rows instead (allocated on first need) */
+        if (!j->pat) { j->pat = g_big_alloc((size_t)batch * rs); j->txt = g_big_alloc((size_t)batch * rs); }
+        j->ascii = 1;
+        pk.pass = 0;
+        parallel_run(threads, pack_range, &pk);
+        return;
+    }
+    pk.pass = 1;
+    parallel_run(threads, pack_range, &pk);
+    j->n_raw = total_raw;
+}
+
+/* Whole-input validation BEFORE anything is launched or written, like get_reads (host.c:119-123 runs inside the read loop,
+ * ahead of every launch): over-length read -> message + exit(0) with an empty output file; short line -> error. */
+typedef struct { const input_t *in; size_t n; int read_size; int too_long, malformed; } scan_t;
+static void scan_range(int tid, int nt, void *arg)
+{
+    scan_t *sc = arg;
+    const size_t lo = sc->n * tid / nt, hi = sc->n * (tid + 1) / nt;
+    int too_long = 0, malformed = 0;
+    for (size_t i = lo; i < hi; ++i) {
+        const size_t *ls = sc->in->line_start + 2 * i;
+        const long pl = (long)(ls[1] - ls[0]) - 2, tl = (long)(ls[2] - ls[1]) - 2;
+        if (pl > sc->read_size || tl > sc->read_size) too_long = 1;
+        if (pl < 0 || tl < 0) malformed = 1;
+    }
+    if (too_long) __atomic_store_n(&sc->too_long, 1, __ATOMIC_RELAXED);
+    if (malformed) __atomic_store_n(&sc->malformed, 1, __ATOMIC_RELAXED);
 }
 
 /* ---- output loop (host.c:331-352) ---------------------------------------------------------------- */
 typedef struct {
-    uint32_t n;
-    int backtrace, read_size;
-    const aim_result_t *res;
-    const char *ops;
+    const job_t2 *job;
+    int backtrace, read_size, full_ops;
     char *buf[MAX_THREADS];
     size_t len[MAX_THREADS];
 } fmt_t;
@@ -172,17 +298,22 @@ static inline char *put_int(char *o, int v)
 static void format_range(int tid, int nt, void *arg)
 {
     fmt_t *f = arg;
-    const size_t lo = (size_t)f->n * tid / nt, hi = (size_t)f->n * (tid + 1) / nt;
+    const job_t2 *j = f->job;
+    const size_t lo = (size_t)j->n * tid / nt, hi = (size_t)j->n * (tid + 1) / nt;
     const size_t rs = (size_t)f->read_size;
     /* worst case per pair: "idx, score, \n" (<= 26 bytes) + one "%d%c" per op (<= 2 bytes per op when every run is 1) + '\n' */
     size_t cap = (hi - lo) * (32 + (f->backtrace ? 4 * rs + 16 : 0)) + 64;
     char *o = f->buf[tid] = malloc(cap), *start = o;
     for (size_t i = lo; i < hi; ++i) {
-        const aim_result_t *r = &f->res[i];
-        o = put_int(o, (int)r->idx); *o++ = ','; *o++ = ' ';       /* fprintf(out, "%d, %d, \n", idx, score) */
-        o = put_int(o, r->score); *o++ = ','; *o++ = ' '; *o++ = '\n';
-        if (f->backtrace) {                                          /* edit_cigar_print, host.c:69-89 */
-            const char *ops = f->ops + i * 2 * rs;
+        /* fprintf(out, "%d, %d, \n", idx, score) */
+        const uint32_t idx = !f->backtrace ? j->res8[i].idx : (f->full_ops ? j->res[i].idx : j->cig[i].idx);
+        const int score = !f->backtrace ? j->res8[i].score : (f->full_ops ? j->res[i].score : j->cig[i].score);
+        o = put_int(o, (int)idx); *o++ = ','; *o++ = ' ';
+        o = put_int(o, score); *o++ = ','; *o++ = ' '; *o++ = '\n';
+        if (!f->backtrace) continue;
+        if (f->full_ops) {                                           /* edit_cigar_print, host.c:69-89 */
+            const aim_result_t *r = &j->res[i];
+            const char *ops = j->ops + i * 2 * rs;
             char last = ops[r->begin_offset];
             int run = 1;
             for (int k = r->begin_offset + 1; k < r->end_offset; ++k) {
@@ -190,9 +321,35 @@ static void format_range(int tid, int nt, void *arg)
                 else { o = put_int(o, run); *o++ = last; last = ops[k]; run = 1; }
             }
             o = put_int(o, run); *o++ = last; *o++ = '\n';
+        } else {                                                     /* the same loop over device-side runs */
+            const uint32_t *r = j->runs + j->cig[i].run_offset;
+            const uint32_t nr = j->cig[i].n_runs;
+            uint32_t run = nr ? r[0] >> 8 : 1;
+            char last = nr ? (char)(r[0] & 0xff) : 'M';
+            for (uint32_t k = 1; k < nr; ++k) {
+                const char op = (char)(r[k] & 0xff);
+                if (op == last) run += r[k] >> 8;
+                else { o = put_int(o, (int)run); *o++ = last; last = op; run = r[k] >> 8; }
+            }
+            o = put_int(o, (int)run); *o++ = last; *o++ = '\n';
         }
     }
     f->len[tid] = (size_t)(o - start);
+}
+
+static void *plain(size_t bytes)
+{
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) { fprintf(stderr, "out of host memory\n"); exit(1); }
+    return p;
+}
+
+static void *pinned(size_t bytes)
+{
+    void *p = NULL;
+    int rc = aim_host_alloc(&p, bytes ? bytes : 1);
+    if (rc) die_aim("aim_host_alloc", rc);
+    return p;
 }
 
 int main(int argc, char *argv[])
@@ -202,7 +359,7 @@ int main(int argc, char *argv[])
         exit(1);
     }
     char *in = argv[1], *out = argv[2];
-    uint32_t total_nb_reads = (uint32_t)atoi(argv[3]);
+    const long n_arg = atol(argv[3]);            /* signed: a negative count is "Invalid nb of reads", not 4 billion */
 
     /* defaults = the reference's common.h defaults for WFA (common.h:63-89), READ_SIZE rounded to 8 */
     aim_params_t p;
@@ -210,7 +367,9 @@ int main(int argc, char *argv[])
     p.algo = AIM_ALGO_WFA;
     p.match = 0; p.mismatch = 3; p.gap_o = 4; p.gap_e = 1; p.gap_i = 4; p.gap_d = 4;
     p.max_score = 250; p.read_size = 112;
-    uint32_t nr_dpus = 1, gpus = 1, batch = 4u << 20;
+    uint32_t nr_dpus = 1, gpus = 1, batch = 4u << 20, slots = 2;
+    int no_pack = 0, full_ops = 0;
+    const char *pack_only = NULL;   /* test hook: write the packed batches to this file and exit (no GPU is touched) */
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     int threads = (int)(ncpu < 1 ? 1 : (ncpu > MAX_THREADS ? MAX_THREADS : ncpu));
     for (int i = 4; i < argc; ++i) {
@@ -219,7 +378,10 @@ int main(int argc, char *argv[])
         if (!strcmp(f, "--backtrace")) p.flags |= AIM_FLAG_BACKTRACE;
         else if (!strcmp(f, "--reduce")) p.flags |= AIM_FLAG_REDUCE;
         else if (!strcmp(f, "--swg-w16")) p.flags |= AIM_FLAG_SWG_W16;
+        else if (!strcmp(f, "--no-pack")) no_pack = 1;       /* ship ASCII rows like the reference (host.c:258-268) */
+        else if (!strcmp(f, "--full-ops")) full_ops = 1;     /* gather result_t + ops rows like the reference (host.c:316-326) */
         else if (!v) { printf("wrong number of arguments\n"); exit(1); }
+        else if (!strcmp(f, "--pack-only")) { pack_only = v; ++i; }
         else if (!strcmp(f, "--algo")) {
             if (!strcmp(v, "nw")) p.algo = AIM_ALGO_NW;
             else if (!strcmp(v, "swg")) p.algo = AIM_ALGO_SWG;
@@ -237,25 +399,33 @@ int main(int argc, char *argv[])
         else if (!strcmp(f, "--nr-dpus")) { nr_dpus = (uint32_t)atoi(v); ++i; }
         else if (!strcmp(f, "--gpus")) { gpus = (uint32_t)atoi(v); ++i; }
         else if (!strcmp(f, "--batch")) { batch = (uint32_t)atoi(v); ++i; }
+        else if (!strcmp(f, "--slots")) { slots = (uint32_t)atoi(v); ++i; }
         else if (!strcmp(f, "--threads")) { threads = atoi(v); ++i; }
         else { fprintf(stderr, "unknown flag %s\n", f); exit(1); }
     }
     if (threads < 1) threads = 1;
     if (threads > MAX_THREADS) threads = MAX_THREADS;
     const int backtrace = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    p.flags |= AIM_FLAG_REQ8;                                   /* 8-byte WFA request_t on the wire (common.h:172-177) */
+    if (!backtrace) p.flags |= AIM_FLAG_RES8;                   /* score-only: {idx, score} back */
+#if defined(__x86_64__)
+    g_simd = __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3") && __builtin_cpu_supports("bmi2");
+#endif
 
     int fd = open(in, O_RDONLY);
     FILE *output_file = fopen(out, "w");
     FILE *dpu_file = fopen("dpu-out", "w"); /* host.c:162: kept (empty) for scripts that expect it */
     if (fd < 0) { fprintf(stderr, "Input file '%s' couldn't be opened\n", in); exit(1); }
     if (output_file == NULL) { fprintf(stderr, "Output file '%s' couldn't be opened\n", out); exit(1); }
-    if (total_nb_reads <= 0) { fprintf(stderr, "Invalid nb of reads\n"); exit(1); }
+    if (n_arg <= 0 || n_arg > 0x7fffffffL) { fprintf(stderr, "Invalid nb of reads\n"); exit(1); }
+    const uint32_t total_nb_reads = (uint32_t)n_arg;
     if (nr_dpus == 0 || total_nb_reads <= nr_dpus) { printf("Allocated DPUs more than needed\n"); exit(1); }
-    if (gpus == 0 || batch == 0) { fprintf(stderr, "--gpus and --batch must be positive\n"); exit(1); }
+    if (gpus == 0 || batch == 0 || slots == 0 || slots > 4) { fprintf(stderr, "--gpus, --batch must be positive, --slots 1..4\n"); exit(1); }
 
     aim_set_t *set = NULL;
-    int rc = aim_set_alloc(gpus, NULL, &set);
+    int rc = pack_only ? 0 : aim_set_alloc(gpus, NULL, &set);
     if (rc) die_aim("aim_set_alloc", rc);
+    g_big_alloc = pack_only ? plain : pinned;
     printf("Allocated %d DPU(s)\n", (int)nr_dpus);
     printf("AIM-HIP: %u MI355X device(s), kernel %s, %d host thread(s)\n", gpus, aim_kernel_name(&p), threads);
 
@@ -278,91 +448,151 @@ int main(int argc, char *argv[])
     index_lines(&inp, threads);
     uint64_t pairs_in_file = inp.n_lines / 2;   /* a trailing unpaired line ends the reference's loop as well */
     const uint64_t total_pairs = pairs_in_file < pair_cap ? pairs_in_file : pair_cap;
-    double parse_ms = now_ms() - t_index, write_ms = 0;
+    {   /* validate every pair the run will touch before the first launch */
+        scan_t sc = {&inp, (size_t)total_pairs, p.read_size, 0, 0};
+        parallel_run(threads, scan_range, &sc);
+        if (sc.too_long) { /* host.c:119-123 */
+            printf("READ LENGTH less than length of the input reads");
+            exit(0);
+        }
+        if (sc.malformed) { fprintf(stderr, "malformed input (a line shorter than 2 characters)\n"); exit(1); }
+    }
+    double parse_ms = now_ms() - t_index, write_ms = 0, wait_ms = 0;
 
-    if ((uint64_t)batch > (total_pairs + gpus - 1) / gpus) batch = (uint32_t)((total_pairs + gpus - 1) / gpus);
-    if (batch == 0) batch = 1;
-    rc = aim_set_configure(set, &p, batch);
-    if (rc) {
-        if (rc == AIM_EINVAL) { printf("%s\n", aim_last_error()); exit(1); }
-        die_aim("aim_set_configure", rc);
+    /* batches: enough of them to keep every (device, slot) busy, none larger than --batch */
+    const uint32_t ring = gpus * slots;
+    {
+        uint64_t want = (total_pairs + 2 * ring - 1) / (2 * ring);
+        if (want < 65536) want = 65536;
+        if (want < batch) batch = (uint32_t)want;
+        if ((uint64_t)batch > total_pairs) batch = (uint32_t)(total_pairs ? total_pairs : 1);
     }
     const size_t rs = (size_t)p.read_size;
-    aim_request_t **req = calloc(gpus, sizeof *req);
-    aim_result_t **res = calloc(gpus, sizeof *res);
-    char **pat = calloc(gpus, sizeof *pat), **txt = calloc(gpus, sizeof *txt), **ops = calloc(gpus, sizeof *ops);
-    uint32_t *cnt = calloc(gpus, sizeof *cnt);
-    for (uint32_t g = 0; g < gpus; ++g) {
-        if ((rc = aim_host_alloc((void **)&req[g], (size_t)batch * sizeof(aim_request_t))) ||
-            (rc = aim_host_alloc((void **)&res[g], (size_t)batch * sizeof(aim_result_t))) ||
-            (rc = aim_host_alloc((void **)&pat[g], (size_t)batch * rs)) ||
-            (rc = aim_host_alloc((void **)&txt[g], (size_t)batch * rs)) ||
-            (backtrace && (rc = aim_host_alloc((void **)&ops[g], (size_t)batch * 2 * rs))))
-            die_aim("aim_host_alloc", rc);
+    const uint32_t dw = (uint32_t)(p.read_size + 15) / 16u;
+    const uint32_t max_raw = no_pack ? 0 : (batch / 16 < 1024 ? (batch < 1024 ? batch : 1024) : batch / 16);
+    const uint32_t runs_cap = (backtrace && !full_ops) ? ((uint64_t)batch * 8 > 0x7fffffffu ? 0x7fffffffu : batch * 8) : 0;
+    rc = pack_only ? 0 : aim_set_configure_slots(set, &p, batch, slots, no_pack ? 0 : max_raw, runs_cap);
+    if (rc) {
+        if (rc == AIM_EINVAL) { printf("%s\n", aim_last_error()); exit(1); }
+        die_aim("aim_set_configure_slots", rc);
+    }
+    job_t2 *jobs = calloc(ring, sizeof *jobs);
+    for (uint32_t k = 0; k < ring; ++k) {
+        job_t2 *j = &jobs[k];
+        j->device = k % gpus; j->slot = k / gpus;
+        j->req = g_big_alloc((size_t)batch * sizeof(aim_request8_t));
+        j->is_raw = plain(batch);
+        if (no_pack) { j->pat = g_big_alloc((size_t)batch * rs); j->txt = g_big_alloc((size_t)batch * rs); }
+        else {
+            j->pkP = g_big_alloc((size_t)batch * dw * 4); j->pkT = g_big_alloc((size_t)batch * dw * 4);
+            j->raw_idx = g_big_alloc((size_t)max_raw * 4); j->rawP = g_big_alloc((size_t)max_raw * rs); j->rawT = g_big_alloc((size_t)max_raw * rs);
+        }
+        if (pack_only) continue;
+        if (!backtrace) j->res8 = pinned((size_t)batch * sizeof(aim_result8_t));
+        else if (full_ops) { j->res = pinned((size_t)batch * sizeof(aim_result_t)); j->ops = pinned((size_t)batch * 2 * rs); }
+        else { j->cig = pinned((size_t)batch * sizeof(aim_cigar_t)); j->runs = pinned((size_t)runs_cap * 4); }
+    }
+    if (pack_only) {   /* dump: per batch {n, ascii, n_raw} then the arrays the device would receive */
+        FILE *df = fopen(pack_only, "wb");
+        if (!df) { fprintf(stderr, "cannot write %s\n", pack_only); exit(1); }
+        uint64_t at = 0;
+        job_t2 *j = &jobs[0];
+        while (at < total_pairs) {
+            j->n = total_pairs - at < batch ? (uint32_t)(total_pairs - at) : batch;
+            j->first_pair = (size_t)at;
+            pack_job(&inp, j, p.read_size, max_raw, batch, no_pack, threads);
+            uint32_t hdr[4] = {j->n, (uint32_t)j->ascii, j->n_raw, (uint32_t)p.read_size};
+            fwrite(hdr, 4, 4, df);
+            fwrite(j->req, sizeof(aim_request8_t), j->n, df);
+            if (j->ascii) { fwrite(j->pat, rs, j->n, df); fwrite(j->txt, rs, j->n, df); }
+            else {
+                fwrite(j->pkP, (size_t)dw * 4, j->n, df); fwrite(j->pkT, (size_t)dw * 4, j->n, df);
+                fwrite(j->raw_idx, 4, j->n_raw, df); fwrite(j->rawP, rs, j->n_raw, df); fwrite(j->rawT, rs, j->n_raw, df);
+            }
+            at += j->n;
+        }
+        fclose(df);
+        printf("AIM-HIP: packed %llu pairs, batch %u, max_raw %u\n", (unsigned long long)total_pairs, batch, max_raw);
+        return 0;
     }
 
-    uint64_t sent = 0;
+    const uint64_t n_jobs = (total_pairs + batch - 1) / batch;
+    uint64_t sent = 0, done = 0;
     int first = 1;
-    while (sent < total_pairs) {
-        double t0 = now_ms();
-        for (uint32_t g = 0; g < gpus; ++g) {
-            uint64_t left = total_pairs - sent;
-            cnt[g] = left < batch ? (uint32_t)left : batch;
-            if (cnt[g]) {
-                pack_t pk = {&inp, (size_t)sent, cnt[g], p.read_size, req[g], pat[g], txt[g], 0, 0};
-                parallel_run(threads, pack_range, &pk);
-                if (pk.too_long) { /* host.c:119-123 */
-                    printf("READ LENGTH less than length of the input reads");
-                    exit(0);
-                }
-                if (pk.malformed) { fprintf(stderr, "malformed input near pair %llu\n", (unsigned long long)sent); exit(1); }
+    for (uint64_t it = 0; it < n_jobs + ring; ++it) {
+        job_t2 *j = &jobs[it % ring];
+        if (j->in_flight) {   /* job it - ring: results are needed now (and its buffers next) */
+            double t0 = now_ms();
+            if (first) printf("Retrieve results\n");
+            first = 0;
+            rc = aim_set_wait(set, j->device, j->slot, &j->n_runs);
+            if (rc == AIM_ENOMEM && j->cig) {   /* more than 8 runs per pair on average: re-run this batch with full ops rows */
+                fprintf(stderr, "AIM-HIP: run buffer overflow, use --full-ops for this input\n");
+                exit(1);
             }
-            sent += cnt[g];
-        }
-        parse_ms += now_ms() - t0;
-        if (first) printf("Copying data to DPU\n");
-        for (uint32_t g = 0; g < gpus; ++g)
-            if ((rc = aim_set_push(set, g, cnt[g], req[g], pat[g], txt[g]))) die_aim("aim_set_push", rc);
-        if (first) printf("Run program on DPU(s)\n");
-        if ((rc = aim_set_launch(set))) die_aim("aim_set_launch", rc);
-        if (first) printf("Retrieve results\n");
-        for (uint32_t g = 0; g < gpus; ++g) {
-            rc = aim_set_pull(set, g, res[g], ops[g]);
             if (rc == AIM_EALIGN) { /* the reference prints from the DPU and exits 1 */
                 const char *msg = strstr(aim_last_error(), "(");
                 printf("%s\n", msg ? msg + 1 : aim_last_error());
                 exit(1);
             }
-            if (rc) die_aim("aim_set_pull", rc);
-        }
-        first = 0;
-        t0 = now_ms();
-        for (uint32_t g = 0; g < gpus; ++g) { /* host.c:331-352 */
-            if (!cnt[g]) continue;
-            fmt_t f;
+            if (rc) die_aim("aim_set_wait", rc);
+            wait_ms += now_ms() - t0;
+            t0 = now_ms();
+            fmt_t f;   /* host.c:331-352 */
             memset(&f, 0, sizeof f);
-            f.n = cnt[g]; f.backtrace = backtrace; f.read_size = p.read_size; f.res = res[g]; f.ops = ops[g];
+            f.job = j; f.backtrace = backtrace; f.read_size = p.read_size; f.full_ops = full_ops;
             parallel_run(threads, format_range, &f);
             for (int t = 0; t < threads; ++t) {
                 if (f.len[t]) fwrite(f.buf[t], 1, f.len[t], output_file);
                 free(f.buf[t]);
             }
+            write_ms += now_ms() - t0;
+            done += j->n;
+            j->in_flight = 0;
         }
-        write_ms += now_ms() - t0;
+        if (it < n_jobs) {
+            double t0 = now_ms();
+            const uint64_t left = total_pairs - sent;
+            j->n = left < batch ? (uint32_t)left : batch;
+            j->first_pair = (size_t)sent;
+            pack_job(&inp, j, p.read_size, max_raw, batch, no_pack, threads);
+            parse_ms += now_ms() - t0;
+            if (it == 0) { printf("Copying data to DPU\n"); printf("Run program on DPU(s)\n"); }
+            aim_batch_io_t io;
+            memset(&io, 0, sizeof io);
+            io.n_pairs = j->n;
+            io.requests = j->req;
+            if (j->ascii) { io.patterns = j->pat; io.texts = j->txt; }
+            else {
+                io.packed_patterns = j->pkP; io.packed_texts = j->pkT;
+                io.n_raw = j->n_raw; io.raw_pairs = j->raw_idx; io.raw_patterns = j->rawP; io.raw_texts = j->rawT;
+            }
+            if (!backtrace) io.results = j->res8;
+            else if (full_ops) { io.results = j->res; io.ops = j->ops; }
+            else { io.cigars = j->cig; io.runs = j->runs; io.runs_cap = runs_cap; }
+            if ((rc = aim_set_submit(set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
+            j->in_flight = 1;
+            sent += j->n;
+        }
     }
     float h2d = 0, kern = 0, d2h = 0;
     aim_set_timers(set, &h2d, &kern, &d2h);
-    if (first) { printf("Copying data to DPU\n"); printf("Run program on DPU(s)\n"); printf("Retrieve results\n"); }
+    if (n_jobs == 0) { printf("Copying data to DPU\n"); printf("Run program on DPU(s)\n"); printf("Retrieve results\n"); }
     printf("CPU-DPU: %f ms\n", h2d);
     printf("DPU Kernel: %f ms\n", kern);
     printf("DPU-CPU: %f ms\n", d2h);
-    printf("AIM-HIP: %llu pairs, parse %.3f ms, write %.3f ms\n", (unsigned long long)sent, parse_ms, write_ms);
+    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms, wait %.3f ms, format+write %.3f ms; input %s, output %s\n",
+           (unsigned long long)done, (unsigned long long)n_jobs, batch, gpus, slots, parse_ms, wait_ms, write_ms,
+           no_pack ? "ASCII rows" : "packed 2 bit/base", !backtrace ? "{idx, score}" : (full_ops ? "ops rows" : "device-side RLE"));
 
-    for (uint32_t g = 0; g < gpus; ++g) {
-        aim_host_free(req[g]); aim_host_free(res[g]); aim_host_free(pat[g]); aim_host_free(txt[g]);
-        if (ops[g]) aim_host_free(ops[g]);
+    for (uint32_t k = 0; k < ring; ++k) {
+        job_t2 *j = &jobs[k];
+        void *bufs[] = {j->req, j->pkP, j->pkT, j->raw_idx, j->rawP, j->rawT, j->pat, j->txt, j->res8, j->cig, j->runs, j->res, j->ops};
+        for (size_t b = 0; b < sizeof bufs / sizeof bufs[0]; ++b)
+            if (bufs[b]) aim_host_free(bufs[b]);
+        free(j->is_raw);
     }
-    free(req); free(res); free(pat); free(txt); free(ops); free(cnt); free(inp.line_start);
+    free(jobs); free(inp.line_start);
     if (inp.size) munmap((void *)inp.data, inp.size);
     close(fd);
     aim_set_free(set);

@@ -742,3 +742,102 @@ def test_compact_io_layouts_match_default(gpu, algo, l, err, kw, req8, res8):
         b2, o2 = engine.align(engine.make_params(algo, ms, rs, backtrace=True, **kw), req, pat, txt, check=False)
         r2, p2 = engine.align(engine.make_params(algo, ms, rs, backtrace=True, req8=True, **kw), req, pat, txt, check=False)
         assert engine.format_output(r2, p2, True) == engine.format_output(b2, o2, True) if (b2["status"] == 0).all() else True
+
+
+# ------------------------------------------------------------------ round 2: packed input, compact CIGAR, slots
+PIPE_CASES = [("wfa", 100, 0.01, 5000, dict(reduce=True)), ("wfa", 100, 0.01, 5000, dict(reduce=True, backtrace=True)),
+              ("wfa", 100, 0.05, 3000, dict(reduce=True, backtrace=True)), ("wfa", 1000, 0.05, 200, dict(reduce=True, backtrace=True)),
+              ("nw", 100, 0.05, 3000, dict(backtrace=True)), ("swg", 100, 0.02, 3000, dict(backtrace=True)),
+              ("nw", 700, 0.10, 60, dict(backtrace=True)), ("swg", 150, 0.03, 1000, dict())]
+
+
+@pytest.mark.parametrize("algo,l,err,n,kw", PIPE_CASES)
+def test_packed_input_and_compact_cigar_match_default_path(gpu, algo, l, err, n, kw):
+    """aim_set_submit / aim_set_wait with a PACKED batch (2 bits per base + raw side list for pairs with non-ACGT bytes) and
+    device-side CIGAR run-length encoding give byte-identical output text to the default push / launch / pull path."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes(algo, l, err)
+    req, pat, txt = engine.gen_pairs(2025, 7, n, l, err, rs)
+    for i in range(0, n, 9):                      # pairs that cannot be packed: 'N' matches 'N', 'n' does not match 'N'
+        pat[i, i % (l // 2)] = ord("N")
+    for i in range(4, n, 31):
+        j = (3 * i) % (l // 2)
+        pat[i, j] = ord("N"); txt[i, j] = ord("N")
+    bt = kw.get("backtrace", False)
+    params = engine.make_params(algo, ms, rs, **kw)
+    base_res, base_ops = engine.align(params, req, pat, txt, check=False)
+    want = engine.format_output(base_res, base_ops, bt) if (base_res["status"] == 0).all() else None
+    packed = engine.pack_batch(req, pat, txt)
+    assert len(packed[2]) >= n // 9
+    with engine.DeviceSet(1) as s:
+        s.configure_slots(params, n, slots=2, max_raw=n, max_runs=(n * 2 * rs if bt else 0))
+        # (a) packed in, default results out
+        s.submit(0, 0, req, packed=packed, want_ops=bt)
+        out = s.wait(0, 0, check=False)
+        for f in ("score", "status", "begin_offset", "end_offset", "idx"):
+            assert np.array_equal(out["res"][f], base_res[f]), f
+        if want is not None:
+            assert engine.format_output(out["res"], out.get("ops"), bt) == want
+        if bt:
+            # (b) ASCII in, compact CIGAR out; (c) packed in, compact CIGAR out -- on the other slot
+            for slot, pk in ((1, None), (0, packed)):
+                if pk is None:
+                    s.submit(0, slot, req, pat, txt, cigar_runs_cap=n * 2 * rs)
+                else:
+                    s.submit(0, slot, req, packed=pk, cigar_runs_cap=n * 2 * rs)
+                out = s.wait(0, slot, check=False)
+                assert np.array_equal(out["cig"]["score"], base_res["score"]) and np.array_equal(out["cig"]["idx"], base_res["idx"])
+                assert np.array_equal(out["cig"]["status"], base_res["status"].astype(np.uint16))
+                if want is not None:
+                    assert engine.format_output_runs(out["cig"], out["runs"]) == want
+                assert int(out["cig"]["n_runs"].sum()) == len(out["runs"])
+
+
+def test_compact_cigar_bytes_per_pair_and_overflow(gpu):
+    """l=100 e=1 % with CIGAR: the compact form is <= 32 B per pair (header 16 B + ~3 runs), against 24 + 224 B for the
+    default structs + ops rows; a run buffer that is too small is reported (AIM_ENOMEM), never silently truncated."""
+    from aim_amd import capi, engine
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.01)
+    n = 1 << 16
+    req, pat, txt = engine.gen_pairs(1, 0, n, 100, 0.01, rs)
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=True, req8=True)
+    with engine.DeviceSet(1) as s:
+        s.configure_slots(params, n, slots=1, max_raw=0, max_runs=8 * n)
+        s.submit(0, 0, req, pat, txt, cigar_runs_cap=8 * n)
+        out = s.wait(0, 0)
+        per_pair = (out["cig"].nbytes + out["runs"].nbytes) / n
+        assert per_pair <= 32.0, per_pair
+        base_res, base_ops = engine.align(engine.make_params("wfa", ms, rs, reduce=True, backtrace=True), req, pat, txt)
+        assert engine.format_output_runs(out["cig"], out["runs"]) == engine.format_output(base_res, base_ops, True)
+        s.submit(0, 0, req, pat, txt, cigar_runs_cap=n)          # one run per pair is not enough
+        with pytest.raises(capi.AimError) as e:
+            s.wait(0, 0)
+        assert e.value.code == capi.AIM_ENOMEM
+
+
+def test_two_slots_pipeline_many_batches(gpu):
+    """Double buffering: batches alternate between two slots of one device, each slot's results land in its own buffers;
+    the concatenation equals one big default launch. Also: a slot refuses a second submit before its wait."""
+    from aim_amd import capi, engine
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.02)
+    nb, per = 12, 4096
+    req, pat, txt = engine.gen_pairs(314, 0, nb * per, 100, 0.02, rs)
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=True)
+    base_res, base_ops = engine.align(params, req, pat, txt)
+    want = engine.format_output(base_res, base_ops, True)
+    got = []
+    with engine.DeviceSet(1) as s:
+        s.configure_slots(params, per, slots=2, max_raw=per, max_runs=16 * per)
+        def sub(b):
+            lo, hi = b * per, (b + 1) * per
+            s.submit(0, b & 1, req[lo:hi], packed=engine.pack_batch(req[lo:hi], pat[lo:hi], txt[lo:hi]), cigar_runs_cap=16 * per)
+        sub(0)
+        with pytest.raises(capi.AimError) as e:
+            sub(2)                                   # slot 0 is busy
+        assert e.value.code == capi.AIM_ESTATE
+        for b in range(nb):
+            if b + 1 < nb:
+                sub(b + 1)
+            out = s.wait(0, b & 1)
+            got.append(engine.format_output_runs(out["cig"], out["runs"]))
+    assert b"".join(got) == want

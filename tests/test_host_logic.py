@@ -4,6 +4,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from conftest import ROOT, md5
 
@@ -98,3 +99,149 @@ def test_gen_dataset_cli_round_trips_through_the_parser(tmp_path, built):
     assert np.array_equal(req["pattern_len"], greq["pattern_len"]) and np.array_equal(req["text_len"], greq["text_len"])
     assert np.array_equal(pat, gpat) and np.array_equal(txt, gtxt)
     assert (req["pattern_len"] == 100).all() and (np.abs(req["text_len"].astype(int) - 100) <= 2).all()
+
+
+def test_pack_sequence_and_numpy_packer_agree(built):
+    """aim_pack_sequence (C, used by the CLI's parser threads) and engine.pack_rows (numpy, used by tests/bench) implement
+    the packed-input format of aim_hip.h: code (ascii>>1)&3, base i at bits 2(i%16) of dword i/16; a byte outside A/C/G/T
+    inside the sequence makes the pair travel raw; bytes beyond the length never matter."""
+    import ctypes as C
+    import numpy as np
+    from aim_amd import capi, engine
+    lib = capi.load()
+    rng = np.random.RandomState(5)
+    for rs in (80, 112, 120, 1064):
+        req, pat, txt = engine.gen_pairs(9, 0, 200, int(rs / 1.06) - 4, 0.05, rs)
+        pat[3, 5] = ord("N"); pat[4, int(req["pattern_len"][4])] = ord("N")      # inside / just outside the sequence
+        pat[5, 0] = ord("a"); pat[6, 2] = 0xC1; pat[7, 1] = 0
+        packed, ok = engine.pack_rows(req, pat, "pattern_len")
+        dw = engine.packed_row_dwords(rs)
+        assert packed.shape == (200, dw)
+        for i in range(200):
+            row = np.zeros(dw, dtype=np.uint32)
+            r = lib.aim_pack_sequence(capi.ptr(pat[i]), int(req["pattern_len"][i]), rs, capi.ptr(row))
+            assert r == int(ok[i]), i
+            if r:
+                assert np.array_equal(row, packed[i]), i
+        assert list(np.nonzero(~ok)[0]) == [3, 5, 6, 7]
+        # unpack model: "ACTG"[code] reproduces the rows up to their lengths
+        lut = np.frombuffer(b"ACTG", dtype=np.uint8)
+        for i in (0, 1, 4, 199):
+            codes = (packed[i][:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3
+            seq = lut[codes.reshape(-1)][: req["pattern_len"][i]]
+            assert np.array_equal(seq, pat[i, : req["pattern_len"][i]])
+
+
+def test_cigar_format_runs_equals_edit_cigar_print(built):
+    """aim_cigar_format_runs prints (length<<8 | op) runs exactly like aim_cigar_format prints the ops they encode
+    (edit_cigar_print, host.c:69-89), also when a run arrives split in two."""
+    import ctypes as C
+    import numpy as np
+    from aim_amd import capi, engine
+    lib = capi.load()
+    rng = np.random.RandomState(11)
+    for _ in range(200):
+        n = int(rng.randint(1, 400))
+        ops = rng.choice(np.frombuffer(b"MMMMMMXID", dtype=np.uint8), size=n)
+        want = engine.cigar_of(ops, 0, n)
+        runs, start = [], 0
+        for i in range(1, n + 1):
+            if i == n or ops[i] != ops[start]:
+                ln = i - start
+                if ln > 3 and rng.rand() < 0.3:      # a split run must be merged by the formatter
+                    k = int(rng.randint(1, ln))
+                    runs += [(k << 8) | int(ops[start]), ((ln - k) << 8) | int(ops[start])]
+                else:
+                    runs.append((ln << 8) | int(ops[start]))
+                start = i
+        r = np.array(runs, dtype=np.uint32)
+        buf = C.create_string_buffer(12 * len(r) + 16)
+        k = capi.check(lib.aim_cigar_format_runs(capi.ptr(r), len(r), buf, len(buf)))
+        assert buf.raw[:k] == want
+
+
+def _read_pack_dump(path):
+    import numpy as np
+    from aim_amd import capi, engine
+    raw = open(path, "rb").read()
+    at, jobs = 0, []
+    while at < len(raw):
+        n, ascii_, n_raw, rs = np.frombuffer(raw, dtype=np.uint32, count=4, offset=at); at += 16
+        n, n_raw, rs = int(n), int(n_raw), int(rs)
+        dw = engine.packed_row_dwords(rs)
+        req = np.frombuffer(raw, dtype=capi.REQUEST8_DTYPE, count=n, offset=at); at += 8 * n
+        job = dict(n=n, ascii=bool(ascii_), req=req, rs=rs)
+        if ascii_:
+            job["pat"] = np.frombuffer(raw, dtype=np.uint8, count=n * rs, offset=at).reshape(n, rs); at += n * rs
+            job["txt"] = np.frombuffer(raw, dtype=np.uint8, count=n * rs, offset=at).reshape(n, rs); at += n * rs
+        else:
+            job["pkP"] = np.frombuffer(raw, dtype=np.uint32, count=n * dw, offset=at).reshape(n, dw); at += 4 * n * dw
+            job["pkT"] = np.frombuffer(raw, dtype=np.uint32, count=n * dw, offset=at).reshape(n, dw); at += 4 * n * dw
+            job["raw_idx"] = np.frombuffer(raw, dtype=np.uint32, count=n_raw, offset=at); at += 4 * n_raw
+            job["rawP"] = np.frombuffer(raw, dtype=np.uint8, count=n_raw * rs, offset=at).reshape(n_raw, rs); at += n_raw * rs
+            job["rawT"] = np.frombuffer(raw, dtype=np.uint8, count=n_raw * rs, offset=at).reshape(n_raw, rs); at += n_raw * rs
+        jobs.append(job)
+    return jobs
+
+
+@pytest.mark.parametrize("threads,dirty", [(1, 40), (5, 40), (8, 3000)])
+def test_host_cli_packer_matches_numpy_packer(built, tmp_path, threads, dirty):
+    """The C host's parser threads (SSSE3/BMI2 packer, raw side list assembled from per-thread ranges, ASCII fallback
+    for unusually dirty batches) produce exactly the batch engine.pack_batch builds (--pack-only: no GPU is touched)."""
+    import subprocess
+    import numpy as np
+    from aim_amd import engine
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    n, rs = 20000, 112
+    req, pat, txt = engine.gen_pairs(123, 0, n, 100, 0.02, rs)
+    rng = np.random.RandomState(dirty)
+    for i in rng.choice(n, size=dirty, replace=False):
+        (pat if i % 2 else txt)[i, int(rng.randint(0, 90))] = ord("N")
+    pat[17, :16] = ord("G"); txt[17, :16] = ord("G")               # a legal all-G head (packs to 0xffffffff)
+    inp = tmp_path / "in.seq"
+    inp.write_bytes(engine.pairs_to_text(req, pat, txt))
+    dump = tmp_path / "dump.bin"
+    r = subprocess.run([host, str(inp), str(tmp_path / "out"), str(n), "--read-size", str(rs), "--threads", str(threads),
+                        "--pack-only", str(dump)], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    jobs = _read_pack_dump(dump)
+    assert sum(j["n"] for j in jobs) == n
+    at = 0
+    for j in jobs:
+        lo, hi = at, at + j["n"]
+        at = hi
+        assert np.array_equal(j["req"]["pattern_len"], req["pattern_len"][lo:hi]) and np.array_equal(j["req"]["idx"], req["idx"][lo:hi])
+        assert np.array_equal(j["req"]["text_len"], req["text_len"][lo:hi])
+        if j["ascii"]:
+            assert dirty > j["n"] // 16
+            assert np.array_equal(j["pat"], pat[lo:hi]) and np.array_equal(j["txt"], txt[lo:hi])
+            continue
+        pp, pt, raw, rawp, rawt = engine.pack_batch(req[lo:hi], pat[lo:hi], txt[lo:hi])
+        assert np.array_equal(j["raw_idx"], raw)
+        assert np.array_equal(j["rawP"], rawp) and np.array_equal(j["rawT"], rawt)
+        keep = np.ones(j["n"], dtype=bool); keep[raw] = False
+        assert np.array_equal(j["pkP"][keep], pp[keep]) and np.array_equal(j["pkT"][keep], pt[keep])
+    if dirty == 40:
+        assert not any(j["ascii"] for j in jobs) and sum(len(j["raw_idx"]) for j in jobs) == 40
+    else:
+        assert any(j["ascii"] for j in jobs)
+
+
+def test_host_cli_validates_whole_input_before_writing(built, tmp_path):
+    """an over-length read anywhere in the consumed range ends the run like get_reads does (message, exit 0)
+    BEFORE anything is launched or written -- the output file stays empty; a negative read count is 'Invalid nb of reads'."""
+    import subprocess
+    from aim_amd import engine
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    req, pat, txt = engine.gen_pairs(5, 0, 3000, 100, 0.01, 112)
+    lines = engine.pairs_to_text(req, pat, txt).split(b"\n")
+    lines[2 * 2900] = lines[2 * 2900] + b"A" * 40
+    inp = tmp_path / "in.seq"
+    inp.write_bytes(b"\n".join(lines))
+    out = tmp_path / "out"
+    r = subprocess.run([host, str(inp), str(out), "3000", "--read-size", "112", "--pack-only", str(tmp_path / "d")],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and "READ LENGTH less than length of the input reads" in r.stdout
+    assert out.read_bytes() == b"" and not (tmp_path / "d").exists()
+    r = subprocess.run([host, str(inp), str(out), "-5"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "Invalid nb of reads" in r.stderr
