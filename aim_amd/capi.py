@@ -64,6 +64,7 @@ SYMBOLS = {
     "aim_set_submit": (C.c_int, [_VP, _U32, _U32, C.POINTER(BatchIO)]),
     "aim_set_wait": (C.c_int, [_VP, _U32, _U32, C.POINTER(_U32)]),
     "aim_pack_sequence": (C.c_int, [_VP, _I32, _I32, _VP]),
+    "aim_pack_batch": (C.c_int, [C.POINTER(Params), _U32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _U32, C.POINTER(_U32), C.c_int]),
     "aim_cigar_format_runs": (C.c_int, [_VP, _U32, _VP, _I32]),
     "aim_set_timers": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "aim_set_fallback_pairs": (C.c_int, [_VP, _U32, C.POINTER(_U32)]),

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -1040,6 +1041,50 @@ int aim_pack_sequence(const char *seq, int32_t len, int32_t read_size, uint32_t 
         row[w] = v;
     }
     return bad == 0;
+}
+
+int aim_pack_batch(const aim_params_t *params, uint32_t n_pairs, const void *requests, const char *patterns, const char *texts,
+                   uint32_t *packed_patterns, uint32_t *packed_texts, uint32_t *raw_pairs, char *raw_patterns, char *raw_texts,
+                   uint32_t max_raw, uint32_t *n_raw, int threads)
+{
+    if (!params || !n_raw || (n_pairs && (!requests || !patterns || !texts || !packed_patterns || !packed_texts)))
+        return fail(AIM_EINVAL, "bad arguments");
+    const int rs = params->read_size;
+    if (rs <= 0 || (rs & 7)) return fail(AIM_EINVAL, "read_size must be a positive multiple of 8");
+    int rc = check_lengths(*params, n_pairs, requests);
+    if (rc) return rc;
+    const uint32_t dw = aim::packed_row_dwords(rs);
+    const bool req8 = params->flags & AIM_FLAG_REQ8;
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    std::vector<uint8_t> is_raw(n_pairs, 0);
+    auto work = [&](int t) {
+        const size_t lo = (size_t)n_pairs * t / threads, hi = (size_t)n_pairs * (t + 1) / threads;
+        for (size_t i = lo; i < hi; ++i) {
+            const int pl = req8 ? static_cast<const aim_request8_t *>(requests)[i].pattern_len : static_cast<const aim_request_t *>(requests)[i].pattern_len;
+            const int tl = req8 ? static_cast<const aim_request8_t *>(requests)[i].text_len : static_cast<const aim_request_t *>(requests)[i].text_len;
+            const int okp = aim_pack_sequence(patterns + i * rs, pl, rs, packed_patterns + i * dw);
+            const int okt = aim_pack_sequence(texts + i * rs, tl, rs, packed_texts + i * dw);
+            is_raw[i] = !(okp == 1 && okt == 1);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < n_pairs; ++i) {
+        if (!is_raw[i]) continue;
+        if (n < max_raw && raw_pairs && raw_patterns && raw_texts) {
+            raw_pairs[n] = i;
+            memcpy(raw_patterns + (size_t)n * rs, patterns + (size_t)i * rs, (size_t)rs);
+            memcpy(raw_texts + (size_t)n * rs, texts + (size_t)i * rs, (size_t)rs);
+        }
+        ++n;
+    }
+    *n_raw = n;
+    if (n > max_raw) return fail(AIM_ENOMEM, "%u pairs must travel raw, side list holds %u", n, max_raw);
+    return AIM_OK;
 }
 
 int aim_cigar_format_runs(const uint32_t *runs, uint32_t n_runs, char *out, int32_t cap)

@@ -36,6 +36,9 @@
 #ifndef AIM_LANE_INTERLEAVE
 #define AIM_LANE_INTERLEAVE 1     // 1 = the next group's 15 LDS-DMA instructions are issued one by one BETWEEN the pack steps of the
 #endif                            // current group instead of as one burst in front of them (0 = burst, round-1 structure)
+#ifndef AIM_LANE_NT_STORE
+#define AIM_LANE_NT_STORE 0       // 1 = score-only result stores are nontemporal
+#endif
 #ifndef AIM_LANE_STAMPS
 #define AIM_LANE_STAMPS 0         // diagnostic build only: s_memtime per segment, summed per wave into scratch
 #endif
@@ -353,17 +356,22 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         // its HBM latency flies under the pack + compute below
         uint4 rawP[NP], rawT[NP];
         load_row<RS, NP>(rowsP, lane, rawP);
+        __builtin_amdgcn_sched_barrier(0);      // LDS operations return in issue order: request, P rows, then T rows
         load_row<RS, NP>(rowsT, lane, rawT);
         uint32_t ngrp = 0;
         const bool nhave = next_group(it + 1, &ngrp);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every ds_read of this group has returned: the buffers are free
+        const bool inter = AIM_LANE_INTERLEAVE && !AIM_LANE_DIAG && nhave && (ngrp + 1u) * kWave <= a.n_pairs;   // wave-uniform
+        // A buffer may be refilled once every ds_read of it has returned. Interleaved mode refills the P buffer during the P
+        // pack and the T buffer during the T pack, so only the P rows (the NP youngest reads are T's) must be back here and
+        // the T reads fly under the P pack; burst mode needs both.
+        if (inter) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         AIM_STAMP(2);                           // LDS row reads
         // The next group's DMA. Issued as ONE burst, 15 KiB from each of the CU's 8 wavefronts back-pressure the vector-memory
         // queue and the wave sits in the issue of its own glds instructions (stamped: 3 350 of 13 400 ticks per group, 220 per
         // instruction, at 67 % of the streaming ceiling). Full groups therefore hand their pieces out one by one between the
         // pack steps below; only the batch's last (partial) group is issued here in one go.
-        const bool inter = AIM_LANE_INTERLEAVE && !AIM_LANE_DIAG && nhave && (ngrp + 1u) * kWave <= a.n_pairs;   // wave-uniform
         if (nhave && !inter) {
             dma_rows<RS, NCH>(offP, a.patterns, ngrp * kWave, a.n_pairs, lane);
             dma_rows<RS, NCH>(offT, a.texts, ngrp * kWave, a.n_pairs, lane);
@@ -392,9 +400,10 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         uint32_t P[NP], T[NP];
         // four instantiations of the pack phase, selected by two wave-uniform tests made ONCE per group
         uint32_t bad;
-        auto pack_both = [&](auto FAST, auto INTER) {
+        auto pack_both = [&](auto FAST, auto INTER) __attribute__((always_inline)) {
             constexpr bool fast = decltype(FAST)::value, with_dma = decltype(INTER)::value;
             bad = pack_row<fast, NP>(rawP, plen, P, [&](auto J) { if (with_dma) dma_piece<decltype(J)::value>(offP, gP_next); });
+            if (with_dma) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }   // T rows are back
             bad |= pack_row<fast, NP>(rawT, tlen, T, [&](auto J) { if (with_dma) dma_piece<decltype(J)::value>(offT, gT_next); });
             if (with_dma) stage_requests(offQ, reqL, a, ngrp * kWave, lane);
         };
@@ -452,7 +461,8 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
             // scores: placed only at the end of the body it was never reached when MAX_SCORE itself has no wavefront, and a
             // pair whose score is exactly MAX_SCORE+1 was then aligned and backtraced instead of reported as exceeded
             // (same score either way, so only CIGAR output showed it; found by tools/fuzz_parity.py).
-            if (s > ms_run) break;
+            // (round 2: the cap is a term of the end test below instead of two scalar branches per score: wavefronts past the
+            // run-time cap are computed and ignored, which is the same answer)
             if (!SH.present[s]) continue;
             if (s > 0) {
                 const int ss = s - X, so = s - O - E, se = s - E;
@@ -501,9 +511,8 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
                 Mv[s][kk] = off;
                 if (k == ak) { m_end = off; end_in_range = true; }
             }
-            if (!done && end_in_range && m_end >= tlen) { done = true; score = s; }
+            if (!done && end_in_range && m_end >= tlen && s <= ms_run) { done = true; score = s; }
             if (__ballot(!done && active) == 0ull) break;   // every pair of this wave has finished
-            if (s + 1 > ms_run) break;                              // runtime MAX_SCORE below the template cap
         }
         if (!done) score = ms_run + 1;                              // wfa.c:368-376
         AIM_STAMP(5);                           // diagonals + WFA
@@ -644,7 +653,10 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
                 if (BT) {
                     store_result(a, pair, r);
                 } else if (res8) {     // ONE global_store_dwordx2 per lane (512 contiguous bytes per wavefront)
-                    *reinterpret_cast<uint2 *>(reinterpret_cast<aim_result8_t *>(a.res) + pair) = make_uint2(r.idx, (uint32_t)r.score);
+                    typedef uint32_t aim_u32x2 __attribute__((ext_vector_type(2)));
+                    aim_u32x2 v2; v2.x = r.idx; v2.y = (uint32_t)r.score;
+                    aim_u32x2 *dst2 = reinterpret_cast<aim_u32x2 *>(reinterpret_cast<aim_result8_t *>(a.res) + pair);
+                    if (AIM_LANE_NT_STORE) __builtin_nontemporal_store(v2, dst2); else *dst2 = v2;
                 } else {               // TWO stores per lane: dwordx4 + dwordx2 (24-B struct, 8-B aligned)
                     uint32_t *dst = reinterpret_cast<uint32_t *>(a.res + pair);
                     *reinterpret_cast<uint4 *>(dst) = make_uint4((uint32_t)r.max_operations, (uint32_t)r.begin_offset, (uint32_t)r.end_offset, (uint32_t)r.score);

@@ -96,6 +96,24 @@ def pack_batch(req, pat, txt):
     return pp, pt, raw, np.ascontiguousarray(pat[raw]), np.ascontiguousarray(txt[raw])
 
 
+def pack_batch_native(params, req, pat, txt, threads=8):
+    """aim_pack_batch (host threads in libaim_hip.so): same result as pack_batch, for batches too large for numpy temporaries."""
+    lib = capi.load()
+    n, rs = len(req), params.read_size
+    dw = packed_row_dwords(rs)
+    if (params.flags & FLAG_REQ8) and req.dtype != REQUEST8_DTYPE:
+        req = to_request8(req)
+    req, pat, txt = np.ascontiguousarray(req), np.ascontiguousarray(pat), np.ascontiguousarray(txt)
+    pp, pt = np.zeros((n, dw), dtype=np.uint32), np.zeros((n, dw), dtype=np.uint32)
+    cap = max(1, n // 8)
+    raw, rawp, rawt = np.zeros(cap, dtype=np.uint32), np.zeros((cap, rs), dtype=np.uint8), np.zeros((cap, rs), dtype=np.uint8)
+    nr = C.c_uint32()
+    capi.check(lib.aim_pack_batch(C.byref(params), n, capi.ptr(req), capi.ptr(pat), capi.ptr(txt), capi.ptr(pp), capi.ptr(pt),
+                                  capi.ptr(raw), capi.ptr(rawp), capi.ptr(rawt), cap, C.byref(nr), threads))
+    k = nr.value
+    return pp, pt, raw[:k].copy(), rawp[:k].copy(), rawt[:k].copy()
+
+
 def format_output_runs(cig, runs):
     """Output file of the reference host (host.c:339-349) from the compact CIGAR (aim_cigar_t headers + run buffer)."""
     lib = capi.load()

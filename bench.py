@@ -40,6 +40,75 @@ def pmc_traffic(kernel, pairs, io):
     return best
 
 
+def _pinned(lib, capi, arr):
+    """Copy a numpy array into pinned host memory (aim_host_alloc); returns (pointer, view)."""
+    p = C.c_void_p()
+    capi.check(lib.aim_host_alloc(C.byref(p), max(arr.nbytes, 1)))
+    view = np.ctypeslib.as_array((C.c_uint8 * max(arr.nbytes, 1)).from_address(p.value))
+    view[: arr.nbytes] = arr.view(np.uint8).reshape(-1)
+    return p, view
+
+
+def e2e_leg(lib, capi, engine, local_rank, ms, rs, req, pat, txt, batches, packed, backtrace):
+    """PCIe-inclusive rate of the drop-in path (AIM's CPU-DPU + DPU Kernel + DPU-CPU, input already in
+    pinned host memory, file parsing excluded): `batches` batches of the same pairs through aim_set_submit / aim_set_wait on
+    two slots, so H2D(k+1) || kernel(k) || D2H(k-1). packed = 2 bits per base + raw side list; else ASCII rows."""
+    n = len(req)
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=backtrace, req8=True, res8=not backtrace)
+    req8 = engine.to_request8(req)
+    keep = []
+    io = [capi.BatchIO(), capi.BatchIO()]
+    runs_cap = 8 * n if backtrace else 0
+    h2d_bytes = req8.nbytes
+    if packed:
+        pp, pt, raw, rawp, rawt = engine.pack_batch_native(params, req, pat, txt, threads=min(64, os.cpu_count() or 1))
+        h2d_bytes += pp.nbytes + pt.nbytes + raw.nbytes + rawp.nbytes + rawt.nbytes
+    else:
+        h2d_bytes += pat.nbytes + txt.nbytes
+    for k in range(2):
+        b = io[k]
+        b.n_pairs = n
+        ptr, v = _pinned(lib, capi, req8); keep.append(v); b.requests = ptr.value
+        if packed:
+            for name, arr in (("packed_patterns", pp), ("packed_texts", pt), ("raw_pairs", raw), ("raw_patterns", rawp), ("raw_texts", rawt)):
+                ptr, v = _pinned(lib, capi, arr); keep.append(v); setattr(b, name, ptr.value)
+            b.n_raw = len(raw)
+        else:
+            for name, arr in (("patterns", pat), ("texts", txt)):
+                ptr, v = _pinned(lib, capi, arr); keep.append(v); setattr(b, name, ptr.value)
+        if backtrace:
+            ptr, v = _pinned(lib, capi, np.zeros(n, dtype=capi.CIGAR_DTYPE)); keep.append(v); b.cigars = ptr.value
+            ptr, v = _pinned(lib, capi, np.zeros(runs_cap, dtype=np.uint32)); keep.append(v); b.runs = ptr.value
+            b.runs_cap = runs_cap
+        else:
+            ptr, v = _pinned(lib, capi, np.zeros(n, dtype=capi.RESULT8_DTYPE)); keep.append(v); b.results = ptr.value
+    s = C.c_void_p()
+    ids = (C.c_int * 1)(local_rank)
+    capi.check(lib.aim_set_alloc(1, ids, C.byref(s)))
+    capi.check(lib.aim_set_configure_slots(s, C.byref(params), n, 2, max(len(raw), 1) if packed else 0, runs_cap))
+    nr = C.c_uint32()
+    total_runs = 0
+    for rep in range(2):                       # first pass warms up (first-touch of device buffers, clocks)
+        t0 = time.perf_counter()
+        capi.check(lib.aim_set_submit(s, 0, 0, C.byref(io[0])))
+        for k in range(batches):
+            if k + 1 < batches:
+                capi.check(lib.aim_set_submit(s, 0, (k + 1) & 1, C.byref(io[(k + 1) & 1])))
+            capi.check(lib.aim_set_wait(s, 0, k & 1, C.byref(nr)))
+            total_runs = nr.value
+        dt = time.perf_counter() - t0
+    h2d, kern, d2h = C.c_float(), C.c_float(), C.c_float()
+    lib.aim_set_timers(s, C.byref(h2d), C.byref(kern), C.byref(d2h))
+    lib.aim_set_free(s)
+    d2h_bytes = (16 * n + 4 * total_runs) if backtrace else 8 * n
+    return {"pairs_per_s": batches * n / dt, "batches": batches, "pairs_per_batch": n, "slots": 2,
+            "input": "packed 2 bit/base + raw side list" if packed else "ASCII rows",
+            "output": "device-side CIGAR runs" if backtrace else "{idx, score}",
+            "h2d_bytes_per_pair": h2d_bytes / n, "d2h_bytes_per_pair": d2h_bytes / n,
+            "h2d_GBps_effective": batches * h2d_bytes / dt / 1e9,
+            "phase_ms_per_batch": {"h2d": h2d.value / (2 * batches), "kernel": kern.value / (2 * batches), "d2h": d2h.value / (2 * batches)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +122,7 @@ def main():
                     help="wire layout of requests/results: 'compact' = the reference's own 8-B WFA request_t + 8-B {idx, score} "
                          "results (AIM_FLAG_REQ8|RES8, score-only); 'default' = the 16-B / 24-B NW/SWG structs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg (reported as `e2e`, never as `value`)")
     ap.add_argument("--verify-pairs", type=int, default=1 << 20, help="pairs re-checked against the CPU oracle after timing")
     args = ap.parse_args()
 
@@ -176,6 +246,13 @@ def main():
                         "sample": "%d passes over the same %d-pair batch, %d threads, %.1f s wall (oracle/aim_oracle.c)"
                                   % (passes, n, cores, spent)}
 
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        ne = min(n, 1 << 22)
+        e2e = {"packed": e2e_leg(lib, capi, engine, local_rank, ms, rs, req[:ne], pat[:ne], txt[:ne], 8, True, args.backtrace),
+               "ascii": e2e_leg(lib, capi, engine, local_rank, ms, rs, req[:ne], pat[:ne], txt[:ne], 4, False, args.backtrace),
+               "note": "input already in pinned host memory; file parsing / packing excluded (SURVEY 8d ii); never used as `value`"}
+
     if args.backtrace:   # algorithmic bytes with CIGAR include the ops actually produced
         alg_bytes += int((res_host["end_offset"].astype(np.int64) - res_host["begin_offset"]).sum())
     if rank == 0:
@@ -205,6 +282,7 @@ def main():
                          "traffic_unit": "bytes/launch", "traffic_source": traffic[1] if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_pair": alg_bytes / n},
             "cpu_baseline": cpu_baseline,
+            "e2e": e2e,
             "gather_ms": gather_ms,
             "verified_vs_oracle": verified,
         }

@@ -213,6 +213,11 @@ int aim_set_wait(aim_set_t *set, uint32_t device, uint32_t slot, uint32_t *n_run
 /* Host-side packer used by the CLI and the tests: packs one sequence (len bytes) into row[ceil(read_size/16)]; returns 1
  * when every byte is A/C/G/T, 0 when the pair must travel raw (the row content is then unspecified). */
 int aim_pack_sequence(const char *seq, int32_t len, int32_t read_size, uint32_t *row);
+/* Whole-batch packer (host threads): ASCII rows -> packed rows + raw side list, exactly what aim_batch_io_t takes.
+ * *n_raw receives the number of pairs that must travel raw; AIM_ENOMEM when it exceeds max_raw (ship the batch as ASCII). */
+int aim_pack_batch(const aim_params_t *params, uint32_t n_pairs, const void *requests, const char *patterns, const char *texts,
+                   uint32_t *packed_patterns, uint32_t *packed_texts, uint32_t *raw_pairs, char *raw_patterns,
+                   char *raw_texts, uint32_t max_raw, uint32_t *n_raw, int threads);
 /* edit_cigar_print (host.c:69-89) from runs: adjacent runs of the same op are merged; returns bytes written incl. '\n'. */
 int aim_cigar_format_runs(const uint32_t *runs, uint32_t n_runs, char *out, int32_t cap);
 
