@@ -163,7 +163,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
     int rc = AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     if (p.algo == AIM_ALGO_WFA) {
-        const bool lane_ok = !kn.force_wave && !pl->no_lane && aim::wfa_lane_supported(p);
+        const bool lane_ok = !kn.force_wave && !pl->no_lane && aim::wfa_lane_supported(p, !kn.no_lane_ext);
         aim::GroupCfg gc;
         int gg = 0;
         uint32_t ggrid = 0;

@@ -297,11 +297,141 @@ __device__ __forceinline__ void raw_diag(const uint4 (&rawP)[NP], const uint4 (&
 }
 
 
-template <int X, int O, int E, int MAXS, int RS, bool BT>
+
+// ---------------------------------------------------------------------------------------------------
+// Shapes whose wavefronts can reach the 10 diagonals at which WFA-adaptive's reduction applies (wfa.c:69-140), e.g. the
+// launcher's MAX_SCORE 10 for l = 100, e = 2 % -- the configuration that fell off a 10x cliff onto wfa_group_kernel in
+// round 1. The score loop stays statically unrolled over the NON-reduced shape, which is a superset of every reduced one
+// (a reduction only raises klo / lowers khi, and a wavefront's bounds are min/max over its sources' bounds). What the
+// reduction makes data-dependent -- klo, khi, the null flags, and through them which wavefronts exist -- is carried per
+// lane in ordinary variables: for every score below the first reducible one they are compile-time constants and fold
+// away, above it they are a handful of integer selects. Every fetch is range-gated by the source's klo/khi exactly like
+// AFFINE_WAVEFRONT_COND_FETCH (common.h:121-124), so cells of the static superset that the reference never allocates are
+// computed but never read. Score-only (with CIGAR the history of a 13-wide shape does not fit the register file).
+template <int X, int O, int E, int MAXS, int NP, int KW>
+__device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], int plen, int tlen, int ms_run, bool reduce, bool active)
+{
+    constexpr WfShape<X, O, E, MAXS> SH{};
+    static_assert(KW == SH.kmax - SH.kmin + 1, "diagonal window");
+    static_assert(SH.kmax < 16 && SH.kmin > -16, "diagonal shifts are single-word funnel shifts");
+    const int ak = tlen - plen;
+    int Mv[MAXS + 1][KW], Iv[MAXS + 1][KW], Dv[MAXS + 1][KW];
+    int klo[MAXS + 1], khi[MAXS + 1];
+    bool pres[MAXS + 1], mnul[MAXS + 1], inul[MAXS + 1], dnul[MAXS + 1];
+    int score = MAXS + 1;
+    bool done = false;
+#pragma unroll
+    for (int s = 0; s <= MAXS; ++s) {
+        if (!SH.present[s]) { pres[s] = false; mnul[s] = inul[s] = dnul[s] = true; klo[s] = 0; khi[s] = -1; continue; }
+        if (s == 0) {   // wavefronts[0] = allocate_new_score(0, 0, 0, 0); M[0] = 0 (wfa.c:347-348)
+            pres[0] = true; mnul[0] = false; inul[0] = dnul[0] = true; klo[0] = khi[0] = 0;
+            Mv[0][-SH.kmin] = 0;
+        } else {        // affine_wfa_compute_next, wfa.c:268-340
+            const int ss = s - X, so = s - O - E, se = s - E;
+            const bool m_sub_null = ss < 0 || !SH.present[ss] || !pres[ss < 0 ? 0 : ss] || mnul[ss < 0 ? 0 : ss];
+            const bool m_o_null = so < 0 || !SH.present[so] || !pres[so < 0 ? 0 : so] || mnul[so < 0 ? 0 : so];
+            const bool i_e_null = se < 0 || !SH.present[se] || !pres[se < 0 ? 0 : se] || inul[se < 0 ? 0 : se];
+            const bool d_e_null = se < 0 || !SH.present[se] || !pres[se < 0 ? 0 : se] || dnul[se < 0 ? 0 : se];
+            const bool i_out_null = m_o_null && i_e_null, d_out_null = m_o_null && d_e_null;
+            pres[s] = !(m_sub_null && i_out_null && d_out_null);
+            const int sub_lo = m_sub_null ? 1 : klo[ss < 0 ? 0 : ss], sub_hi = m_sub_null ? -1 : khi[ss < 0 ? 0 : ss];
+            const int o_lo = m_o_null ? 1 : klo[so < 0 ? 0 : so], o_hi = m_o_null ? -1 : khi[so < 0 ? 0 : so];
+            const bool e_none = i_e_null && d_e_null;
+            const int e_lo = e_none ? 1 : klo[se < 0 ? 0 : se], e_hi = e_none ? -1 : khi[se < 0 ? 0 : se];
+            klo[s] = min(min(sub_lo, o_lo), e_lo) - 1;
+            khi[s] = max(max(sub_hi, o_hi), e_hi) + 1;
+            mnul[s] = false; inul[s] = i_out_null; dnul[s] = d_out_null;
+#pragma unroll
+            for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {   // affine_wfa_compute_offsets, wfa.c:231-266
+                const int kk = k - SH.kmin;
+                const int km1 = kk > 0 ? kk - 1 : 0, kp1 = kk + 1 < KW ? kk + 1 : KW - 1;   // clamped: only read when in range
+                const int sso = so < 0 ? 0 : so, sse = se < 0 ? 0 : se, sss = ss < 0 ? 0 : ss;
+                int ins = -10;
+                {
+                    const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? Mv[sso][km1] : kLaneNull;
+                    const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? Iv[sse][km1] : kLaneNull;
+                    const int v = (ins_g == kLaneNull && ins_i == kLaneNull) ? kLaneNull : max(ins_g, ins_i) + 1;
+                    ins = i_out_null ? -10 : v;
+                    Iv[s][kk] = v;
+                }
+                int del = -10;
+                {
+                    const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? Mv[sso][kp1] : kLaneNull;
+                    const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? Dv[sse][kp1] : kLaneNull;
+                    const int v = max(del_g, del_d);
+                    del = d_out_null ? -10 : v;
+                    Dv[s][kk] = v;
+                }
+                int sub = -10;
+                if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? Mv[sss][kk] + 1 : kLaneNull;
+                Mv[s][kk] = max(del, max(sub, ins));
+            }
+        }
+        // affine_wfa_extend (wfa.c:186-208), bit-parallel
+#pragma unroll
+        for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {
+            const int kk = k - SH.kmin;
+            int off = Mv[s][kk];
+            const int v = off - k;
+            const int limit = min(plen, tlen - k);
+            if (off >= 0 && v >= 0 && v < limit) {
+                const int stop = min(first_stop<NP>(dk[kk], v), limit);
+                off += stop - v;
+            }
+            Mv[s][kk] = off;
+        }
+        // affine_wfa_reduce_wvs (WFA-adaptive, wfa.c:69-140): only shapes that can hold >= 10 diagonals get this code
+        if (SH.hi[s] - SH.lo[s] + 1 >= 10) {
+            const bool apply = reduce && pres[s] && !mnul[s] && (khi[s] - klo[s] + 1) >= 10;
+            int dist[KW];
+            int min_distance = max(plen, tlen);
+#pragma unroll
+            for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {
+                const int kk = k - SH.kmin;
+                const int off = Mv[s][kk];
+                dist[kk] = max(plen - (off - k), tlen - off);
+                if (klo[s] <= k && k <= khi[s]) min_distance = min(min_distance, dist[kk]);
+            }
+            // first / last diagonal of [klo, khi] within 50 of the best (the reference's two scans stop there)
+            int kfirst = 0x7fffffff, klast = -0x7fffffff;
+#pragma unroll
+            for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {
+                const int kk = k - SH.kmin;
+                const bool ok = klo[s] <= k && k <= khi[s] && (dist[kk] - min_distance) <= 50;
+                kfirst = ok ? min(kfirst, k) : kfirst;
+                klast = ok ? max(klast, k) : klast;
+            }
+            int nklo = klo[s], nkhi = khi[s];
+            const int top_limit = min(ak - 1, khi[s]);
+            if (klo[s] < top_limit) nklo = min(top_limit, kfirst);
+            const int bottom_limit = max(ak + 1, nklo);
+            if (khi[s] > bottom_limit) nkhi = max(bottom_limit, klast);
+            const bool kill = nklo > nkhi;
+            if (apply) {
+                mnul[s] = kill; inul[s] = inul[s] || kill; dnul[s] = dnul[s] || kill;
+                klo[s] = kill ? klo[s] : nklo;
+                khi[s] = kill ? khi[s] : nkhi;
+            }
+        }
+        // affine_wfa_end_reached (wfa.c:210-230); the run-time MAX_SCORE cap is a term of the test (wfa.c:368-376)
+        {
+            int m_end = kLaneNull;
+#pragma unroll
+            for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) m_end = (k == ak) ? Mv[s][k - SH.kmin] : m_end;
+            if (!done && pres[s] && !mnul[s] && klo[s] <= ak && ak <= khi[s] && m_end >= tlen && s <= ms_run) { done = true; score = s; }
+        }
+        if (__ballot(!done && active) == 0ull) break;   // every pair of this wave has finished
+    }
+    if (!done) score = ms_run + 1;                      // wfa.c:368-376
+    return score;
+}
+
+template <int X, int O, int E, int MAXS, int RS, bool BT, bool DYN = false>
 __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs a)
 {
     constexpr WfShape<X, O, E, MAXS> SH{};
-    static_assert(SH.maxw < 10, "WFA-adaptive reduction could fire: shape not eligible for the static kernel");
+    static_assert(DYN || SH.maxw < 10, "WFA-adaptive reduction could fire: shape needs the dynamic-bounds score loop (DYN)");
+    static_assert(!(DYN && BT), "the dynamic-bounds score loop is score-only");
     static_assert(RS % 16 == 0 && (RS / 16) % 2 == 1, "row stride must be an odd number of 16-B slots");
     constexpr int NCH = RS / 16;                // 1-KiB DMA pieces per array per group (64 rows * RS / 1024)
     constexpr int NP = RS / 16;                 // packed dwords per sequence
@@ -454,6 +584,10 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
         int Mv[MAXS + 1][KW], Iv[MAXS + 1][KW], Dv[MAXS + 1][KW];
         int score = MAXS + 1;
         bool done = false;
+        if constexpr (DYN) {
+            score = wfa_scores_dynamic<X, O, E, MAXS, NP, KW>(dk, plen, tlen, ms_run, (a.p.flags & AIM_FLAG_REDUCE) != 0, active);
+            done = score <= ms_run;
+        } else {
 #pragma unroll
         for (int s = 0; s <= MAXS; ++s) {
             // runtime MAX_SCORE below the template cap: the reference leaves its loop as "exceeded" when the score passes
@@ -515,6 +649,7 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
             if (__ballot(!done && active) == 0ull) break;   // every pair of this wave has finished
         }
         if (!done) score = ms_run + 1;                              // wfa.c:368-376
+        }
         AIM_STAMP(5);                           // diagonals + WFA
 
         int begin_offset = plen + tlen - 1;     // edit_cigar_allocate, wfa.c:57-67
@@ -693,12 +828,15 @@ __global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs 
 // ---------------------------------------------------------------------------------------------------
 constexpr uint32_t kLaneGrid = 256 * AIM_LANE_WGS_PER_CU;   // single-wave workgroups, LDS 2 x 64 rows x 112 B = 14 KiB each
 
-inline bool wfa_lane_supported(const aim_params_t &p)
+constexpr int kLaneDynMaxScore = 10;   // the dynamic-bounds instantiation: MAX_SCORE 6..10 (l = 100: e up to 2 %), score-only
+
+inline bool wfa_lane_supported(const aim_params_t &p, bool allow_dynamic = true)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
     if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the reference's default penalties
-    if (p.max_score > 5) return false;
-    return p.read_size == 80 || p.read_size == 112;   // odd number of 16-B slots per row (conflict-free row reads)
+    if (p.read_size != 80 && p.read_size != 112) return false;           // odd number of 16-B slots per row (conflict-free row reads)
+    if (p.max_score <= 5) return true;
+    return allow_dynamic && p.max_score <= kLaneDynMaxScore && !(p.flags & AIM_FLAG_BACKTRACE);
 }
 
 inline size_t wfa_lane_todo_bytes(uint32_t n_pairs) { return ((size_t)(LANE_TODO_LIST + n_pairs) * 4 + 255) & ~(size_t)255; }
@@ -723,6 +861,11 @@ inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block
         if (bt) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS, true>), dim3(grid), dim3(kWave), lds, s, ka);    \
         else hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS, false>), dim3(grid), dim3(kWave), lds, s, ka);      \
     } while (0)
+    if (p.max_score > 5) {   // dynamic-bounds shape (score-only)
+        if (p.read_size == 80) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, kLaneDynMaxScore, 80, false, true>), dim3(grid), dim3(kWave), lds, s, ka);
+        else hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, kLaneDynMaxScore, 112, false, true>), dim3(grid), dim3(kWave), lds, s, ka);
+        return;
+    }
     switch (p.read_size) {
     case 80: AIM_LANE_LAUNCH(80); break;
     case 112: AIM_LANE_LAUNCH(112); break;

@@ -47,6 +47,7 @@ def run(name, cfg, reps=3):
             k = s.timers()[1] - k0
             best = k if best is None else min(best, k)
         res, ops = s.pull(0)
+        plan = s.plan_describe(0)
     cells = float((req["pattern_len"].astype(np.int64) * req["text_len"]).sum())
     alg = float(req["pattern_len"].sum() + req["text_len"].sum() + 16 * cfg["n"])
     if ops is not None:
@@ -54,7 +55,8 @@ def run(name, cfg, reps=3):
     print(json.dumps({"config": name, "kernel": capi.load().aim_kernel_name(__import__("ctypes").byref(params)).decode(),
                       "pairs": cfg["n"], "max_score": ms, "read_size": rs, "kernel_ms": best,
                       "pairs_per_s": cfg["n"] / (best * 1e-3), "gcups": cells / (best * 1e-3) / 1e9,
-                      "algorithmic_GBps": alg / (best * 1e-3) / 1e9, "mean_score": float(res["score"].mean())}), flush=True)
+                      "algorithmic_GBps": alg / (best * 1e-3) / 1e9, "algorithmic_bytes": alg, "mean_score": float(res["score"].mean()),
+                      "plan": plan}), flush=True)
 
 
 if __name__ == "__main__":

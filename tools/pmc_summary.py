@@ -45,8 +45,20 @@ def main():
 
     # ---- pass 0: kernel trace + stats
     d = os.path.join(work, "stats")
-    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "p", "--output-format", "csv", "--"] + cmd,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1800)
+    r0 = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", d, "-o", "p", "--output-format", "csv", "--"] + cmd,
+                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=1800, text=True)
+    for line in (r0.stdout or "").splitlines():   # the profiled program may state its own algorithmic bytes / plan (tools/bench_configs.py)
+        if line.startswith("{"):
+            try:
+                j = json.loads(line)
+            except Exception:
+                continue
+            if a.alg_bytes is None and "algorithmic_bytes" in j:
+                a.alg_bytes = float(j["algorithmic_bytes"])
+            if "plan" in j:
+                summary["plan"] = j["plan"]
+            if "config" in j and isinstance(j["config"], dict) and "plan" in j["config"]:
+                summary["plan"] = j["config"]["plan"]
     durs, disp = [], None
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
