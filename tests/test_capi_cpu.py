@@ -81,7 +81,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112))) == b"wfa_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True))) == b"wfa_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True, mismatch=4))) == b"wfa_group_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112))) == b"wfa_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112))) == b"wfa_lane_kernel"          # round 2: dynamic-bounds shape, score-only
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112, backtrace=True))) == b"wfa_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 11, 112))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 250, 1064, backtrace=True, reduce=True))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 2000, 8000))) == b"wfa_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 500, 10112, backtrace=True))) == b"dp_wave_kernel"
@@ -115,11 +117,11 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
     assert (g, ring_m) == (64, 6) and per_cu >= 12     # exact-size ring: max(x, o+e) + 1 = 6 rows
     assert G(400, 0.10)[0] == 64                # 4 per CU at G = 16 -> a wavefront per pair
     assert G(250, 0.10)[0] == 16                # 6 per CU at G = 16 stays (measured break-even)
-    assert G(100, 0.10)[0] == 16 and G(100, 0.02)[0] <= 16
+    assert G(100, 0.10)[0] == 16 and G(100, 0.02, AIM_NO_LANE_EXT="1")[0] <= 16   # (e = 2 % score-only now runs on wfa_lane_kernel)
     assert G(1000, 0.05, AIM_GROUP_G="16")[0] == 16 and G(100, 0.10, AIM_GROUP_G="64")[0] == 64
     # residency comes from the 1280-B LDS granule (aim_device.hpp: lds_workgroups_per_cu), capped at 16: a byte-granular
     # estimate would say 12 for the 12.8-KB and 13.3-KB workgroups, which measurably breaks into two rounds
-    assert G(100, 0.02)[2] == 11 and G(250, 0.05)[2] == 11
+    assert G(100, 0.02, AIM_NO_LANE_EXT="1")[2] == 11 and G(250, 0.05)[2] == 11
     assert G(100, 0.05)[2] == 14 and G(100, 0.10)[2] == 16 and G(1000, 0.05)[2] == 14   # 11.2 KB / 9.8 KB / 10.7 KB workgroups
 
 

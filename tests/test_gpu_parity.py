@@ -303,7 +303,7 @@ def test_fast_path_handles_non_acgt_bytes_itself(gpu, sample_bytes, err_bytes):
     params = engine.make_params("wfa", 5, 112, reduce=True)
     assert lib.aim_kernel_name(C.byref(params)) == b"wfa_lane_kernel"
     assert lib.aim_scratch_bytes(C.byref(params), 1 << 22) == 256     # a token: the kernel uses no scratch
-    gparams = engine.make_params("wfa", 10, 112, reduce=True)      # MAX_SCORE 10 -> wfa_group_kernel
+    gparams = engine.make_params("wfa", 12, 112, reduce=True)      # MAX_SCORE 12 -> wfa_group_kernel
     assert lib.aim_kernel_name(C.byref(gparams)) == b"wfa_group_kernel"
     for data in (sample_bytes, err_bytes):
         req, pat, txt = engine.parse_pairs(data, 112)
@@ -841,3 +841,28 @@ def test_two_slots_pipeline_many_batches(gpu):
             out = s.wait(0, b & 1)
             got.append(engine.format_output_runs(out["cig"], out["runs"]))
     assert b"".join(got) == want
+
+
+@pytest.mark.parametrize("rs,l", [(112, 100), (80, 70)])
+@pytest.mark.parametrize("reduce", [True, False])
+def test_wfa_lane_dynamic_bounds_shape(gpu, rs, l, reduce):
+    """MAX_SCORE 6..10 at the default penalties runs on wfa_lane_kernel's dynamic-bounds instantiation (score-only): wavefronts
+    reach 11 and 13 diagonals, so WFA-adaptive's reduction (wfa.c:69-140) fires and klo/khi/null flags become per-pair data.
+    Error rates up to 10 % make the reduction actually cut, pairs exceed the cap, and non-ACGT pairs take the raw path."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    lib = capi.load()
+    for ms in (6, 8, 10):
+        for err in (0.02, 0.05, 0.10):
+            params = engine.make_params("wfa", ms, rs, reduce=reduce)
+            assert lib.aim_kernel_name(C.byref(params)) == b"wfa_lane_kernel"
+            req, pat, txt = engine.gen_pairs(900 + ms, 0, 6000, l, err, rs)
+            for i in range(0, 6000, 97):
+                pat[i, i % (l // 2)] = ord("N")
+            res, _, ores = _compare("wfa", params, req, pat, txt)
+            assert (res["score"] == ms + 1).any() or err < 0.05      # the cap is exercised
+    # the reduction changes at least one score somewhere in this family (otherwise the dynamic path is untested)
+    req, pat, txt = engine.gen_pairs(4321, 0, 20000, l, 0.10, rs)
+    a, _ = engine.align(engine.make_params("wfa", 10, rs, reduce=True), req, pat, txt)
+    b, _ = engine.align(engine.make_params("wfa", 10, rs, reduce=False), req, pat, txt)
+    print("pairs whose score differs with / without reduction:", int((a["score"] != b["score"]).sum()))

@@ -59,10 +59,10 @@ def main():
             # default penalties, MAX_SCORE 0..5, READ_SIZE 80 or 112, any pair count (partial last groups), non-ACGT bytes
             rs = rng.choice([80, 112])
             l = rng.randint(1, rs - 12)
-            e = rng.choice([0.0, 0.01, 0.02, 0.03, 0.05])
-            ms = rng.randint(0, 5)
+            e = rng.choice([0.0, 0.01, 0.02, 0.03, 0.05, 0.08, 0.10])
+            ms = rng.randint(0, 10)                       # 6..10: the dynamic-bounds shape (score-only; WFA-adaptive's reduction can fire)
             n = rng.choice([1, 63, 64, 65, 127, 1000, 4097, 20000])
-            kw = dict(backtrace=rng.random() < 0.6, reduce=rng.random() < 0.7)
+            kw = dict(backtrace=rng.random() < 0.6 and ms <= 5, reduce=rng.random() < 0.7)
             params = engine.make_params("wfa", ms, rs, **kw)
             for k in list(os.environ):
                 if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
