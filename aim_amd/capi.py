@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIM_LIB") or os.path.join(_HERE, "libaim_hip.so")   # AIM_LIB: A/B builds of the same ABI
 
 AIM_OK, AIM_EINVAL, AIM_ENODEV, AIM_ENOMEM, AIM_ESTATE, AIM_EALIGN = 0, -1, -2, -3, -4, -5
-ALGO_NW, ALGO_SWG, ALGO_WFA = 0, 1, 2
-ALGO_BY_NAME = {"nw": ALGO_NW, "swg": ALGO_SWG, "wfa": ALGO_WFA}
+ALGO_NW, ALGO_SWG, ALGO_WFA, ALGO_GENASM = 0, 1, 2, 3
+ALGO_BY_NAME = {"nw": ALGO_NW, "swg": ALGO_SWG, "wfa": ALGO_WFA, "genasm": ALGO_GENASM}
 FLAG_BACKTRACE, FLAG_REDUCE, FLAG_SWG_W16, FLAG_REQ8, FLAG_RES8 = 1, 2, 4, 8, 16
 PAIR_OK, PAIR_WFA_NO_LINK, PAIR_SWG_NO_OP, PAIR_NOMEM = 0, 1, 2, 3
 

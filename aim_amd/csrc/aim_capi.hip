@@ -25,6 +25,7 @@
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
 #include "batch_io.hpp"
+#include "genasm_wave.hpp"
 
 namespace {
 
@@ -50,7 +51,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5 };
 
 struct Plan {
     KernelId kid;
@@ -136,10 +137,18 @@ uint64_t stateless_budget_bytes(const aim::Knobs &kn)
 
 int validate_params(const aim_params_t &p)
 {
-    if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG && p.algo != AIM_ALGO_WFA)
+    if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG && p.algo != AIM_ALGO_WFA && p.algo != AIM_ALGO_GENASM)
         return fail(AIM_EINVAL, "unknown algorithm %d", p.algo);
     if (p.read_size <= 0 || (p.read_size & 7)) return fail(AIM_EINVAL, "read_size must be a positive multiple of 8 (got %d)", p.read_size);
     if (p.max_score < 0) return fail(AIM_EINVAL, "max_score must be >= 0");
+    if ((p.flags & AIM_FLAG_REQ8) && p.read_size >= 32760)
+        return fail(AIM_EINVAL, "AIM_FLAG_REQ8 carries int16 lengths: read_size must be < 32760");
+    if (p.algo == AIM_ALGO_GENASM) {   // no penalties, no score cap; lengths are int32
+        if ((p.flags & AIM_FLAG_RES8) && (p.flags & AIM_FLAG_BACKTRACE))
+            return fail(AIM_EINVAL, "AIM_FLAG_RES8 (idx, score results) cannot be combined with AIM_FLAG_BACKTRACE");
+        if (p.read_size > (1 << 24)) return fail(AIM_EINVAL, "read_size must be <= 2^24");
+        return AIM_OK;
+    }
     // same admission rule as the launchers (run-wfa-pim-wram.py:41-43): m <= 0 and x, g, a > 0
     if (p.algo == AIM_ALGO_NW) {
         if (p.mismatch <= 0 || p.gap_i <= 0 || p.gap_d <= 0) return fail(AIM_EINVAL, "NW penalties must be x, g > 0");
@@ -162,6 +171,12 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
 {
     int rc = AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    if (p.algo == AIM_ALGO_GENASM) {
+        pl->kid = K_GENASM;
+        aim::genasm_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+        pl->scratch_total = 256;
+        return AIM_OK;
+    }
     if (p.algo == AIM_ALGO_WFA) {
         const bool lane_ok = !kn.force_wave && !pl->no_lane && aim::wfa_lane_supported(p, !kn.no_lane_ext);
         aim::GroupCfg gc;
@@ -286,6 +301,7 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
     case K_WFA_GROUP: return "wfa_group_kernel";
     case K_DP_LANE: return p_is_nw(&p) ? "nw_lane_kernel" : "swg_lane_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
+    case K_GENASM: return "genasm_wave_kernel";
     }
     return "";
 }
@@ -390,6 +406,9 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         break;
     case K_DP_WAVE:
         aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);
+        break;
+    case K_GENASM:
+        aim::genasm_launch(p, pl.grid, pl.lds, ka, stream);
         break;
     }
     HIP_TRY(hipGetLastError());
@@ -1124,7 +1143,7 @@ int aim_gen_pairs(uint64_t seed, uint64_t first_idx, uint32_t n_pairs, int32_t l
     const int nedits = (int)std::ceil((double)len * error);
     if (len + nedits > read_size) return fail(AIM_EINVAL, "read_size %d too small for len %d + %d edits", read_size, len, nedits);
     static const char kBase[4] = {'A', 'C', 'G', 'T'};
-    for (uint32_t i = 0; i < n_pairs; ++i) {
+    auto one = [&](uint32_t i) {
         uint64_t st = seed * 0xD1342543DE82EF95ull + (first_idx + i) * 0x2545F4914F6CDD1Dull + 0x632BE59BD9B4E019ull;
         char *p = patterns + (size_t)i * read_size;
         char *t = texts + (size_t)i * read_size;
@@ -1154,6 +1173,18 @@ int aim_gen_pairs(uint64_t seed, uint64_t first_idx, uint32_t n_pairs, int32_t l
         requests[i].text_len = cur;
         requests[i].padding = 0;
         requests[i].idx = (uint32_t)(first_idx + i);
+    };
+    // pair i depends only on (seed, first_idx + i): long reads (each edit moves up to len bytes) are generated by all cores
+    const uint64_t work = (uint64_t)n_pairs * (uint64_t)len * (uint64_t)(nedits + 1);
+    unsigned nt = work > (1ull << 28) ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u) : 1u;
+    if (nt > n_pairs) nt = n_pairs ? n_pairs : 1;
+    if (nt <= 1) {
+        for (uint32_t i = 0; i < n_pairs; ++i) one(i);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] { for (uint32_t i = t; i < n_pairs; i += nt) one(i); });
+        for (auto &x : th) x.join();
     }
     return AIM_OK;
 }

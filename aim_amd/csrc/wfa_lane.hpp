@@ -427,7 +427,7 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
 }
 
 template <int X, int O, int E, int MAXS, int RS, bool BT, bool DYN = false>
-__global__ __launch_bounds__(64, AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs a)
+__global__ __launch_bounds__(64, DYN ? 2 : AIM_LANE_MIN_WAVES) void wfa_lane_kernel(KArgs a)   // DYN: 2 waves per SIMD (<= 256 VGPRs), else the grid runs in two rounds
 {
     constexpr WfShape<X, O, E, MAXS> SH{};
     static_assert(DYN || SH.maxw < 10, "WFA-adaptive reduction could fire: shape needs the dynamic-bounds score loop (DYN)");

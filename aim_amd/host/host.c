@@ -118,7 +118,9 @@ static void index_lines(input_t *in, int nthreads)
 typedef struct {
     uint32_t n;                      /* pairs in this job */
     size_t first_pair;               /* global index of pair 0 */
-    aim_request8_t *req;             /* the reference's own 8-byte WFA request_t (AIM_FLAG_REQ8) */
+    void *req;                       /* aim_request8_t[] (the reference's own 8-byte WFA request_t, AIM_FLAG_REQ8) when lengths
+                                        fit int16, else aim_request_t[] (long reads) */
+    int req8;
     uint32_t *pkP, *pkT;             /* packed rows (2 bits per base) */
     uint32_t *raw_idx; char *rawP, *rawT; uint32_t n_raw;   /* side list: pairs with a byte outside A/C/G/T */
     char *pat, *txt;                 /* ASCII rows: --no-pack, or a batch whose side list overflowed (allocated lazily) */
@@ -204,7 +206,13 @@ static void pack_range(int tid, int nt, void *arg)
         for (size_t i = lo; i < hi; ++i) {
             const char *p, *t; long pl, tl;
             pair_lines(pk->in, j->first_pair + i, &p, &pl, &t, &tl);
-            j->req[i].pattern_len = (int16_t)pl; j->req[i].text_len = (int16_t)tl; j->req[i].idx = (uint32_t)(j->first_pair + i);
+            if (j->req8) {
+                aim_request8_t *r = (aim_request8_t *)j->req + i;
+                r->pattern_len = (int16_t)pl; r->text_len = (int16_t)tl; r->idx = (uint32_t)(j->first_pair + i);
+            } else {
+                aim_request_t *r = (aim_request_t *)j->req + i;
+                r->pattern_len = (int32_t)pl; r->text_len = (int32_t)tl; r->padding = 0; r->idx = (uint32_t)(j->first_pair + i);
+            }
             if (j->ascii) {
                 char *dp = j->pat + i * rs, *dt = j->txt + i * rs;
                 memcpy(dp, p, (size_t)pl); memset(dp + pl, 0, (size_t)(rs - pl));
@@ -386,6 +394,7 @@ int main(int argc, char *argv[])
             if (!strcmp(v, "nw")) p.algo = AIM_ALGO_NW;
             else if (!strcmp(v, "swg")) p.algo = AIM_ALGO_SWG;
             else if (!strcmp(v, "wfa")) p.algo = AIM_ALGO_WFA;
+            else if (!strcmp(v, "genasm")) p.algo = AIM_ALGO_GENASM;
             else { fprintf(stderr, "unknown --algo %s\n", v); exit(1); }
             ++i;
         }
@@ -406,7 +415,8 @@ int main(int argc, char *argv[])
     if (threads < 1) threads = 1;
     if (threads > MAX_THREADS) threads = MAX_THREADS;
     const int backtrace = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    p.flags |= AIM_FLAG_REQ8;                                   /* 8-byte WFA request_t on the wire (common.h:172-177) */
+    const int use_req8 = p.read_size < 32760;                   /* int16 lengths */
+    if (use_req8) p.flags |= AIM_FLAG_REQ8;                     /* 8-byte WFA request_t on the wire (common.h:172-177) */
     if (!backtrace) p.flags |= AIM_FLAG_RES8;                   /* score-only: {idx, score} back */
 #if defined(__x86_64__)
     g_simd = __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3") && __builtin_cpu_supports("bmi2");
@@ -469,8 +479,17 @@ int main(int argc, char *argv[])
     }
     const size_t rs = (size_t)p.read_size;
     const uint32_t dw = (uint32_t)(p.read_size + 15) / 16u;
+    /* device-side CIGAR runs: room for max(8, READ_SIZE/4 + 2) runs per pair (an alignment with e errors has <= 2e+1 runs; the
+       launchers size READ_SIZE for e <= l*error), at most 1 GiB per job -- longer reads get smaller batches */
+    const uint32_t rpp = (uint32_t)(p.read_size / 4 + 2 > 8 ? p.read_size / 4 + 2 : 8);
+    if (backtrace && !full_ops && (uint64_t)batch * rpp > (1ull << 28)) {
+        batch = (uint32_t)((1ull << 28) / rpp);
+        if (batch < 64) batch = 64;
+    }
+    /* also bound the pinned / device sequence buffers of one job to ~1 GiB (long reads) */
+    while (batch > 64 && (uint64_t)batch * rs > (1ull << 30)) batch /= 2;
+    const uint32_t runs_cap = (backtrace && !full_ops) ? batch * rpp : 0;
     const uint32_t max_raw = no_pack ? 0 : (batch / 16 < 1024 ? (batch < 1024 ? batch : 1024) : batch / 16);
-    const uint32_t runs_cap = (backtrace && !full_ops) ? ((uint64_t)batch * 8 > 0x7fffffffu ? 0x7fffffffu : batch * 8) : 0;
     rc = pack_only ? 0 : aim_set_configure_slots(set, &p, batch, slots, no_pack ? 0 : max_raw, runs_cap);
     if (rc) {
         if (rc == AIM_EINVAL) { printf("%s\n", aim_last_error()); exit(1); }
@@ -480,7 +499,8 @@ int main(int argc, char *argv[])
     for (uint32_t k = 0; k < ring; ++k) {
         job_t2 *j = &jobs[k];
         j->device = k % gpus; j->slot = k / gpus;
-        j->req = g_big_alloc((size_t)batch * sizeof(aim_request8_t));
+        j->req8 = use_req8;
+        j->req = g_big_alloc((size_t)batch * (use_req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t)));
         j->is_raw = plain(batch);
         if (no_pack) { j->pat = g_big_alloc((size_t)batch * rs); j->txt = g_big_alloc((size_t)batch * rs); }
         else {
@@ -503,7 +523,7 @@ int main(int argc, char *argv[])
             pack_job(&inp, j, p.read_size, max_raw, batch, no_pack, threads);
             uint32_t hdr[4] = {j->n, (uint32_t)j->ascii, j->n_raw, (uint32_t)p.read_size};
             fwrite(hdr, 4, 4, df);
-            fwrite(j->req, sizeof(aim_request8_t), j->n, df);
+            fwrite(j->req, j->req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t), j->n, df);
             if (j->ascii) { fwrite(j->pat, rs, j->n, df); fwrite(j->txt, rs, j->n, df); }
             else {
                 fwrite(j->pkP, (size_t)dw * 4, j->n, df); fwrite(j->pkT, (size_t)dw * 4, j->n, df);
@@ -526,7 +546,7 @@ int main(int argc, char *argv[])
             if (first) printf("Retrieve results\n");
             first = 0;
             rc = aim_set_wait(set, j->device, j->slot, &j->n_runs);
-            if (rc == AIM_ENOMEM && j->cig) {   /* more than 8 runs per pair on average: re-run this batch with full ops rows */
+            if (rc == AIM_ENOMEM && j->cig) {   /* more runs than READ_SIZE/4 + 2 per pair on average */
                 fprintf(stderr, "AIM-HIP: run buffer overflow, use --full-ops for this input\n");
                 exit(1);
             }

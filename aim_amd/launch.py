@@ -37,6 +37,8 @@ def _parser(algo):
     ap.add_argument("-b", "--backtrace", action="store_true", help="Enable backtracing")
     if algo == "wfa":
         ap.add_argument("-r", "--reduced", action="store_true", help="Enable WFA-Adaptive")
+    if algo == "genasm":
+        ap.add_argument("-r", "--reduced", action="store_true", help="accepted and ignored")
     ap.add_argument("-t", "--nr_of_tasklets", type=int, help="accepted for compatibility; tasklets do not exist on MI355X")
     ap.add_argument("-d", "--nr_of_dpus", type=int, help="logical NR_DPUs of the reference partition rule (default=1)")
     ap.add_argument("--gpus", type=int, default=1, help="MI355X devices to shard over")
@@ -99,7 +101,7 @@ def host_command(cfg):
         cmd += ["--gap-o", str(cfg["gap_o"]), "--gap-e", str(cfg["gap_e"])]
     if cfg["backtrace"]:
         cmd.append("--backtrace")
-    if cfg["reduce"]:
+    if cfg["reduce"] and cfg["algo"] == "wfa":
         cmd.append("--reduce")
     if cfg["swg_w16"]:
         cmd.append("--swg-w16")
@@ -108,8 +110,8 @@ def host_command(cfg):
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
-    if not argv or argv[0] not in ("nw", "swg", "wfa"):
-        print("usage: python -m aim_amd.launch {nw,swg,wfa} -i IN -l LEN -e ERR -n N [options]")
+    if not argv or argv[0] not in ("nw", "swg", "wfa", "genasm"):
+        print("usage: python -m aim_amd.launch {nw,swg,wfa,genasm} -i IN -l LEN -e ERR -n N [options]")
         return 2
     cfg = parse(argv[0], argv[1:])
     print("run-time configuration:", flag_line(cfg))

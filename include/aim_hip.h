@@ -37,6 +37,11 @@ extern "C" {
 #define AIM_ALGO_NW 0  /* NW/DPU-{WRAM,MRAM}   nw_compute      nw.c:109-153   */
 #define AIM_ALGO_SWG 1 /* SWG/DPU-{WRAM,MRAM}  swg_compute     swg.c:121-171  */
 #define AIM_ALGO_WFA 2 /* WFA/DPU-{WRAM,MRAM}  affine_wfa_compute wfa.c:342-379 */
+#define AIM_ALGO_GENASM 3 /* aim-genasm (BASELINE config 5): bit-vector edit distance + windowed traceback for long reads.
+                             PARITY UNPINNED: the reference tree holds only an un-pinned, empty submodule
+                             (.gitmodules:1-3); this implements the published GenASM algorithm (MICRO 2020) as restated
+                             in oracle/genasm_oracle.c.  score = edit distance of the reported alignment; penalties and
+                             max_score are ignored; ops are written forward (begin_offset = 0). */
 
 /* ---- flags: the reference's compile-time -D switches, now run time ------ */
 #define AIM_FLAG_BACKTRACE 0x1u /* -DBACKTRACE (run-*-pim-*.py -b)            */

@@ -637,6 +637,8 @@ static int align_pair_scr(const orc_params_t *p, orc_scratch_t *scr, const char 
         return (w == 1) ? swg_pair_w8(p, scr, pattern, plen, text, tlen, ops, res)
                         : swg_pair_w16(p, scr, pattern, plen, text, tlen, ops, res);
     }
+    case ORC_ALGO_GENASM:
+        return orc_genasm_pair(p, pattern, plen, text, tlen, p->backtrace ? ops : NULL, res);
     default:
         return -1;
     }

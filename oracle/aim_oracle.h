@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-enum { ORC_ALGO_NW = 0, ORC_ALGO_SWG = 1, ORC_ALGO_WFA = 2 };
+enum { ORC_ALGO_NW = 0, ORC_ALGO_SWG = 1, ORC_ALGO_WFA = 2, ORC_ALGO_GENASM = 3 /* genasm_oracle.c: PARITY UNPINNED */ };
 
 enum {
     ORC_OK = 0,
@@ -70,6 +70,9 @@ typedef struct orc_result {
  * p->backtrace is set (ignored otherwise).  Returns status (also in res). */
 int orc_align_pair(const orc_params_t *p, const char *pattern, int plen,
                    const char *text, int tlen, char *ops, orc_result_t *res);
+
+/* GenASM (genasm_oracle.c): windowed Bitap distance + traceback, the published algorithm (parity unpinned). */
+int orc_genasm_pair(const orc_params_t *p, const char *pattern, int plen, const char *text, int tlen, char *ops, orc_result_t *res);
 
 /* Batch in the reference's wire layout: patterns/texts are [n][read_size]
  * byte rows, ops is [n][2*read_size] (may be NULL without backtrace).

@@ -8,7 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libaim_oracle.so")
-ALGO = {"nw": 0, "swg": 1, "wfa": 2}
+ALGO = {"nw": 0, "swg": 1, "wfa": 2, "genasm": 3}
 
 
 class OrcParams(C.Structure):

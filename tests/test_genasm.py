@@ -1,0 +1,144 @@
+"""GenASM (BASELINE config 5).  PARITY UNPINNED: the reference tree holds only an un-pinned, empty submodule
+(/root/reference/.gitmodules:1-3), so there is nothing of AIM's to compare with.  What is tested: (CPU) the oracle's
+restatement of the published algorithm against the defining properties of an alignment and against the exact edit
+distance on small inputs; (GPU) the HIP kernel against that oracle, bit for bit, up to config 5's read length."""
+import numpy as np
+import pytest
+
+
+def _edit_distance(a, b):
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def _check_alignment(req, pat, txt, res, ops):
+    """The ops consume exactly the pattern (M/X/D) and the text (M/X/I), 'M' only over equal bytes, 'X' only over different
+    ones, and score = number of non-M operations."""
+    for i in range(len(req)):
+        pl, tl = int(req["pattern_len"][i]), int(req["text_len"][i])
+        assert res["begin_offset"][i] == 0 and res["status"][i] == 0
+        o = ops[i, : res["end_offset"][i]]
+        is_m, is_x, is_i, is_d = (o == ord("M")), (o == ord("X")), (o == ord("I")), (o == ord("D"))
+        assert (is_m | is_x | is_i | is_d).all()
+        adv_p = (is_m | is_x | is_d).astype(np.int64)
+        adv_t = (is_m | is_x | is_i).astype(np.int64)
+        assert adv_p.sum() == pl and adv_t.sum() == tl, i
+        pi, ti = np.cumsum(adv_p) - adv_p, np.cumsum(adv_t) - adv_t
+        diag = is_m | is_x
+        assert ((pat[i, pi[diag]] == txt[i, ti[diag]]) == is_m[diag]).all(), i
+        assert int((~is_m).sum()) == int(res["score"][i]), i
+
+
+@pytest.mark.parametrize("l,err,n", [(1, 0.0, 4), (30, 0.1, 300), (64, 0.05, 300), (100, 0.1, 300), (300, 0.25, 60), (1000, 0.1, 40)])
+def test_genasm_oracle_properties_and_upper_bound(built, l, err, n):
+    from aim_amd import engine
+    from oracle import oracle
+    rs = ((int(l * (1 + err)) + 8 + 7) // 8) * 8
+    req, pat, txt = engine.gen_pairs(7 + l, 0, n, l, err, rs)
+    for i in range(0, n, 11):
+        pat[i, i % l] = ord("N")                       # any byte is a character; equal bytes match
+    res, ops, worst = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), req["pattern_len"], req["text_len"], pat, txt, nthreads=4)
+    assert worst == 0
+    _check_alignment(req, pat, txt, res, ops)
+    sres, _, _ = oracle.align_batch(oracle.params("genasm", 0, rs), req["pattern_len"], req["text_len"], pat, txt, nthreads=2)
+    assert np.array_equal(sres["score"], res["score"])
+    if l <= 300:
+        exact = 0
+        for i in range(min(n, 80)):
+            ed = _edit_distance(pat[i, : req["pattern_len"][i]].tobytes(), txt[i, : req["text_len"][i]].tobytes())
+            assert res["score"][i] >= ed
+            exact += int(res["score"][i] == ed)
+        assert exact >= 0.8 * min(n, 80)              # the windowed heuristic is exact on most pairs
+
+
+def test_genasm_oracle_identical_and_disjoint_sequences(built):
+    from oracle import oracle
+    rs = 208
+    pat = np.zeros((3, rs), dtype=np.uint8); txt = np.zeros((3, rs), dtype=np.uint8)
+    pat[0, :200] = ord("A"); txt[0, :200] = ord("A")                       # identical
+    pat[1, :200] = ord("A"); txt[1, :200] = ord("C")                       # no character in common: the [spec] fallback window
+    pat[2, :150] = ord("G"); txt[2, :60] = ord("G")                        # text much shorter
+    plen = np.array([200, 200, 150], dtype=np.int32); tlen = np.array([200, 200, 60], dtype=np.int32)
+    res, ops, worst = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), plen, tlen, pat, txt)
+    assert worst == 0 and list(res["score"]) == [0, 200, 90]
+    req = np.zeros(3, dtype=[("pattern_len", "<i4"), ("text_len", "<i4")]); req["pattern_len"] = plen; req["text_len"] = tlen
+    _check_alignment(req, pat, txt, res, ops)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def gpu(built):
+    from aim_amd import capi
+    import ctypes as C
+    lib = capi.load()
+    n = C.c_int()
+    assert lib.aim_device_count(C.byref(n)) == 0 and n.value >= 1, "no HIP device visible"
+    return lib
+
+
+def _hip_vs_oracle(l, err, n, seed, backtrace, dirty=True, **mk):
+    from aim_amd import engine
+    from oracle import oracle
+    rs = ((int(l * (1 + err)) + 8 + 7) // 8) * 8
+    req, pat, txt = engine.gen_pairs(seed, 0, n, l, err, rs)
+    if dirty:
+        for i in range(0, n, 5):
+            pat[i, (7 * i) % l] = ord("N")
+    params = engine.make_params("genasm", 0, rs, backtrace=backtrace, **mk)
+    res, ops = engine.align(params, req, pat, txt)
+    ores, oops, worst = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=backtrace), req["pattern_len"], req["text_len"],
+                                           pat, txt, nthreads=16)
+    assert worst == 0
+    assert np.array_equal(res["score"], ores["score"]) and np.array_equal(res["idx"], req["idx"])
+    if not mk.get("res8"):
+        for f in ("max_operations", "begin_offset", "end_offset", "status"):
+            assert np.array_equal(res[f], ores[f]), f
+    if backtrace:
+        for i in range(n):
+            e = int(res["end_offset"][i])
+            assert np.array_equal(ops[i, :e], oops[i, :e]), i
+        _check_alignment(req, pat, txt, res, ops)
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backtrace", [True, False])
+@pytest.mark.parametrize("l,err,n", [(1, 0.0, 70), (30, 0.1, 500), (64, 0.05, 500), (100, 0.1, 2000), (300, 0.25, 300), (1000, 0.1, 300),
+                                     (5000, 0.02, 64), (10000, 0.1, 40)])
+def test_genasm_hip_matches_oracle(gpu, l, err, n, backtrace):
+    _hip_vs_oracle(l, err, n, 100 + l, backtrace)
+    if not backtrace:
+        _hip_vs_oracle(l, err, min(n, 100), 200 + l, False, res8=True)
+
+
+@pytest.mark.gpu
+def test_genasm_cfg5_l100000_e10(gpu):
+    """BASELINE config 5's shape: 100 kb reads at 10 % error (~2 600 dependent windows per pair), with CIGAR."""
+    res = _hip_vs_oracle(100000, 0.10, 24, 5, True, dirty=False)
+    assert res["score"].min() > 5000 and res["score"].max() < 12000
+
+
+@pytest.mark.gpu
+def test_genasm_through_the_host_cli(gpu, tmp_path):
+    """`python -m aim_amd.launch genasm` -> C host (packed input, device-side CIGAR runs) prints the oracle's alignment."""
+    import subprocess, sys
+    from conftest import ROOT
+    from aim_amd import engine
+    from oracle import oracle
+    l, err, n = 3000, 0.1, 60
+    rs = int(np.ceil((l + l * err + 7) / 8)) * 8
+    req, pat, txt = engine.gen_pairs(77, 0, n, l, err, rs)
+    inp = tmp_path / "in.seq"
+    inp.write_bytes(engine.pairs_to_text(req, pat, txt))
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, "-m", "aim_amd.launch", "genasm", "-i", str(inp), "-o", str(out), "-l", str(l), "-e", str(err),
+                        "-n", str(n), "-b"], capture_output=True, text=True, cwd=tmp_path, env=dict(__import__("os").environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout + r.stderr
+    ores, oops, _ = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), req["pattern_len"], req["text_len"], pat, txt, nthreads=8)
+    ores["idx"] = req["idx"]
+    assert out.read_bytes() == oracle.format_output(ores, oops, True)
