@@ -142,6 +142,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         const aim_request_t rq = rq_next;
+        // (Tried in round 2 and reverted: for G == 64 every bound / flag is wave-uniform, and moving that bookkeeping to SGPRs
+        // with v_readfirstlane cut 28 static VALU instructions per step -- and made cfg3 11 % SLOWER (8.21 -> 9.15 ms, same box):
+        // the scalar chain lengthened the wave's critical path more than the freed vector slots were worth.)
         const int plen = rq.pattern_len, tlen = rq.text_len;
         // ---- validate + pack: the G lanes of a group split the packed dwords of their pair ------------------------
         uint32_t bad = 0;
@@ -318,24 +321,35 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
                     part = 0x7fffffff;
                     for (int k = lo + g; k <= hi; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
+                        // The five source cells are fetched TOGETHER and unconditionally (every row is a valid LDS row of
+                        // wcap = 2*MAX_SCORE+3 entries and |k +- 1| <= MAX_SCORE+1, so the addresses are always in bounds);
+                        // AFFINE_WAVEFRONT_COND_FETCH's range / null tests then select. Guarded reads compiled to one
+                        // exec-masked branch and one LDS round trip EACH: five dependent round trips per cell.
+                        const int raw_mo_m1 = r_mo[k - 1], raw_ie_m1 = r_ie[k - 1], raw_mo_p1 = r_mo[k + 1], raw_de_p1 = r_de[k + 1],
+                                  raw_ms = r_ms[k];
                         int ins = -10;
-                        if (!i_out_null) {
-                            const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? (int)r_mo[k - 1] : kGrpNull;
-                            const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? (int)r_ie[k - 1] : kGrpNull;
-                            ins = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : (int)(int16_t)(max(ins_g, ins_i) + 1);
-                            oi[k] = (int16_t)ins;
-                            if (BT) hI(score)[k] = (int16_t)ins;
+                        {
+                            const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
+                            const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? raw_ie_m1 : kGrpNull;
+                            const int v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : (int)(int16_t)(max(ins_g, ins_i) + 1);
+                            if (!i_out_null) {
+                                ins = v;
+                                oi[k] = (int16_t)ins;
+                                if (BT) hI(score)[k] = (int16_t)ins;
+                            }
                         }
                         int del = -10;
-                        if (!d_out_null) {
-                            const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? (int)r_mo[k + 1] : kGrpNull;
-                            const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? (int)r_de[k + 1] : kGrpNull;
-                            del = max(del_g, del_d);
-                            od[k] = (int16_t)del;
-                            if (BT) hD(score)[k] = (int16_t)del;
+                        {
+                            const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? raw_mo_p1 : kGrpNull;
+                            const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? raw_de_p1 : kGrpNull;
+                            if (!d_out_null) {
+                                del = max(del_g, del_d);
+                                od[k] = (int16_t)del;
+                                if (BT) hD(score)[k] = (int16_t)del;
+                            }
                         }
                         int sub = -10;
-                        if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(int16_t)(r_ms[k] + 1) : kGrpNull;
+                        if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(int16_t)(raw_ms + 1) : kGrpNull;
                         // M[s][k] as the reference stores it (int16), then affine_wfa_extend (wfa.c:186-208) on that value: a
                         // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
                         const int ext = extend(k, (int)(int16_t)max(del, max(sub, ins)));

@@ -510,12 +510,13 @@ def test_cfg4_full_size_1024_pairs_properties(gpu, monkeypatch):
     _compare("swg", params, req[sub], pat[sub], txt[sub], threads=8)
 
 
-def test_wfa_group_kernel_coverage(gpu):
+def test_wfa_group_kernel_coverage(gpu, monkeypatch):
     """The G-lanes-per-pair kernel: every group width (G = 1..16), WFA-adaptive on/off with wavefronts wide enough
     for the reduction to fire, custom penalties, non-ACGT fallback, ragged tails."""
     from aim_amd import capi, engine
     import ctypes as C
     lib = capi.load()
+    monkeypatch.setenv("AIM_NO_LANE_EXT", "1")   # (l = 100, e = 2 %, score-only) otherwise runs on wfa_lane_kernel's dynamic-bounds shape
     cases = [(100, 0.02, {}), (100, 0.05, {}), (100, 0.10, {}), (150, 0.05, {}), (250, 0.05, {}), (250, 0.08, {}),
              (100, 0.05, dict(mismatch=2, gap_o=3, gap_e=1)), (100, 0.04, dict(mismatch=5, gap_o=4, gap_e=2)),
              (200, 0.03, dict(mismatch=1, gap_o=1, gap_e=1))]
