@@ -129,6 +129,8 @@ typedef struct {
     aim_result8_t *res8;             /* score-only results */
     aim_cigar_t *cig; uint32_t *runs; uint32_t n_runs;      /* compact CIGAR */
     aim_result_t *res; char *ops;    /* --full-ops: the reference's own result_t + ops rows */
+    int use_full;                    /* this job's output came back as result_t + ops rows (--full-ops, or the run buffer overflowed) */
+    aim_batch_io_t io;               /* what was submitted (kept for a re-submission) */
     uint32_t device, slot;
     int in_flight;
 } job_t2;
@@ -314,12 +316,13 @@ static void format_range(int tid, int nt, void *arg)
     char *o = f->buf[tid] = malloc(cap), *start = o;
     for (size_t i = lo; i < hi; ++i) {
         /* fprintf(out, "%d, %d, \n", idx, score) */
-        const uint32_t idx = !f->backtrace ? j->res8[i].idx : (f->full_ops ? j->res[i].idx : j->cig[i].idx);
-        const int score = !f->backtrace ? j->res8[i].score : (f->full_ops ? j->res[i].score : j->cig[i].score);
+        const int full = f->full_ops || j->use_full;
+        const uint32_t idx = !f->backtrace ? j->res8[i].idx : (full ? j->res[i].idx : j->cig[i].idx);
+        const int score = !f->backtrace ? j->res8[i].score : (full ? j->res[i].score : j->cig[i].score);
         o = put_int(o, (int)idx); *o++ = ','; *o++ = ' ';
         o = put_int(o, score); *o++ = ','; *o++ = ' '; *o++ = '\n';
         if (!f->backtrace) continue;
-        if (f->full_ops) {                                           /* edit_cigar_print, host.c:69-89 */
+        if (full) {                                                  /* edit_cigar_print, host.c:69-89 */
             const aim_result_t *r = &j->res[i];
             const char *ops = j->ops + i * 2 * rs;
             char last = ops[r->begin_offset];
@@ -546,9 +549,16 @@ int main(int argc, char *argv[])
             if (first) printf("Retrieve results\n");
             first = 0;
             rc = aim_set_wait(set, j->device, j->slot, &j->n_runs);
-            if (rc == AIM_ENOMEM && j->cig) {   /* more runs than READ_SIZE/4 + 2 per pair on average */
-                fprintf(stderr, "AIM-HIP: run buffer overflow, use --full-ops for this input\n");
-                exit(1);
+            if (rc == AIM_ENOMEM && j->cig && !j->use_full) {
+                /* more runs than READ_SIZE/4 + 2 per pair on average (e.g. SWG with MAX_SCORE as +infinity on dissimilar reads):
+                   run this batch again and gather result_t + ops rows like the reference (host.c:316-326); the inputs are
+                   still in the job's buffers */
+                if (!j->res) { j->res = pinned((size_t)batch * sizeof(aim_result_t)); j->ops = pinned((size_t)batch * 2 * rs); }
+                j->io.cigars = NULL; j->io.runs = NULL; j->io.runs_cap = 0;
+                j->io.results = j->res; j->io.ops = j->ops;
+                j->use_full = 1;
+                if ((rc = aim_set_submit(set, j->device, j->slot, &j->io))) die_aim("aim_set_submit", rc);
+                rc = aim_set_wait(set, j->device, j->slot, NULL);
             }
             if (rc == AIM_EALIGN) { /* the reference prints from the DPU and exits 1 */
                 const char *msg = strstr(aim_last_error(), "(");
@@ -590,6 +600,8 @@ int main(int argc, char *argv[])
             if (!backtrace) io.results = j->res8;
             else if (full_ops) { io.results = j->res; io.ops = j->ops; }
             else { io.cigars = j->cig; io.runs = j->runs; io.runs_cap = runs_cap; }
+            j->io = io;
+            j->use_full = 0;
             if ((rc = aim_set_submit(set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
             j->in_flight = 1;
             sent += j->n;

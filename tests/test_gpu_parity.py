@@ -867,3 +867,27 @@ def test_wfa_lane_dynamic_bounds_shape(gpu, rs, l, reduce):
     a, _ = engine.align(engine.make_params("wfa", 10, rs, reduce=True), req, pat, txt)
     b, _ = engine.align(engine.make_params("wfa", 10, rs, reduce=False), req, pat, txt)
     print("pairs whose score differs with / without reduction:", int((a["score"] != b["score"]).sum()))
+
+
+def test_host_cli_falls_back_to_ops_rows_when_the_run_buffer_overflows(gpu, tmp_path):
+    """Found by tools/fuzz_cli.py --focus dplong in round 2: SWG with MAX_SCORE as '+infinity' (S2) on l = 700 reads produces
+    alignments with hundreds of one-operation runs, more than the READ_SIZE/4 + 2 per pair the compact-CIGAR buffer holds.
+    The host must then gather result_t + ops rows for that batch (like the reference) instead of giving up."""
+    import subprocess, sys
+    from conftest import ROOT
+    from aim_amd import engine
+    l, err, cost = 700, 0.02, dict(mismatch=3, gap_o=3, gap_e=2)
+    ms, rs = engine.launcher_sizes("swg", l, err, **cost)
+    req, pat, txt = engine.gen_pairs(1234, 0, 40, l, err, rs)
+    inp = tmp_path / "in.seq"
+    inp.write_bytes(engine.pairs_to_text(req, pat, txt))
+    common = ["-i", str(inp), "-l", str(l), "-e", str(err), "-n", "2", "-d", "1", "-b", "-x", "3", "-g", "3", "-a", "2"]
+    rh = subprocess.run([sys.executable, "-m", "aim_amd.launch", "swg", "-o", str(tmp_path / "h.out")] + common, capture_output=True, text=True,
+                        cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT))
+    ro = subprocess.run([os.path.join(ROOT, "oracle", "oracle_cli"), "swg", "-o", str(tmp_path / "o.out")] + common, capture_output=True, text=True,
+                        cwd=tmp_path)
+    assert (rh.returncode == 0) == (ro.returncode == 0), rh.stdout + rh.stderr
+    if ro.returncode == 0:
+        assert (tmp_path / "h.out").read_bytes() == (tmp_path / "o.out").read_bytes()
+        runs = (tmp_path / "o.out").read_bytes().split(b"\n")[1]
+        assert sum(c in b"MXID" for c in runs) > rs // 4 + 2      # the case really overflows the compact buffer
