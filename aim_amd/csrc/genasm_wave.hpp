@@ -11,6 +11,8 @@
 //     R_a[d] = X_a[d] & (R_a[d-1] << 1),   X_a[d] = match & substitution & text-only edit   (all from column a+1)
 //  => R_a[d] = AND_{j <= d} (X_a[d-j] << j), a prefix-AND with a shift per step: six Hillis-Steele steps over the lanes
 //     (stride 1, 2, 4, ..., 32; the shift of a step equals its stride), instead of GenASM's 64-deep hardware chain.
+// Almost every window needs far fewer than 16 edits, so the column loop first runs levels 0..15 only, in one 16-lane DPP row
+// (four row_shr steps, no LDS crossbar), and falls back to all 64 levels (six ds_bpermute steps) when that finds no alignment.
 // Lane d keeps R[d] of the current column in two VGPRs; every column is also written to LDS ([a][d], 33 KB per
 // wavefront) because the traceback -- a wave-uniform walk of <= ~80 steps per window -- reads R_a[d], R_{a+1}[d] and
 // R_{a+1}[d-1] along its path.  Pattern masks are not tabulated: PM[c] = ~ballot(reversed pattern char == c) is one
@@ -31,6 +33,15 @@ __device__ __forceinline__ uint64_t ga_shfl_up(uint64_t v, int delta, int lane)
     const int src = (lane - delta) < 0 ? lane : lane - delta;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)v);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// lane L receives the value of lane L - S of its own 16-lane row (DPP row_shr: no LDS crossbar); lanes whose source would
+// lie outside the row receive `fill`
+template <int S>
+__device__ __forceinline__ uint64_t ga_row_shr(uint64_t v, uint64_t fill)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x110 + S, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x110 + S, 0xf, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t ga_uniform(uint64_t v)   // value known to be wave-uniform -> SGPRs
@@ -69,34 +80,53 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const int prev = lane < m ? (int)gP[pi + m - 1 - lane] : 0x100;     // 0x100 never equals a byte
             const int pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
             const int tfwd = lane < n ? (int)gT[ti + lane] : 0x300;
+            // FAST PATH: levels 0..15 only, in lanes 0..15, with DPP row shifts (four scan steps, no LDS crossbar). Level d of a
+            // column depends on levels <= d only, so these 16 levels are exactly the first 16 of the full computation; if the
+            // window aligns within 15 edits (at e = 10 % a 64-character window carries ~6) the traceback never looks further.
             uint64_t R = ONES << lane;                                           // R_n[d] = ~0 << d
             Rs[n * 64 + lane] = R;
+            const int dl = lane & 15;
             for (int col = n - 1; col >= 0; --col) {
                 const int c = __builtin_amdgcn_readlane(tfwd, col);
                 const uint64_t pm = ~__ballot(prev == c);                       // bit j = 0 <=> p[m-1-j] == t[col]
                 const uint64_t old = R;
-                const uint64_t oldm1 = ga_shfl_up(old, 1, lane);
+                const uint64_t oldm1 = ga_row_shr<1>(old, ONES);
                 uint64_t y = (old << 1) | pm;                                   // match
-                if (lane > 0) y &= (oldm1 << 1) & oldm1;                        // substitution, text-only edit (from level d-1)
-#pragma unroll
-                for (int s = 1; s < 64; s <<= 1) {                              // pattern-only edit: prefix-AND with shift
-                    const uint64_t up = ga_shfl_up(y, s, lane);
-                    if (lane >= s) y &= up << s;
-                }
+                if (dl > 0) y &= (oldm1 << 1) & oldm1;                          // substitution, text-only edit (from level d-1)
+                uint64_t up;
+                up = ga_row_shr<1>(y, ONES); if (dl >= 1) y &= up << 1;         // pattern-only edit: prefix-AND with shift
+                up = ga_row_shr<2>(y, ONES); if (dl >= 2) y &= up << 2;
+                up = ga_row_shr<4>(y, ONES); if (dl >= 4) y &= up << 4;
+                up = ga_row_shr<8>(y, ONES); if (dl >= 8) y &= up << 8;
                 R = y;
-                Rs[col * 64 + lane] = R;
+                if (lane < 16) Rs[col * 64 + lane] = R;
+            }
+            uint64_t hit = __ballot(lane < 16 && !((R >> (m - 1)) & 1ull));
+            if (!hit) {
+                // SLOW PATH (a window that needs 16..63 edits): all 64 levels, one per lane, scan steps through ds_bpermute
+                R = ONES << lane;
+                for (int col = n - 1; col >= 0; --col) {
+                    const int c = __builtin_amdgcn_readlane(tfwd, col);
+                    const uint64_t pm = ~__ballot(prev == c);
+                    const uint64_t old = R;
+                    const uint64_t oldm1 = ga_shfl_up(old, 1, lane);
+                    uint64_t y = (old << 1) | pm;
+                    if (lane > 0) y &= (oldm1 << 1) & oldm1;
+#pragma unroll
+                    for (int s = 1; s < 64; s <<= 1) {
+                        const uint64_t up = ga_shfl_up(y, s, lane);
+                        if (lane >= s) y &= up << s;
+                    }
+                    R = y;
+                    Rs[col * 64 + lane] = R;
+                }
+                hit = __ballot(!((R >> (m - 1)) & 1ull));
             }
             // d0 = smallest level whose bit m-1 is clear in column 0
-            const uint64_t hit = __ballot(!((R >> (m - 1)) & 1ull));
             int d = hit ? (int)__builtin_ctzll(hit) : -1;
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the columns are in LDS (one wavefront: in-order LDS)
             int ca = 0, cb = 0, wn = 0;           // consumed text / pattern characters, ops of this window (uniform)
             auto emit = [&](unsigned char ch) { if (lane == 0) wops[wn] = ch; ++wn; };
-            auto ok = [&](int col, int lvl, int b) -> bool {
-                if (b >= m) return true;
-                const uint64_t r = ga_uniform(Rs[col * 64 + lvl]);
-                return !((r >> (m - 1 - b)) & 1ull);
-            };
             if (d < 0) {   // [spec] no alignment of this window within 63 edits: diagonal steps
                 int steps = min(min(m, n), kGaCommit);
                 for (; ca < steps; ++ca, ++cb) {
@@ -109,11 +139,17 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                     if (cb == m) break;
                     if (!last && (ca >= kGaCommit || cb >= kGaCommit)) break;
                     if (ca == n) { emit('D'); ++cb; --d; ++dist; continue; }
+                    // the three vectors a step can look at, fetched together (one LDS round trip per step instead of up to four)
+                    const int dm1 = d > 0 ? d - 1 : 0;
+                    const uint64_t r_next_d = ga_uniform(Rs[(ca + 1) * 64 + d]);       // R_{a+1}[d]   : match
+                    const uint64_t r_next_dm1 = ga_uniform(Rs[(ca + 1) * 64 + dm1]);   // R_{a+1}[d-1] : substitution (b+1), text-only edit (b)
+                    const uint64_t r_cur_dm1 = ga_uniform(Rs[ca * 64 + dm1]);          // R_a[d-1]     : pattern-only edit (b+1)
+                    auto clear = [&](uint64_t r, int b) -> bool { return b >= m || !((r >> (m - 1 - b)) & 1ull); };
                     const bool eq = __builtin_amdgcn_readlane(pfwd, cb) == __builtin_amdgcn_readlane(tfwd, ca);
-                    if (eq && ok(ca + 1, d, cb + 1)) { emit('M'); ++ca; ++cb; continue; }
-                    if (d > 0 && ok(ca + 1, d - 1, cb + 1)) { emit('X'); ++ca; ++cb; --d; ++dist; continue; }
-                    if (d > 0 && ok(ca, d - 1, cb + 1)) { emit('D'); ++cb; --d; ++dist; continue; }
-                    if (d > 0 && ok(ca + 1, d - 1, cb)) { emit('I'); ++ca; --d; ++dist; continue; }
+                    if (eq && clear(r_next_d, cb + 1)) { emit('M'); ++ca; ++cb; continue; }
+                    if (d > 0 && clear(r_next_dm1, cb + 1)) { emit('X'); ++ca; ++cb; --d; ++dist; continue; }
+                    if (d > 0 && clear(r_cur_dm1, cb + 1)) { emit('D'); ++cb; --d; ++dist; continue; }
+                    if (d > 0 && clear(r_next_dm1, cb)) { emit('I'); ++ca; --d; ++dist; continue; }
                     status = AIM_PAIR_WFA_NO_LINK;   // cannot happen (the recurrence guarantees one rule applies)
                     break;
                 }

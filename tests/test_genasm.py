@@ -142,3 +142,31 @@ def test_genasm_through_the_host_cli(gpu, tmp_path):
     ores, oops, _ = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), req["pattern_len"], req["text_len"], pat, txt, nthreads=8)
     ores["idx"] = req["idx"]
     assert out.read_bytes() == oracle.format_output(ores, oops, True)
+
+
+@pytest.mark.gpu
+def test_genasm_windows_that_need_more_than_15_edits(gpu):
+    """The kernel's fast path computes 16 error levels per window and falls back to all 64; both sides of that switch and the
+    [spec] no-alignment window are exercised: e = 35-60 % error rates, unrelated sequences, single-letter sequences."""
+    from aim_amd import engine
+    from oracle import oracle
+    for l, err, n, seed in ((200, 0.35, 400, 1), (500, 0.6, 200, 2), (64, 0.5, 500, 3)):
+        rs = ((int(l * (1 + err)) + 8 + 7) // 8) * 8
+        req, pat, txt = engine.gen_pairs(seed, 0, n, l, err, rs)
+        rng = np.random.RandomState(seed)
+        for i in range(0, n, 3):                                   # unrelated text: random bases over the whole length
+            tl = int(req["text_len"][i])
+            txt[i, :tl] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=tl)
+        if n > 10:
+            pat[1, : req["pattern_len"][1]] = ord("A"); txt[1, : req["text_len"][1]] = ord("C")   # nothing matches: the [spec] fallback window
+        params = engine.make_params("genasm", 0, rs, backtrace=True)
+        res, ops = engine.align(params, req, pat, txt)
+        ores, oops, worst = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), req["pattern_len"], req["text_len"], pat, txt, nthreads=16)
+        assert worst == 0
+        for f in ("score", "end_offset", "status"):
+            assert np.array_equal(res[f], ores[f]), f
+        for i in range(n):
+            e = int(res["end_offset"][i])
+            assert np.array_equal(ops[i, :e], oops[i, :e]), i
+        _check_alignment(req, pat, txt, res, ops)
+        assert (res["score"] > 16 * (req["pattern_len"] // 40 + 1) // 2).any()   # some windows are far beyond 15 edits
