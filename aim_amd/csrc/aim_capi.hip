@@ -99,6 +99,7 @@ aim::Knobs read_knobs()
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
+    k.group_wlds = env_int("AIM_GROUP_WLDS", -1);
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
     k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;

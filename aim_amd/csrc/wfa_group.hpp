@@ -34,6 +34,10 @@ struct GroupCfg {
     int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)
     int rows_per_wave;
     int hist_stride;  // BACKTRACE: int16 entries of one pair's HBM history slab = (MAX_SCORE+2) * (3*wcap + 4)
+    int wlds;         // entries per ring row IN LDS: wcap (every diagonal has its own home), or a power of two < wcap ("narrow
+                      // window": homes are (k + kbias) & wmask; a pair whose wavefront outgrows wlds - 2 diagonals is handed
+                      // to the general kernel through the to-do list, like a pair with non-ACGT bytes)
+    int wmask;        // wlds - 1 in narrow mode, 0xffff otherwise
 };
 
 enum { GF_PRESENT = 1, GF_MNULL = 2, GF_INULL = 4, GF_DNULL = 8, GF_HASI = 16, GF_HASD = 32 };
@@ -45,6 +49,13 @@ __device__ __forceinline__ int group_min(int v)
 {
     constexpr int big = 0x7fffffff;
     if (G == 64) return wave_min_i32(v);   // a whole wavefront per pair
+    if (G == 32) {                         // two DPP rows per pair: row minimum, then the partner row's through the LDS crossbar
+        v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x140, 0xf, 0xf, false));
+        return min(v, __builtin_amdgcn_ds_bpermute((int)((threadIdx.x ^ 16u) << 2), v));
+    }
     if (G >= 2) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     if (G >= 4) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
     if (G >= 8) v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x141, 0xf, 0xf, false));   // row_half_mirror
@@ -69,17 +80,17 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int rs = a.p.read_size;
     // raw rows of one array, whole 16-B chunks; a whole-wavefront group (G == 64) packs straight from global memory
     // instead (one pair per ~2 ms of compute: nothing to hide, and 2*READ_SIZE bytes of LDS buy residency)
-    const int rows_dw = G == 64 ? 0 : ((PPW * rs + 15) / 16) * 4;
+    const int rows_dw = G >= 32 ? 0 : ((PPW * rs + 15) / 16) * 4;
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + rows_dw;
     uint32_t *pairmem = rowsT + rows_dw + 1;
     // per-pair region
     uint32_t *mine = pairmem + q * c.pair_dwords;
-    int16_t *Mw = reinterpret_cast<int16_t *>(mine);                        // [ring_m][wcap]
-    int16_t *Iw = Mw + c.ring_m * c.wcap;                                    // [ring_e][wcap]
-    int16_t *Dw = Iw + c.ring_e * c.wcap;                                    // [ring_e][wcap]
-    int16_t *meta = Dw + c.ring_e * c.wcap;                                  // [ring_m][4] = klo, khi, flags, pad
-    uint32_t *packed = mine + ((c.ring_m + 2 * c.ring_e) * c.wcap * 2 + c.ring_m * 8 + 3) / 4;   // P then T, np dwords each
+    int16_t *Mw = reinterpret_cast<int16_t *>(mine);                        // [ring_m][wlds]
+    int16_t *Iw = Mw + c.ring_m * c.wlds;                                    // [ring_e][wlds]
+    int16_t *Dw = Iw + c.ring_e * c.wlds;                                    // [ring_e][wlds]
+    int16_t *meta = Dw + c.ring_e * c.wlds;                                  // [ring_m][4] = klo, khi, flags, pad
+    uint32_t *packed = mine + ((c.ring_m + 2 * c.ring_e) * c.wlds * 2 + c.ring_m * 8 + 3) / 4;   // P then T, np dwords each
     uint32_t *pkP = packed, *pkT = packed + c.np;
 
     const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int nchunk_total = (PPW * rs + 15) / 16;       // 16-B chunks per array per unit (the last one may run into the next row / tail slack)
 
     auto dma = [&](uint32_t unit) {
-        if (G == 64) return;
+        if (G >= 32) return;
         const uint32_t pair0 = unit * PPW;
         const uint32_t rows = min((uint32_t)PPW, a.n_pairs - pair0);
         const int nchunks = (int)((rows * rs + 15) / 16);
@@ -118,10 +129,12 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     // Computing the index at every use instead measured 3-5 % slower on the G <= 16 plans.
     int score = 0, sm = 0, i_x = 0, i_oe = 0, i_e = 0;
     auto back = [&](int d) { const int i = sm - d; return i < 0 ? i + c.ring_m : i; };   // 0 <= d < ring_m
-    auto mrow_at = [&](int i) { return Mw + i * c.wcap + kb; };                      // row pointer biased: row[k]
+    const int wmask = c.wmask;
+    auto H = [&](int k) { return (k + kb) & wmask; };                                // home of diagonal k inside a ring row
+    auto mrow_at = [&](int i) { return Mw + i * c.wlds; };                           // row base: row[H(k)]
     auto meta_at = [&](int i) { return meta + i * 4; };
-    auto islot = [&](int s) { return Iw + (s & (c.ring_e - 1)) * c.wcap + kb; };
-    auto dslot = [&](int s) { return Dw + (s & (c.ring_e - 1)) * c.wcap + kb; };
+    auto islot = [&](int s) { return Iw + (s & (c.ring_e - 1)) * c.wlds; };
+    auto dslot = [&](int s) { return Dw + (s & (c.ring_e - 1)) * c.wlds; };
     auto fence = [&]() { asm volatile("" ::: "memory"); };   // same-wave LDS traffic is ordered; compiler fence only
 
 #ifdef AIM_GROUP_STAMPS
@@ -149,8 +162,8 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         // ---- validate + pack: the G lanes of a group split the packed dwords of their pair ------------------------
         uint32_t bad = 0;
         {
-            const uint32_t *rp = G == 64 ? reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs) : rowsP + (q * rs) / 4;
-            const uint32_t *rt = G == 64 ? reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs) : rowsT + (q * rs) / 4;
+            const uint32_t *rp = G >= 32 ? reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs) : rowsP + (q * rs) / 4;
+            const uint32_t *rt = G >= 32 ? reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs) : rowsT + (q * rs) / 4;
             const int npw = (rs + 15) / 16;
             for (int j = g; j < npw; j += G) {
 #pragma unroll
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int w = 4 * j + i;
-                        const uint32_t av = (4 * w < rs && (G != 64 || active)) ? r[w] : 0u;
+                        const uint32_t av = (4 * w < rs && (G < 32 || active)) ? r[w] : 0u;
                         const uint32_t t = (av >> 1) & 0x03030303u;
                         const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);
                         const int rem = len - 4 * w;
@@ -213,13 +226,16 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         score = 0; sm = 0; i_x = i_oe = i_e = 0;
         int final_score = -1;
         bool done = !active || bad != 0u;
+#ifdef AIM_GROUP_COUNT_WIDTHS   // diagnostic builds only: wavefront width statistics into the result (max_operations = sum of widths, begin_offset = steps with width > 32, end_offset = steps with width > 64)
+        int dbg_wsum = 0, dbg_w32 = 0, dbg_w64 = 0;
+#endif
         // wavefronts[0]: lo = hi = 0, M[0] = 0 (wfa.c:347-348)
         int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
         // Every later wavefront is extended by the lane that computes it (below); score 0 has no compute step.
         int part = 0x7fffffff;                     // min over my diagonals of the distance to the end (for the reduction)
         if (g == 0) {
             const int m00 = done ? 0 : extend(0, 0);
-            mrow_at(0)[0] = (int16_t)m00;
+            mrow_at(0)[H(0)] = (int16_t)m00;
             if (BT && !done) hM(0)[0] = (int16_t)m00;
             meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
         }
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     const int mind = min(max(plen, tlen), group_min<G>(part));
                     int kfirst = 0x7fffffff, klast = -0x7fffffff;
                     for (int k = klo + g; k <= khi; k += G) {
-                        const int off = mrow[k];
+                        const int off = mrow[H(k)];
                         if ((max(plen - (off - k), tlen - off) - mind) <= 50) { kfirst = min(kfirst, k); klast = max(klast, k); }
                     }
                     kfirst = group_min<G>(kfirst);
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     hm[0] = (int16_t)klo; hm[1] = (int16_t)khi; hm[2] = (int16_t)flags;
                 }
                 // affine_wfa_end_reached, wfa.c:210-230
-                if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[ak] >= tlen) {
+                if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[H(ak)] >= tlen) {
                     done = true;
                     final_score = score;
                 } else if (score + 1 > MS) {   // wfa.c:368-376
@@ -316,6 +332,13 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                     const int hi = max(max(sub_hi, o_hi), e_hi) + 1;
                     flags = GF_PRESENT | (i_out_null ? GF_INULL : GF_HASI) | (d_out_null ? GF_DNULL : GF_HASD);
                     klo = lo; khi = hi;
+                    if (hi - lo + 1 > c.wlds - 2) {   // narrow window outgrown (never true in linear mode): the general kernel takes the pair
+                        bad = 1u;
+                        done = true;
+                    }
+#ifdef AIM_GROUP_COUNT_WIDTHS
+                    dbg_wsum += hi - lo + 1; dbg_w32 += (hi - lo + 1) > 32; dbg_w64 += (hi - lo + 1) > 64;
+#endif
                     const int16_t *r_ms = mrow_at(i_x), *r_mo = mrow_at(i_oe);   // valid rows even when the score does not exist
                     const int16_t *r_ie = islot(s_e < 0 ? 0 : s_e), *r_de = dslot(s_e < 0 ? 0 : s_e);
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
@@ -325,8 +348,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         // wcap = 2*MAX_SCORE+3 entries and |k +- 1| <= MAX_SCORE+1, so the addresses are always in bounds);
                         // AFFINE_WAVEFRONT_COND_FETCH's range / null tests then select. Guarded reads compiled to one
                         // exec-masked branch and one LDS round trip EACH: five dependent round trips per cell.
-                        const int raw_mo_m1 = r_mo[k - 1], raw_ie_m1 = r_ie[k - 1], raw_mo_p1 = r_mo[k + 1], raw_de_p1 = r_de[k + 1],
-                                  raw_ms = r_ms[k];
+                        const int hk = H(k), hkm = H(k - 1), hkp = H(k + 1);
+                        const int raw_mo_m1 = r_mo[hkm], raw_ie_m1 = r_ie[hkm], raw_mo_p1 = r_mo[hkp], raw_de_p1 = r_de[hkp],
+                                  raw_ms = r_ms[hk];
                         int ins = -10;
                         {
                             const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                             const int v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : (int)(int16_t)(max(ins_g, ins_i) + 1);
                             if (!i_out_null) {
                                 ins = v;
-                                oi[k] = (int16_t)ins;
+                                oi[hk] = (int16_t)ins;
                                 if (BT) hI(score)[k] = (int16_t)ins;
                             }
                         }
@@ -344,7 +368,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                             const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? raw_de_p1 : kGrpNull;
                             if (!d_out_null) {
                                 del = max(del_g, del_d);
-                                od[k] = (int16_t)del;
+                                od[hk] = (int16_t)del;
                                 if (BT) hD(score)[k] = (int16_t)del;
                             }
                         }
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                         // M[s][k] as the reference stores it (int16), then affine_wfa_extend (wfa.c:186-208) on that value: a
                         // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
                         const int ext = extend(k, (int)(int16_t)max(del, max(sub, ins)));
-                        om[k] = (int16_t)ext;
+                        om[hk] = (int16_t)ext;
                         if (BT) hM(score)[k] = (int16_t)ext;
                         part = min(part, max(plen - (ext - k), tlen - ext));
                     }
@@ -466,6 +490,9 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
                 r.score = final_score;
                 r.status = status;
                 r.idx = rq.idx;
+#ifdef AIM_GROUP_COUNT_WIDTHS
+                r.max_operations = dbg_wsum; r.begin_offset = dbg_w32; r.end_offset = dbg_w64;
+#endif
                 store_result(a, pair, r);
             }
         }
@@ -496,7 +523,22 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     c->ring_m = ring_m;
     c->ring_e = ring_e;
     c->np = (p.read_size + 15) / 16 + 1;
-    int dw = ((ring_m + 2 * ring_e) * c->wcap * 2 + ring_m * 8 + 3) / 4 + 2 * c->np;
+    // Ring rows in LDS. Every diagonal having its own home costs 2*MAX_SCORE+3 entries per row although WFA-adaptive keeps
+    // the wavefront narrow (measured, tools/group_widths.py: l = 1000 e = 5 %: mean width 23, 20.6 % of the score steps wider
+    // than 32, 0.1 % wider than 64, MAX_SCORE 250 -> 503 homes). From 256 homes up the rows are 128 entries addressed
+    // modulo 128 instead: 3.2 KB per pair instead of 10.7 KB at cfg3, i.e. 2-4x the pairs resident per CU -- which is what
+    // this latency-bound kernel lacked. A wavefront that outgrows 126 diagonals sends its pair to the general kernel.
+    c->wlds = c->wcap;
+    c->wmask = 0xffff;
+    {
+        // (same-box probe, tools/group_policy2.py, score-only kernel ms, row of 128 vs one home per diagonal at the better G:
+        // l=1000 e=5% 3.76 vs 6.06; l=400 e=10% 1.57 vs 2.29; l=500 e=5% 1.89 vs 2.12; l=250 e=10% 1.87 vs 2.18; l=1000 e=2% 1.63
+        // vs 1.63; no pair of these sets outgrew the row. Rows of 64 cost 0.3-47 % of the pairs a detour, rows of 32 most.)
+        int narrow = (p.flags & AIM_FLAG_REDUCE) && c->wcap >= 192 ? 128 : 0;   // without the reduction widths grow with the score
+        if (kn.group_wlds >= 0) narrow = kn.group_wlds;
+        if (narrow >= 16 && (narrow & (narrow - 1)) == 0 && narrow < c->wcap) { c->wlds = narrow; c->wmask = narrow - 1; }
+    }
+    int dw = ((ring_m + 2 * ring_e) * c->wlds * 2 + ring_m * 8 + 3) / 4 + 2 * c->np;
     dw |= 1;
     c->pair_dwords = dw;
     // LDS budget for the wavefront windows of one wavefront's pairs: 12 KiB measured best (occupancy beats lanes per
@@ -505,12 +547,13 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     int g = 32;
     for (size_t cap_kb : {12, 24, 48}) {
         size_t cap_bytes = cap_kb * 1024;
+        if (cap_kb == 12 && c->wlds != c->wcap) cap_bytes = 10 * 1024;   // narrow rows: two pairs per wavefront beat four from ~2.8 KB per pair up (same probe)
         if (kn.group_lds_kb >= 0) cap_bytes = (size_t)kn.group_lds_kb * 1024;
         g = 1;
-        while (g <= 16 && (size_t)(kWave / g) * dw * 4 > cap_bytes) g *= 2;
-        if (g <= 16) break;
+        while (g <= 32 && (size_t)(kWave / g) * dw * 4 > cap_bytes) g *= 2;
+        if (g <= 32) break;
     }
-    if (g > 16) {   // a whole wavefront per pair (long reads / large MAX_SCORE)
+    if (g > 32) {   // a whole wavefront per pair (long reads / large MAX_SCORE)
         if ((size_t)dw * 4 > 48 * 1024) return false;
         g = 64;
     } else {
@@ -518,16 +561,17 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
         // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s, each plan at its real LDS fit): 3 per CU
         // 1.56x (l=1000 e=5%), 4 per CU 1.55x (l=400 e=10%); 6 per CU 1.07x / 0.91x / 0.79x; 11 per CU 0.57x; 16 per CU
         // 0.48x. 5 per CU is not measured.
-        const size_t wg = (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8 + (size_t)(kWave / g) * dw * 4 + 64;
+        const size_t stage = g >= 32 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;   // G >= 32 packs from global memory
+        const size_t wg = stage + (size_t)(kWave / g) * dw * 4 + 64;
         if (lds_workgroups_per_cu(wg) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
     }
     if (kn.group_g >= 0) {   // experiments: force the lanes per pair if the plan is feasible at all
         const int fg = kn.group_g;
-        if ((fg == 1 || fg == 2 || fg == 4 || fg == 8 || fg == 16 || fg == 64) && (size_t)(kWave / fg) * dw * 4 <= 48 * 1024) g = fg;
+        if ((fg == 1 || fg == 2 || fg == 4 || fg == 8 || fg == 16 || fg == 32 || fg == 64) && (size_t)(kWave / fg) * dw * 4 <= 48 * 1024) g = fg;
     }
     *G = g;
     c->rows_per_wave = kWave / g;
-    const size_t rows_bytes = g == 64 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
+    const size_t rows_bytes = g >= 32 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
     if (*lds > 64 * 1024) return false;   // beyond the dynamic-LDS limit of a plain launch (only a forced AIM_GROUP_G gets here)
     const size_t lds_fit = lds_workgroups_per_cu(*lds);
@@ -543,8 +587,8 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     if (gr > need) gr = need < 8u ? 8u : need;
     *grid = gr;
     if (kn.plan_debug)
-        fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u\n", g, ring_m, ring_e,
-                c->wcap, dw * 4, *lds, lds_fit, per_cu, gr);
+        fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u wlds=%d\n", g, ring_m, ring_e,
+                c->wcap, dw * 4, *lds, lds_fit, per_cu, gr, c->wlds);
     c->hist_stride = (p.max_score + 2) * (3 * c->wcap + 4);
     *hist_bytes = (p.flags & AIM_FLAG_BACKTRACE) ? (((size_t)gr * (kWave / g) * c->hist_stride * 2 + 255) & ~(size_t)255) : 0;
     return true;
@@ -566,6 +610,7 @@ inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, ui
     case 4: AIM_GRP(4); break;
     case 8: AIM_GRP(8); break;
     case 16: AIM_GRP(16); break;
+    case 32: AIM_GRP(32); break;
     case 64: AIM_GRP(64); break;
     default: break;
     }

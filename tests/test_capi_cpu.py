@@ -113,16 +113,19 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
         m = re.search(r"G=(\d+) ring_m=(\d+) .* per_cu=(\d+)", line)
         assert m, line
         return int(m.group(1)), int(m.group(2)), int(m.group(3))
-    g, ring_m, per_cu = G(1000, 0.05)            # config 3: window of 503 diagonals
-    assert (g, ring_m) == (64, 6) and per_cu >= 12     # exact-size ring: max(x, o+e) + 1 = 6 rows
-    assert G(400, 0.10)[0] == 64                # 4 per CU at G = 16 -> a wavefront per pair
-    assert G(250, 0.10)[0] == 16                # 6 per CU at G = 16 stays (measured break-even)
+    g, ring_m, per_cu = G(1000, 0.05)            # config 3: 503 diagonals, but WFA-adaptive keeps ~23 alive: narrow 128-entry rows,
+    assert (g, ring_m) == (32, 6) and per_cu >= 12     # two pairs per wavefront (round 2); exact-size ring: max(x, o+e) + 1 = 6 rows
+    g, ring_m, per_cu = G(1000, 0.05, AIM_GROUP_WLDS="0")   # one home per diagonal (round-1 layout, 10.7 KB per pair): 7 per CU
+    assert (g, ring_m) == (32, 6) and per_cu == 7
+    assert G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14
+    assert G(400, 0.10)[0] == 32 and G(400, 0.10, AIM_GROUP_WLDS="0")[0] == 32   # (round-1 layout had no 32: 4 per CU at G = 16 -> a wavefront per pair)
+    assert G(250, 0.10)[0] == 32 and G(250, 0.10, AIM_GROUP_WLDS="0")[0] == 32   # (round 1: 16; 32 lanes per pair exist since round 2)
     assert G(100, 0.10)[0] == 16 and G(100, 0.02, AIM_NO_LANE_EXT="1")[0] <= 16   # (e = 2 % score-only now runs on wfa_lane_kernel)
-    assert G(1000, 0.05, AIM_GROUP_G="16")[0] == 16 and G(100, 0.10, AIM_GROUP_G="64")[0] == 64
+    assert G(1000, 0.05, AIM_GROUP_G="16")[0] == 16 and G(100, 0.10, AIM_GROUP_G="64")[0] == 64 and G(1000, 0.05, AIM_GROUP_G="64")[0] == 64
     # residency comes from the 1280-B LDS granule (aim_device.hpp: lds_workgroups_per_cu), capped at 16: a byte-granular
     # estimate would say 12 for the 12.8-KB and 13.3-KB workgroups, which measurably breaks into two rounds
     assert G(100, 0.02, AIM_NO_LANE_EXT="1")[2] == 11 and G(250, 0.05)[2] == 11
-    assert G(100, 0.05)[2] == 14 and G(100, 0.10)[2] == 16 and G(1000, 0.05)[2] == 14   # 11.2 KB / 9.8 KB / 10.7 KB workgroups
+    assert G(100, 0.05)[2] == 14 and G(100, 0.10)[2] == 16 and G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14   # 11.2 KB / 9.8 KB / 10.7 KB workgroups
 
 
 def test_scratch_bound_default_and_override(built):

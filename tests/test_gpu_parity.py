@@ -891,3 +891,28 @@ def test_host_cli_falls_back_to_ops_rows_when_the_run_buffer_overflows(gpu, tmp_
         assert (tmp_path / "h.out").read_bytes() == (tmp_path / "o.out").read_bytes()
         runs = (tmp_path / "o.out").read_bytes().split(b"\n")[1]
         assert sum(c in b"MXID" for c in runs) > rs // 4 + 2      # the case really overflows the compact buffer
+
+
+@pytest.mark.parametrize("env,expect_fallback", [(dict(), False), (dict(AIM_GROUP_WLDS="64"), True), (dict(AIM_GROUP_WLDS="0"), False),
+                                                 (dict(AIM_GROUP_G="16"), False), (dict(AIM_GROUP_G="64", AIM_GROUP_WLDS="64"), True)])
+def test_wfa_group_narrow_window_and_two_pairs_per_wavefront(gpu, monkeypatch, env, expect_fallback):
+    """Round 2: for MAX_SCORE >= 127 with WFA-adaptive the ring rows in LDS are 128 entries addressed modulo 128 instead of
+    2*MAX_SCORE+3 homes, and 32 lanes own a pair (two pairs per wavefront). A wavefront wider than the row sends its pair to
+    the general kernel (forced here with 64-entry rows); every combination stays bit-exact, with and without CIGAR."""
+    from aim_amd import engine
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ms, rs = engine.launcher_sizes("wfa", 1000, 0.05)
+    req, pat, txt = engine.gen_pairs(2718, 0, 3001, 1000, 0.05, rs)
+    pat[7, 100] = ord("N")
+    for kw in (dict(reduce=True), dict(reduce=True, backtrace=True)):
+        params = engine.make_params("wfa", ms, rs, **kw)
+        with engine.DeviceSet(1) as ds:
+            ds.align(params, req, pat, txt)
+            fb = ds.fallback_pairs(0)
+            plan = ds.plan_describe(0)
+        assert "wfa_group_kernel" in plan
+        assert (fb > 1) == expect_fallback, (fb, plan)
+        _compare("wfa", params, req, pat, txt)
+    if not env:
+        assert "G=32" in plan
