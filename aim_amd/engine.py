@@ -259,7 +259,7 @@ class DeviceSet:
         self._inflight[(device, slot)] = (io, keep, out)
 
     def wait(self, device, slot, check=True):
-        io, keep, out = self._inflight.pop((device, slot))
+        io, keep, out = self._inflight.pop((device, slot), (None, None, {}))   # nothing in flight: the library reports AIM_ESTATE
         nr = C.c_uint32()
         rc = self.lib.aim_set_wait(self.handle, device, slot, C.byref(nr))
         if rc != capi.AIM_EALIGN or check:

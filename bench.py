@@ -35,7 +35,7 @@ def pmc_traffic(kernel, pairs, io):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("kernel", "").startswith(kernel) and d.get("pairs_per_launch") == pairs and d.get("io", "default") == io:
+        if kernel in d.get("kernel", "") and d.get("pairs_per_launch") == pairs and d.get("io", "default") == io:
             best = (d["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
     return best
 

@@ -916,3 +916,38 @@ def test_wfa_group_narrow_window_and_two_pairs_per_wavefront(gpu, monkeypatch, e
         _compare("wfa", params, req, pat, txt)
     if not env:
         assert "G=32" in plan
+
+
+def test_slots_on_several_devices_and_empty_batches(gpu):
+    """aim_set_submit / aim_set_wait on every (device, slot) of a set (the same physical GPU three times here), an empty
+    batch, and aim_pack_batch's side-list overflow report."""
+    import ctypes as C
+    from aim_amd import capi, engine
+    lib = capi.load()
+    ms, rs = engine.launcher_sizes("wfa", 100, 0.01)
+    n = 5000
+    req, pat, txt = engine.gen_pairs(99, 0, 3 * n, 100, 0.01, rs)
+    params = engine.make_params("wfa", ms, rs, reduce=True, req8=True, res8=True)
+    base, _ = engine.align(engine.make_params("wfa", ms, rs, reduce=True), req, pat, txt)
+    with engine.DeviceSet(device_ids=[0, 0, 0]) as s:
+        s.configure_slots(params, n, slots=2, max_raw=16, max_runs=0)
+        for d in range(3):
+            lo = d * n
+            s.submit(d, d & 1, req[lo:lo + n], packed=engine.pack_batch(req[lo:lo + n], pat[lo:lo + n], txt[lo:lo + n]))
+        for d in (2, 0, 1):                                  # waits in any order
+            out = s.wait(d, d & 1)
+            assert np.array_equal(out["res"]["score"], base["score"][d * n:(d + 1) * n])
+            assert np.array_equal(out["res"]["idx"], req["idx"][d * n:(d + 1) * n])
+        s.submit(1, 0, req[:0], pat[:0], txt[:0])            # empty batch
+        assert len(s.wait(1, 0)["res"]) == 0
+        with pytest.raises(capi.AimError) as e:
+            s.wait(1, 0)                                     # nothing in flight
+        assert e.value.code == capi.AIM_ESTATE
+    dirty = pat.copy()
+    dirty[:200, 3] = ord("N")
+    pp = np.zeros((3 * n, engine.packed_row_dwords(rs)), dtype=np.uint32); pt = pp.copy()
+    raw = np.zeros(16, dtype=np.uint32); rawp = np.zeros((16, rs), dtype=np.uint8); rawt = rawp.copy()
+    nr = C.c_uint32()
+    rc = lib.aim_pack_batch(C.byref(params), 3 * n, capi.ptr(engine.to_request8(req)), capi.ptr(dirty), capi.ptr(txt), capi.ptr(pp), capi.ptr(pt),
+                            capi.ptr(raw), capi.ptr(rawp), capi.ptr(rawt), 16, C.byref(nr), 4)
+    assert rc == capi.AIM_ENOMEM and nr.value == 200
