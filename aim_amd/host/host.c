@@ -381,6 +381,7 @@ int main(int argc, char *argv[])
     uint32_t nr_dpus = 1, gpus = 1, batch = 4u << 20, slots = 2;
     int no_pack = 0, full_ops = 0;
     const char *pack_only = NULL;   /* test hook: write the packed batches to this file and exit (no GPU is touched) */
+    int dev_ids[64], n_dev_ids = 0; /* --device-ids a,b,c: physical device of every set member (tests put one GPU in twice) */
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     int threads = (int)(ncpu < 1 ? 1 : (ncpu > MAX_THREADS ? MAX_THREADS : ncpu));
     for (int i = 4; i < argc; ++i) {
@@ -393,6 +394,11 @@ int main(int argc, char *argv[])
         else if (!strcmp(f, "--full-ops")) full_ops = 1;     /* gather result_t + ops rows like the reference (host.c:316-326) */
         else if (!v) { printf("wrong number of arguments\n"); exit(1); }
         else if (!strcmp(f, "--pack-only")) { pack_only = v; ++i; }
+        else if (!strcmp(f, "--device-ids")) {
+            for (const char *q = v; *q && n_dev_ids < 64; ) { dev_ids[n_dev_ids++] = atoi(q); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            gpus = (uint32_t)n_dev_ids;
+            ++i;
+        }
         else if (!strcmp(f, "--algo")) {
             if (!strcmp(v, "nw")) p.algo = AIM_ALGO_NW;
             else if (!strcmp(v, "swg")) p.algo = AIM_ALGO_SWG;
@@ -436,7 +442,7 @@ int main(int argc, char *argv[])
     if (gpus == 0 || batch == 0 || slots == 0 || slots > 4) { fprintf(stderr, "--gpus, --batch must be positive, --slots 1..4\n"); exit(1); }
 
     aim_set_t *set = NULL;
-    int rc = pack_only ? 0 : aim_set_alloc(gpus, NULL, &set);
+    int rc = pack_only ? 0 : aim_set_alloc(gpus, n_dev_ids ? dev_ids : NULL, &set);
     if (rc) die_aim("aim_set_alloc", rc);
     g_big_alloc = pack_only ? plain : pinned;
     printf("Allocated %d DPU(s)\n", (int)nr_dpus);

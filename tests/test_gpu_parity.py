@@ -951,3 +951,21 @@ def test_slots_on_several_devices_and_empty_batches(gpu):
     rc = lib.aim_pack_batch(C.byref(params), 3 * n, capi.ptr(engine.to_request8(req)), capi.ptr(dirty), capi.ptr(txt), capi.ptr(pp), capi.ptr(pt),
                             capi.ptr(raw), capi.ptr(rawp), capi.ptr(rawt), 16, C.byref(nr), 4)
     assert rc == capi.AIM_ENOMEM and nr.value == 200
+
+
+def test_host_cli_pipeline_over_two_set_members(gpu, sample_bytes, ref_digests, tmp_path):
+    """The host's job ring over gpus x slots (the same physical GPU entered twice, small batches so that every (device, slot)
+    is used several times): output identical to the reference digests, with packed input and with --no-pack / --full-ops."""
+    import subprocess
+    from conftest import ROOT
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    inp = tmp_path / "sample"
+    inp.write_bytes(sample_bytes)
+    for extra, key in ((["--backtrace", "--reduce"], "wfa_reduce_backtrace"), (["--reduce"], "wfa_score_only"),
+                       (["--backtrace", "--reduce", "--no-pack", "--full-ops"], "wfa_reduce_backtrace")):
+        out = tmp_path / "out"
+        r = subprocess.run([host, str(inp), str(out), "20000", "--algo", "wfa", "--max-score", "5", "--read-size", "112", "--device-ids", "0,0",
+                            "--slots", "2", "--batch", "1500"] + extra, capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "14 batch(es)" in r.stdout and "2 device(s) x 2 slot(s)" in r.stdout, r.stdout
+        assert md5(out.read_bytes()) == ref_digests[key]
