@@ -58,6 +58,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
     debug_poison_lds(a, smem);
     uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);                       // [kGaW + 1][64]: column a, level d
     unsigned char *wops = reinterpret_cast<unsigned char *>(Rs + (kGaW + 1) * 64);   // ops of the current window (<= 128)
+    unsigned char *pwin = wops + 192, *twin = wops + 256;                            // the window's characters, for the traceback's run test
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
     constexpr uint64_t ONES = ~0ull;
@@ -80,6 +81,8 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const int prev = lane < m ? (int)gP[pi + m - 1 - lane] : 0x100;     // 0x100 never equals a byte
             const int pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
             const int tfwd = lane < n ? (int)gT[ti + lane] : 0x300;
+            pwin[lane] = (unsigned char)pfwd;
+            twin[lane] = (unsigned char)tfwd;
             // FAST PATH: levels 0..15 only, in lanes 0..15, with DPP row shifts (four scan steps, no LDS crossbar). Level d of a
             // column depends on levels <= d only, so these 16 levels are exactly the first 16 of the full computation; if the
             // window aligns within 15 edits (at e = 10 % a 64-character window carries ~6) the traceback never looks further.
@@ -136,6 +139,22 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 }
             } else {
                 for (;;) {
+                    // A run of matches in ONE step: lane i tests what the sequential walk would test at (ca+i, cb+i) -- window
+                    // limits, equal characters, and bit (m-2-cb-i) of R_{ca+i+1}[d] clear ('M' never changes d) -- and the run
+                    // is as long as the leading true lanes. The walk below then takes the one non-match step that ends it.
+                    {
+                        const int ai = ca + lane, bi = cb + lane;
+                        bool cond = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
+                        const int aic = cond ? ai : 0, bic = cond ? bi : 0;
+                        const uint64_t rr = Rs[(aic + 1) * 64 + d];
+                        cond = cond && pwin[bic] == twin[aic] && (bic + 1 >= m || !((rr >> (m - 2 - bic)) & 1ull));
+                        const uint64_t bad = ~__ballot(cond);
+                        const int run = bad ? (int)__builtin_ctzll(bad) : 64;
+                        if (run) {
+                            if (lane < run) wops[wn + lane] = 'M';
+                            wn += run; ca += run; cb += run;
+                        }
+                    }
                     if (cb == m) break;
                     if (!last && (ca >= kGaCommit || cb >= kGaCommit)) break;
                     if (ca == n) { emit('D'); ++cb; --d; ++dist; continue; }
@@ -191,7 +210,7 @@ inline void genasm_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid,
 {
     (void)p;
     *block = kWave;
-    *lds = (size_t)(kGaW + 1) * 64 * 8 + 256;
+    *lds = (size_t)(kGaW + 1) * 64 * 8 + 384;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
