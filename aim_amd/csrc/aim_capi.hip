@@ -175,7 +175,8 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
     if (p.algo == AIM_ALGO_GENASM) {
         pl->kid = K_GENASM;
         aim::genasm_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
-        pl->scratch_total = 256;
+        pl->scratch_per_wg = aim::kGaSlabBytes;
+        pl->scratch_total = (size_t)pl->grid * aim::kGaSlabBytes;   // slow-path columns, one slab per wavefront
         return AIM_OK;
     }
     if (p.algo == AIM_ALGO_WFA) {

@@ -13,8 +13,8 @@
 //     (stride 1, 2, 4, ..., 32; the shift of a step equals its stride), instead of GenASM's 64-deep hardware chain.
 // Almost every window needs far fewer than 16 edits, so the column loop first runs levels 0..15 only, in one 16-lane DPP row
 // (four row_shr steps, no LDS crossbar), and falls back to all 64 levels (six ds_bpermute steps) when that finds no alignment.
-// Lane d keeps R[d] of the current column in two VGPRs; every column is also written to LDS ([a][d], 33 KB per
-// wavefront) because the traceback -- a wave-uniform walk of <= ~80 steps per window -- reads R_a[d], R_{a+1}[d] and
+// Lane d keeps R[d] of the current column in two VGPRs; every column is also kept ([a][d]: 16 levels in LDS, 8.3 KB per
+// wavefront; all 64 in an HBM slab on the slow path) because the traceback -- a wave-uniform walk of <= ~80 steps per window -- reads R_a[d], R_{a+1}[d] and
 // R_{a+1}[d-1] along its path.  Pattern masks are not tabulated: PM[c] = ~ballot(reversed pattern char == c) is one
 // compare per text character and works for ANY byte values (the reference family compares raw bytes).
 // Integer / bit work only; HBM sees each sequence byte once and the ops once.
@@ -56,8 +56,13 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
-    uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);                       // [kGaW + 1][64]: column a, level d
-    unsigned char *wops = reinterpret_cast<unsigned char *>(Rs + (kGaW + 1) * 64);   // ops of the current window (<= 128)
+    // Columns of the window for the traceback. The fast path (16 levels) keeps them in LDS, [kGaW + 1][16] = 8.3 KB, so that
+    // 8 wavefronts are resident per CU (all 64 levels in LDS were 33 KB: 4 per CU, one per SIMD, nothing to overlap the
+    // dependent column chain with); the rare slow path (a window needing 16..63 edits) writes [kGaW + 1][64] to this
+    // wavefront's slab of HBM scratch instead.
+    uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);
+    uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
+    unsigned char *wops = reinterpret_cast<unsigned char *>(Rs + (kGaW + 1) * 16);   // ops of the current window (<= 128)
     unsigned char *pwin = wops + 192, *twin = wops + 256;                            // the window's characters, for the traceback's run test
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             // column depends on levels <= d only, so these 16 levels are exactly the first 16 of the full computation; if the
             // window aligns within 15 edits (at e = 10 % a 64-character window carries ~6) the traceback never looks further.
             uint64_t R = ONES << lane;                                           // R_n[d] = ~0 << d
-            Rs[n * 64 + lane] = R;
+            if (lane < 16) Rs[n * 16 + lane] = R;
             const int dl = lane & 15;
             for (int col = n - 1; col >= 0; --col) {
                 const int c = __builtin_amdgcn_readlane(tfwd, col);
@@ -102,12 +107,15 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 up = ga_row_shr<4>(y, ONES); if (dl >= 4) y &= up << 4;
                 up = ga_row_shr<8>(y, ONES); if (dl >= 8) y &= up << 8;
                 R = y;
-                if (lane < 16) Rs[col * 64 + lane] = R;
+                if (lane < 16) Rs[col * 16 + lane] = R;
             }
             uint64_t hit = __ballot(lane < 16 && !((R >> (m - 1)) & 1ull));
-            if (!hit) {
-                // SLOW PATH (a window that needs 16..63 edits): all 64 levels, one per lane, scan steps through ds_bpermute
+            const bool slow = !hit;            // wave-uniform
+            if (slow) {
+                // SLOW PATH (a window that needs 16..63 edits): all 64 levels, one per lane, scan steps through ds_bpermute;
+                // columns go to this wavefront's HBM slab
                 R = ONES << lane;
+                Rg[n * 64 + lane] = R;
                 for (int col = n - 1; col >= 0; --col) {
                     const int c = __builtin_amdgcn_readlane(tfwd, col);
                     const uint64_t pm = ~__ballot(prev == c);
@@ -121,10 +129,12 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                         if (lane >= s) y &= up << s;
                     }
                     R = y;
-                    Rs[col * 64 + lane] = R;
+                    Rg[col * 64 + lane] = R;
                 }
                 hit = __ballot(!((R >> (m - 1)) & 1ull));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront reads its own slab back below
             }
+            auto R_at = [&](int col, int lvl) -> uint64_t { return slow ? Rg[col * 64 + lvl] : Rs[col * 16 + lvl]; };
             // d0 = smallest level whose bit m-1 is clear in column 0
             int d = hit ? (int)__builtin_ctzll(hit) : -1;
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the columns are in LDS (one wavefront: in-order LDS)
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                         const int ai = ca + lane, bi = cb + lane;
                         bool cond = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
                         const int aic = cond ? ai : 0, bic = cond ? bi : 0;
-                        const uint64_t rr = Rs[(aic + 1) * 64 + d];
+                        const uint64_t rr = R_at(aic + 1, d);
                         cond = cond && pwin[bic] == twin[aic] && (bic + 1 >= m || !((rr >> (m - 2 - bic)) & 1ull));
                         const uint64_t bad = ~__ballot(cond);
                         const int run = bad ? (int)__builtin_ctzll(bad) : 64;
@@ -160,9 +170,9 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                     if (ca == n) { emit('D'); ++cb; --d; ++dist; continue; }
                     // the three vectors a step can look at, fetched together (one LDS round trip per step instead of up to four)
                     const int dm1 = d > 0 ? d - 1 : 0;
-                    const uint64_t r_next_d = ga_uniform(Rs[(ca + 1) * 64 + d]);       // R_{a+1}[d]   : match
-                    const uint64_t r_next_dm1 = ga_uniform(Rs[(ca + 1) * 64 + dm1]);   // R_{a+1}[d-1] : substitution (b+1), text-only edit (b)
-                    const uint64_t r_cur_dm1 = ga_uniform(Rs[ca * 64 + dm1]);          // R_a[d-1]     : pattern-only edit (b+1)
+                    const uint64_t r_next_d = ga_uniform(R_at(ca + 1, d));       // R_{a+1}[d]   : match
+                    const uint64_t r_next_dm1 = ga_uniform(R_at(ca + 1, dm1));   // R_{a+1}[d-1] : substitution (b+1), text-only edit (b)
+                    const uint64_t r_cur_dm1 = ga_uniform(R_at(ca, dm1));          // R_a[d-1]     : pattern-only edit (b+1)
                     auto clear = [&](uint64_t r, int b) -> bool { return b >= m || !((r >> (m - 1 - b)) & 1ull); };
                     const bool eq = __builtin_amdgcn_readlane(pfwd, cb) == __builtin_amdgcn_readlane(tfwd, ca);
                     if (eq && clear(r_next_d, cb + 1)) { emit('M'); ++ca; ++cb; continue; }
@@ -206,11 +216,13 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
     }
 }
 
+constexpr uint64_t kGaSlabBytes = (uint64_t)(kGaW + 1) * 64 * 8;   // one wavefront's slow-path columns in HBM scratch
+
 inline void genasm_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
 {
     (void)p;
     *block = kWave;
-    *lds = (size_t)(kGaW + 1) * 64 * 8 + 384;
+    *lds = (size_t)(kGaW + 1) * 16 * 8 + 384;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;

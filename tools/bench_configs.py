@@ -33,6 +33,7 @@ CONFIGS = {
     # BASELINE config 5 (parity unpinned: published GenASM algorithm, oracle/genasm_oracle.c)
     "genasm_l100000_e10_cigar": dict(algo="genasm", l=100000, e=0.10, n=1024, kw=dict(backtrace=True)),
     "genasm_l100000_e10_score": dict(algo="genasm", l=100000, e=0.10, n=1024, kw=dict()),
+    "genasm_l100000_e10_cigar_n4096": dict(algo="genasm", l=100000, e=0.10, n=4096, kw=dict(backtrace=True)),
     "genasm_l10000_e10_cigar": dict(algo="genasm", l=10000, e=0.10, n=8192, kw=dict(backtrace=True)),
     "genasm_l100_e10_cigar": dict(algo="genasm", l=100, e=0.10, n=1 << 18, kw=dict(backtrace=True)),
 }
