@@ -23,6 +23,13 @@
 #include "wfa_lane.hpp"
 
 
+#ifndef AIM_GROUP_DIRECT_G
+#define AIM_GROUP_DIRECT_G 8      // groups of at least this many lanes pack their sequences straight from global memory (no LDS staging rows)
+#endif
+#ifndef AIM_GROUP_MAX_PER_CU
+#define AIM_GROUP_MAX_PER_CU 20   // cap on resident single-wave workgroups per CU (5 per SIMD at <= 102 VGPRs; 24 measured worse on cfg3 with CIGAR)
+#endif
+
 namespace aim {
 
 struct GroupCfg {
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int rs = a.p.read_size;
     // raw rows of one array, whole 16-B chunks; a whole-wavefront group (G == 64) packs straight from global memory
     // instead (one pair per ~2 ms of compute: nothing to hide, and 2*READ_SIZE bytes of LDS buy residency)
-    const int rows_dw = G >= 32 ? 0 : ((PPW * rs + 15) / 16) * 4;
+    const int rows_dw = G >= AIM_GROUP_DIRECT_G ? 0 : ((PPW * rs + 15) / 16) * 4;
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + rows_dw;
     uint32_t *pairmem = rowsT + rows_dw + 1;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
     const int nchunk_total = (PPW * rs + 15) / 16;       // 16-B chunks per array per unit (the last one may run into the next row / tail slack)
 
     auto dma = [&](uint32_t unit) {
-        if (G >= 32) return;
+        if (G >= AIM_GROUP_DIRECT_G) return;
         const uint32_t pair0 = unit * PPW;
         const uint32_t rows = min((uint32_t)PPW, a.n_pairs - pair0);
         const int nchunks = (int)((rows * rs + 15) / 16);
@@ -162,8 +169,8 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
         // ---- validate + pack: the G lanes of a group split the packed dwords of their pair ------------------------
         uint32_t bad = 0;
         {
-            const uint32_t *rp = G >= 32 ? reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs) : rowsP + (q * rs) / 4;
-            const uint32_t *rt = G >= 32 ? reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs) : rowsT + (q * rs) / 4;
+            const uint32_t *rp = G >= AIM_GROUP_DIRECT_G ? reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs) : rowsP + (q * rs) / 4;
+            const uint32_t *rt = G >= AIM_GROUP_DIRECT_G ? reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs) : rowsT + (q * rs) / 4;
             const int npw = (rs + 15) / 16;
             for (int j = g; j < npw; j += G) {
 #pragma unroll
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int w = 4 * j + i;
-                        const uint32_t av = (4 * w < rs && (G < 32 || active)) ? r[w] : 0u;
+                        const uint32_t av = (4 * w < rs && (G < AIM_GROUP_DIRECT_G || active)) ? r[w] : 0u;
                         const uint32_t t = (av >> 1) & 0x03030303u;
                         const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, t);
                         const int rem = len - 4 * w;
@@ -561,7 +568,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
         // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s, each plan at its real LDS fit): 3 per CU
         // 1.56x (l=1000 e=5%), 4 per CU 1.55x (l=400 e=10%); 6 per CU 1.07x / 0.91x / 0.79x; 11 per CU 0.57x; 16 per CU
         // 0.48x. 5 per CU is not measured.
-        const size_t stage = g >= 32 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;   // G >= 32 packs from global memory
+        const size_t stage = g >= AIM_GROUP_DIRECT_G ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;   // G >= 32 packs from global memory
         const size_t wg = stage + (size_t)(kWave / g) * dw * 4 + 64;
         if (lds_workgroups_per_cu(wg) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
     }
@@ -571,7 +578,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     }
     *G = g;
     c->rows_per_wave = kWave / g;
-    const size_t rows_bytes = g >= 32 ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
+    const size_t rows_bytes = g >= AIM_GROUP_DIRECT_G ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
     if (*lds > 64 * 1024) return false;   // beyond the dynamic-LDS limit of a plain launch (only a forced AIM_GROUP_G gets here)
     const size_t lds_fit = lds_workgroups_per_cu(*lds);
@@ -579,7 +586,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     // the fused score step and the correct LDS granule; sweep on one box (ms at 8 -> best per CU): l=100 e=2% 0.671 -> 0.553
     // (11), e=5% 3.85 -> 2.82 (14), e=10% 6.17 -> 4.10 (16), l=250 e=5% 4.23 -> 3.53 (11), l=150 e=2% 1.94 -> 1.28 (16),
     // l=100 e=5% CIGAR 2.29 -> 1.73 (14); G = 64 (cfg3): 11 / 12 / 13 / 14 per CU = 7.81 / 7.10 / 7.42 / 7.06 ms.
-    uint32_t per_cu = (uint32_t)std::min<size_t>(16, lds_fit);
+    uint32_t per_cu = (uint32_t)std::min<size_t>(AIM_GROUP_MAX_PER_CU, lds_fit);
     if (kn.group_per_cu >= 0) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.group_per_cu), lds_fit);   // residency sweeps
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
     uint32_t gr = 256 * per_cu;
