@@ -258,6 +258,9 @@ def test_cfg2_full_size_4M_pairs(gpu):
     assert np.array_equal(res["score"], ores["score"])
     # checksum of checksums: order-sensitive digest of (idx, score)
     assert md5(res["score"].tobytes()) == md5(ores["score"].tobytes())
+    # the same 4M pairs through the opt-in compact layouts (8-B WFA request_t in, {idx, score} out): what bench.py times
+    cres, _ = engine.align(engine.make_params("wfa", ms, rs, reduce=True, req8=True, res8=True), req, pat, txt)
+    assert np.array_equal(cres["idx"], res["idx"]) and np.array_equal(cres["score"], ores["score"])
 
 
 def test_multi_device_split_matches_single(gpu):
