@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cells", type=float, default=4e8, help="bound on n * l * l per case (oracle time)")
-    ap.add_argument("--focus", choices=["all", "lane"], default="all", help="'lane': stay inside wfa_lane_kernel's eligibility window")
+    ap.add_argument("--focus", choices=["all", "lane", "genasm"], default="all", help="'lane': stay inside wfa_lane_kernel's eligibility window; 'genasm': GenASM only")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     lib = capi.load()
@@ -77,6 +77,39 @@ def main():
                 err = "exception: %r" % (ex,)
             cases += 1
             kernels[kn] = kernels.get(kn, 0) + 1
+            if err:
+                print(json.dumps(dict(case, ok=False)), flush=True)
+                print("MISMATCH:", err, flush=True)
+                return 1
+            continue
+        if a.focus == "genasm":
+            # GenASM (parity unpinned: checked against oracle/genasm_oracle.c): any length, error rates up to 45 % (windows beyond the
+            # 16-level fast path), unrelated texts, non-ACGT bytes
+            l = rng.choice([1, 2, 17, 39, 40, 41, 63, 64, 65, 100, 128, 200, 500, 1000, 3000, 8000])
+            e = rng.choice([0.0, 0.01, 0.05, 0.10, 0.20, 0.30, 0.45])
+            rs = ((int(l * (1 + e)) + 8 + 7) // 8) * 8
+            n = int(min(rng.choice([1, 3, 64, 65, 500, 2000]), max(1, 4e7 // (l * 64))))
+            bt = rng.random() < 0.7
+            params = engine.make_params("genasm", 0, rs, backtrace=bt, res8=(not bt and rng.random() < 0.3))
+            req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
+            for i in range(n):
+                r = rng.random()
+                if r < 0.1:                                   # unrelated text
+                    tl = int(req["text_len"][i]); txt[i, :tl] = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(tl)), dtype=np.uint8)
+                elif r < 0.2:
+                    pat[i, rng.randrange(l)] = ord(rng.choice("Nn*"))
+            case = dict(algo="genasm", l=l, e=e, n=n, read_size=rs, backtrace=int(bt), kernel="genasm_wave_kernel")
+            try:
+                if params.flags & capi.FLAG_RES8:
+                    res, _ = engine.align(params, req, pat, txt)
+                    ores, _, _ = oracle.align_batch(oracle.params("genasm", 0, rs), req["pattern_len"], req["text_len"], pat, txt, nthreads=64)
+                    err = None if np.array_equal(res["score"], ores["score"]) else "score differs (res8)"
+                else:
+                    err = compare("genasm", params, req, pat, txt)
+            except Exception as ex:
+                err = "exception: %r" % (ex,)
+            cases += 1
+            kernels["genasm_wave_kernel"] = kernels.get("genasm_wave_kernel", 0) + 1
             if err:
                 print(json.dumps(dict(case, ok=False)), flush=True)
                 print("MISMATCH:", err, flush=True)

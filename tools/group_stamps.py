@@ -5,11 +5,13 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aim_amd import capi, engine
 lib = capi.load()
-n = 1 << 15
-ms, rs = engine.launcher_sizes("wfa", 1000, 0.05)
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+E = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 15
+ms, rs = engine.launcher_sizes("wfa", L, E)
 params = engine.make_params("wfa", ms, rs, reduce=True)
 assert lib.aim_kernel_name(C.byref(params)) == b"wfa_group_kernel"
-req, pat, txt = engine.gen_pairs(42, 0, n, 1000, 0.05, rs)
+req, pat, txt = engine.gen_pairs(42, 0, n, L, E, rs)
 dev = torch.device("cuda", 0)
 def to_dev(a, pad=64):
     t = torch.zeros(a.nbytes + pad, dtype=torch.uint8, device=dev); t[:a.nbytes].copy_(torch.from_numpy(a.view(np.uint8).reshape(-1))); return t
@@ -19,10 +21,12 @@ sb = lib.aim_scratch_bytes(C.byref(params), n)
 d_scr = torch.zeros(sb, dtype=torch.uint8, device=dev)
 capi.check(lib.aim_align_device(C.byref(params), n, d_req.data_ptr(), d_pat.data_ptr(), d_txt.data_ptr(), d_res.data_ptr(), None, d_scr.data_ptr(), sb, None))
 torch.cuda.synchronize()
-grid = int(sys.argv[1]) if len(sys.argv) > 1 else 3584
+buf = C.create_string_buffer(512); capi.check(lib.aim_plan_describe(C.byref(params), n, buf, 512)); plan = buf.value.decode(); print(plan)
+grid = int(plan.split("grid=")[1].split()[0]) if len(sys.argv) < 2 or sys.argv[1] == "auto" else int(sys.argv[1])
+ppw = 64 // int(plan.split(" G=")[1].split()[0])
 st = d_scr[256: 256 + grid * 64].cpu().numpy().view(np.uint64).reshape(grid, 8).astype(np.float64)
 res = np.frombuffer(d_res[: n * 24].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
-steps = float(res["score"].sum()) / grid
+steps = float(res["score"].sum()) / grid / ppw   # wave score-steps ~ mean score x units per wave (the wave steps to its slowest pair: a lower bound)
 names = ["staging+pack", "reduce+desc+end", "score++/src desc", "compute+extend", "desc store", "loop edge", "exit", "backtrace+result"]
 tot = st.sum(axis=1).mean()
 print("per-wave ticks %.0f, score steps per wave %.0f, ticks/step %.0f" % (tot, steps, tot / steps))
