@@ -40,7 +40,7 @@
 #define AIM_LANE_NT_STORE 0       // 1 = score-only result stores are nontemporal
 #endif
 #ifndef AIM_LANE_PACK_X2
-#define AIM_LANE_PACK_X2 1        // pack from 2 * code (no per-dword shift); 0 = the round-1 form
+#define AIM_LANE_PACK_X2 0        // 1 = pack from 2 * code (no per-dword shift); off until measured and parity-checked on the GPU
 #endif
 #ifndef AIM_LANE_STAMPS
 #define AIM_LANE_STAMPS 0         // diagnostic build only: s_memtime per segment, summed per wave into scratch
