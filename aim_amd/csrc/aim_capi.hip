@@ -801,65 +801,80 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
     HIP_TRY(hipSetDevice(d.dev));
     s.io = *io;
     s.n_pairs = n;
-    HIP_TRY(hipEventRecord(s.ev[0], s.stream));
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(s.d_req, io->requests, (size_t)n * req_size(p), hipMemcpyHostToDevice, s.stream));
-        if (packed) {
-            HIP_TRY(hipMemcpyAsync(s.d_packP, io->packed_patterns, (size_t)n * rowb, hipMemcpyHostToDevice, s.stream));
-            HIP_TRY(hipMemcpyAsync(s.d_packT, io->packed_texts, (size_t)n * rowb, hipMemcpyHostToDevice, s.stream));
-            if (io->n_raw) {
-                HIP_TRY(hipMemcpyAsync(s.d_rawidx, io->raw_pairs, (size_t)io->n_raw * 4, hipMemcpyHostToDevice, s.stream));
-                HIP_TRY(hipMemcpyAsync(s.d_rawP, io->raw_patterns, (size_t)io->n_raw * rs, hipMemcpyHostToDevice, s.stream));
-                HIP_TRY(hipMemcpyAsync(s.d_rawT, io->raw_texts, (size_t)io->n_raw * rs, hipMemcpyHostToDevice, s.stream));
-            }
-        } else {
-            HIP_TRY(hipMemcpyAsync(s.d_pat, io->patterns, (size_t)n * rs, hipMemcpyHostToDevice, s.stream));
-            HIP_TRY(hipMemcpyAsync(s.d_txt, io->texts, (size_t)n * rs, hipMemcpyHostToDevice, s.stream));
-        }
-    }
-    HIP_TRY(hipEventRecord(s.ev[1], s.stream));
-    HIP_TRY(hipEventRecord(s.ev[2], s.stream));
-    if (n) {
-        aim::KArgs ka;
-        memset(&ka, 0, sizeof ka);
-        ka.p = p;
-        ka.n_pairs = n;
-        ka.req = static_cast<const aim_request_t *>(s.d_req);
-        ka.res = static_cast<aim_result_t *>(s.d_res);
-        ka.ops = s.d_ops;
-        if (packed) {   // expand into the reference's char[n][READ_SIZE] layout (batch_io.hpp), then run as usual
-            const uint64_t threads = (uint64_t)n * (rs / 8);
-            hipLaunchKernelGGL(aim::unpack_rows_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s.stream, ka, s.d_packP,
-                               s.d_packT, s.d_pat, s.d_txt);
-            if (io->n_raw) {
-                const uint64_t rt = (uint64_t)io->n_raw * (rs / 8);
-                hipLaunchKernelGGL(aim::scatter_raw_rows_kernel, dim3((unsigned)((rt + 255) / 256), 2), dim3(256), 0, s.stream, p.read_size,
-                                   io->n_raw, s.d_rawidx, s.d_rawP, s.d_rawT, s.d_pat, s.d_txt);
-            }
-            HIP_TRY(hipGetLastError());
-        }
-        rc = launch_on_slot(set, d, s);
-        if (rc) return rc;
-        if (io->cigars) {
-            HIP_TRY(hipMemsetAsync(s.d_cursor, 0, 4, s.stream));
-            hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((n + 63) / 64), dim3(64), 0, s.stream, ka, s.d_cig, s.d_runs,
-                               std::min(io->runs_cap, set->max_runs), s.d_cursor);
-            HIP_TRY(hipGetLastError());
-        }
-    }
-    HIP_TRY(hipEventRecord(s.ev[3], s.stream));
-    HIP_TRY(hipEventRecord(s.ev[4], s.stream));
-    if (n) {
-        if (io->cigars) {
-            HIP_TRY(hipMemcpyAsync(s.h_cursor, s.d_cursor, 4, hipMemcpyDeviceToHost, s.stream));
-            HIP_TRY(hipMemcpyAsync(io->cigars, s.d_cig, (size_t)n * sizeof(aim_cigar_t), hipMemcpyDeviceToHost, s.stream));
-        }
-        if (io->results) HIP_TRY(hipMemcpyAsync(io->results, s.d_res, (size_t)n * res_size(p), hipMemcpyDeviceToHost, s.stream));
-        if (io->ops) HIP_TRY(hipMemcpyAsync(io->ops, s.d_ops, (size_t)n * 2 * rs, hipMemcpyDeviceToHost, s.stream));
-    }
-    HIP_TRY(hipEventRecord(s.ev[5], s.stream));
-    s.submitted = true;
     s.pushed = s.launched = false;
+    // Everything below only enqueues work on the slot's stream. Should an enqueue fail half-way, the copies already queued
+    // still reference the caller's buffers: the stream is drained before the error is returned, so that a failed submit
+    // never leaves the slot (or the caller's memory) in flight.
+    auto enqueue = [&]() -> int {
+        HIP_TRY(hipEventRecord(s.ev[0], s.stream));
+        if (n) {
+            HIP_TRY(hipMemcpyAsync(s.d_req, io->requests, (size_t)n * req_size(p), hipMemcpyHostToDevice, s.stream));
+            if (packed) {
+                HIP_TRY(hipMemcpyAsync(s.d_packP, io->packed_patterns, (size_t)n * rowb, hipMemcpyHostToDevice, s.stream));
+                HIP_TRY(hipMemcpyAsync(s.d_packT, io->packed_texts, (size_t)n * rowb, hipMemcpyHostToDevice, s.stream));
+                if (io->n_raw) {
+                    HIP_TRY(hipMemcpyAsync(s.d_rawidx, io->raw_pairs, (size_t)io->n_raw * 4, hipMemcpyHostToDevice, s.stream));
+                    HIP_TRY(hipMemcpyAsync(s.d_rawP, io->raw_patterns, (size_t)io->n_raw * rs, hipMemcpyHostToDevice, s.stream));
+                    HIP_TRY(hipMemcpyAsync(s.d_rawT, io->raw_texts, (size_t)io->n_raw * rs, hipMemcpyHostToDevice, s.stream));
+                }
+            } else {
+                HIP_TRY(hipMemcpyAsync(s.d_pat, io->patterns, (size_t)n * rs, hipMemcpyHostToDevice, s.stream));
+                HIP_TRY(hipMemcpyAsync(s.d_txt, io->texts, (size_t)n * rs, hipMemcpyHostToDevice, s.stream));
+            }
+        }
+        HIP_TRY(hipEventRecord(s.ev[1], s.stream));
+        HIP_TRY(hipEventRecord(s.ev[2], s.stream));
+        if (n) {
+            aim::KArgs ka;
+            memset(&ka, 0, sizeof ka);
+            ka.p = p;
+            ka.n_pairs = n;
+            ka.req = static_cast<const aim_request_t *>(s.d_req);
+            ka.res = static_cast<aim_result_t *>(s.d_res);
+            ka.ops = s.d_ops;
+            if (packed) {   // expand into the reference's char[n][READ_SIZE] layout (batch_io.hpp), then run as usual
+                const uint64_t threads = (uint64_t)n * (rs / 8);
+                hipLaunchKernelGGL(aim::unpack_rows_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s.stream, ka, s.d_packP,
+                                   s.d_packT, s.d_pat, s.d_txt);
+                if (io->n_raw) {
+                    const uint64_t rt = (uint64_t)io->n_raw * (rs / 8);
+                    hipLaunchKernelGGL(aim::scatter_raw_rows_kernel, dim3((unsigned)((rt + 255) / 256), 2), dim3(256), 0, s.stream, p.read_size,
+                                       io->n_raw, s.d_rawidx, s.d_rawP, s.d_rawT, s.d_pat, s.d_txt);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+            rc = launch_on_slot(set, d, s);
+            if (rc) return rc;
+            if (io->cigars) {
+                HIP_TRY(hipMemsetAsync(s.d_cursor, 0, 4, s.stream));
+                hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((n + 63) / 64), dim3(64), 0, s.stream, ka, s.d_cig, s.d_runs,
+                                   std::min(io->runs_cap, set->max_runs), s.d_cursor);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        HIP_TRY(hipEventRecord(s.ev[3], s.stream));
+        HIP_TRY(hipEventRecord(s.ev[4], s.stream));
+        if (n) {
+            if (io->cigars) {
+                HIP_TRY(hipMemcpyAsync(s.h_cursor, s.d_cursor, 4, hipMemcpyDeviceToHost, s.stream));
+                HIP_TRY(hipMemcpyAsync(io->cigars, s.d_cig, (size_t)n * sizeof(aim_cigar_t), hipMemcpyDeviceToHost, s.stream));
+            }
+            if (io->results) HIP_TRY(hipMemcpyAsync(io->results, s.d_res, (size_t)n * res_size(p), hipMemcpyDeviceToHost, s.stream));
+            if (io->ops) HIP_TRY(hipMemcpyAsync(io->ops, s.d_ops, (size_t)n * 2 * rs, hipMemcpyDeviceToHost, s.stream));
+        }
+        HIP_TRY(hipEventRecord(s.ev[5], s.stream));
+        return AIM_OK;
+    };
+    rc = enqueue();
+    if (rc) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        (void)hipStreamSynchronize(s.stream);
+        (void)hipGetLastError();
+        memcpy(g_err, keep, sizeof keep);
+        return rc;
+    }
+    s.submitted = true;
     return AIM_OK;
 }
 

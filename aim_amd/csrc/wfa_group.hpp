@@ -1,16 +1,17 @@
-// wfa_group.hpp -- short-read WFA / WFA-adaptive for ANY penalties / MAX_SCORE (score-only): G LANES PER PAIR,
+// wfa_group.hpp -- WFA / WFA-adaptive for ANY penalties / MAX_SCORE, score-only or with CIGAR: G LANES PER PAIR,
 // 64/G pairs per wavefront, everything after the HBM->LDS DMA in LDS and registers.
 //
 // Same results as affine_wfa_compute (WFA/DPU-WRAM/dpu/wfa.c:342-379, with -DREDUCE wfa.c:69-140).  The static
-// kernel (wfa_lane.hpp) covers the reference's default shape at MAX_SCORE <= 5; this one covers the rest of the
-// short-read space (READ_SIZE <= 512, MAX_SCORE up to ~120) at run-time parameters:
-//   * a pair is owned by G consecutive lanes (G = 1,2,4,8,16, picked so that the wavefront window of all 64/G
-//     pairs of a wavefront fits ~24 KiB of LDS); the lanes of a group take the diagonals k = lo+g, lo+g+G, ...
+// kernel (wfa_lane.hpp) covers the reference's default penalties at MAX_SCORE <= 5 (<= 10 score-only); this one covers
+// the rest (READ_SIZE <= 2048, MAX_SCORE <= 400; beyond that wfa_wave.hpp) at run-time parameters:
+//   * a pair is owned by G consecutive lanes (G = 1 .. 64, picked by wfa_group_plan from the LDS one pair's window
+//     needs and the residency that leaves); the lanes of a group take the diagonals k = lo+g, lo+g+G, ...
 //   * the live window of wavefronts -- M for the last max(x,o+e)+1 scores, I and D for the last e+1 -- lives in
-//     LDS as int16, indexed [ring slot][k + MAX_SCORE + 1], so every diagonal a score can ever touch has a fixed
-//     home and the +/-1 neighbours of affine_wfa_compute_offsets (wfa.c:231-266) are plain LDS reads;
-//   * sequences arrive by LDS-DMA exactly as in wfa_lane.hpp, are validated (A/C/G/T only) and packed 2 bits per
-//     base into LDS; affine_wfa_extend (wfa.c:186-208) compares 16 bases per step with funnel shifts;
+//     LDS as int16, indexed [ring slot][k + MAX_SCORE + 1] (or modulo 128 in the narrow-window mode, GroupCfg::wlds),
+//     so the +/-1 neighbours of affine_wfa_compute_offsets (wfa.c:231-266) are plain LDS reads;
+//   * sequences arrive by LDS-DMA as in wfa_lane.hpp (G < 8) or straight from global memory (G >= 8), are validated
+//     (A/C/G/T only) and packed 2 bits per base into LDS; affine_wfa_extend (wfa.c:186-208) compares 32 bases per
+//     trip with funnel shifts;
 //   * per-pair descriptors (klo, khi, flags) sit in a small LDS ring, so WFA-adaptive's per-pair bounds
 //     (wfa.c:96-139) cost nothing when they do not fire.
 // Pairs with non-ACGT bytes go to the to-do list drained by wfa_wave_kernel, as in wfa_lane.hpp.
@@ -25,6 +26,12 @@
 
 #ifndef AIM_GROUP_DIRECT_G
 #define AIM_GROUP_DIRECT_G 8      // groups of at least this many lanes pack their sequences straight from global memory (no LDS staging rows)
+#endif
+// Wavefronts per SIMD the register allocation must leave room for (20 single-wave workgroups per CU = 5 per SIMD = at
+// most 96 VGPRs). The score-only variants use 61-68 registers; the CIGAR variants sit at 87-100, right at that step, and one
+// register over it cost cfg3 with CIGAR 28 % (4.45 -> 5.71 ms, same box): the bound is stated instead of left to chance.
+#ifndef AIM_GROUP_MIN_WAVES
+#define AIM_GROUP_MIN_WAVES 5
 #endif
 #ifndef AIM_GROUP_MAX_PER_CU
 #define AIM_GROUP_MAX_PER_CU 20   // cap on resident single-wave workgroups per CU (5 per SIMD at <= 102 VGPRs; 24 measured worse on cfg3 with CIGAR)
@@ -77,7 +84,7 @@ __device__ __forceinline__ int group_min(int v)
 #define AIM_GSTAMP(i) do { } while (0)
 #endif
 template <int G, bool REDUCE, bool BT>
-__global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MIN_WAVES))) void wfa_group_kernel(KArgs a, GroupCfg c)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
@@ -217,14 +224,20 @@ __global__ __launch_bounds__(64) void wfa_group_kernel(KArgs a, GroupCfg c)
             if (off < 0 || v < 0) return off;
             int rem = min(plen - v, tlen - h);
             while (rem > 0) {
+                // 32 bases per trip: the trip count of a wavefront is its longest run, and every pair has one diagonal on
+                // which runs average 1/e bases (same box, 16 -> 32 bases: l=100 e=5 % +3.3 %, l=150 e=2 % +6 %, cfg3 +2-3 %).
+                // Word wp + 2 may lie one dword past the pair's packed image (the next array, or the workgroup's 64-B LDS
+                // slack): whatever it holds sits >= 128 - v bases ahead, beyond `rem`.
                 const int wp = v >> 4, wt = h >> 4;
-                const uint32_t pw = __builtin_amdgcn_alignbit(pkP[wp + 1], pkP[wp], (uint32_t)((v & 15) * 2));
-                const uint32_t tw = __builtin_amdgcn_alignbit(pkT[wt + 1], pkT[wt], (uint32_t)((h & 15) * 2));
-                const uint32_t x = pw ^ tw;
-                const int n = x ? (__builtin_ctz(x) >> 1) : 16;
-                if (n >= rem) { v += rem; h += rem; break; }
-                v += n; h += n; rem -= n;
-                if (n < 16) break;
+                const uint32_t sp = (uint32_t)((v & 15) * 2), st = (uint32_t)((h & 15) * 2);
+                const uint32_t p0 = pkP[wp], p1 = pkP[wp + 1], p2 = pkP[wp + 2];
+                const uint32_t t0 = pkT[wt], t1 = pkT[wt + 1], t2 = pkT[wt + 2];
+                const uint32_t xlo = __builtin_amdgcn_alignbit(p1, p0, sp) ^ __builtin_amdgcn_alignbit(t1, t0, st);
+                const uint32_t xhi = __builtin_amdgcn_alignbit(p2, p1, sp) ^ __builtin_amdgcn_alignbit(t2, t1, st);
+                const int n = xlo ? (__builtin_ctz(xlo) >> 1) : (xhi ? 16 + (__builtin_ctz(xhi) >> 1) : 32);
+                const int adv = min(n, rem);       // stop at the first mismatch or at the end of either sequence
+                h += adv; v += adv; rem -= adv;
+                if (adv < 32) break;
             }
             return h;
         };

@@ -14,6 +14,7 @@ from aim_amd import capi, engine  # noqa: E402
 CONFIGS = {
     "wfa_l100_e1_cigar": dict(algo="wfa", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True, reduce=True)),
     "wfa_l100_e2_score": dict(algo="wfa", l=100, e=0.02, n=1 << 20, kw=dict(reduce=True)),
+    "wfa_l100_e2_cigar": dict(algo="wfa", l=100, e=0.02, n=1 << 20, kw=dict(backtrace=True, reduce=True)),
     "wfa_l100_e5_score": dict(algo="wfa", l=100, e=0.05, n=1 << 20, kw=dict(reduce=True)),
     "wfa_l100_e10_score": dict(algo="wfa", l=100, e=0.10, n=1 << 19, kw=dict(reduce=True)),
     "wfa_l250_e5_score": dict(algo="wfa", l=250, e=0.05, n=1 << 18, kw=dict(reduce=True)),

@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cells", type=float, default=4e8, help="bound on n * l * l per case (oracle time)")
-    ap.add_argument("--focus", choices=["all", "lane", "genasm"], default="all", help="'lane': stay inside wfa_lane_kernel's eligibility window; 'genasm': GenASM only")
+    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa"], default="all", help="'lane': stay inside wfa_lane_kernel's eligibility window; 'genasm': GenASM only; 'wfa': the general generator restricted to WFA (wfa_group / wfa_wave / wfa_lane)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     lib = capi.load()
@@ -115,7 +115,7 @@ def main():
                 print("MISMATCH:", err, flush=True)
                 return 1
             continue
-        algo = rng.choice(["wfa", "wfa", "wfa", "nw", "swg"])
+        algo = "wfa" if a.focus == "wfa" else rng.choice(["wfa", "wfa", "wfa", "nw", "swg"])
         l = rng.choice([3, 8, 20, 33, 64, 100, 100, 150, 250, 300, 400, 700, 1000, 1500, 2500, 3500])
         e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15, 0.25])
         cost = {}
