@@ -6,17 +6,21 @@
 // Algorithm 1; GenASM-TB and the W = 64 / O = 24 windows, Section 6) exactly as oracle/genasm_oracle.c restates it --
 // every open choice is fixed there and marked [spec] -- and is tested bit for bit against that restatement.
 //
-// Mapping.  A pair of 100 kb reads is ~2 500 dependent windows, so the parallelism has to come from inside a window.
-// GenASM-DC's levels are coupled only through the pattern-only edit (R_a[d] needs the NEW R_a[d-1] << 1):
-//     R_a[d] = X_a[d] & (R_a[d-1] << 1),   X_a[d] = match & substitution & text-only edit   (all from column a+1)
-//  => R_a[d] = AND_{j <= d} (X_a[d-j] << j), a prefix-AND with a shift per step: six Hillis-Steele steps over the lanes
-//     (stride 1, 2, 4, ..., 32; the shift of a step equals its stride), instead of GenASM's 64-deep hardware chain.
-// Almost every window needs far fewer than 16 edits, so the column loop first runs levels 0..15 only, in one 16-lane DPP row
-// (four row_shr steps, no LDS crossbar), and falls back to all 64 levels (six ds_bpermute steps) when that finds no alignment.
-// Lane d keeps R[d] of the current column in two VGPRs; every column is also kept ([a][d]: 16 levels in LDS, 8.3 KB per
-// wavefront; all 64 in an HBM slab on the slow path) because the traceback -- a wave-uniform walk of <= ~80 steps per window -- reads R_a[d], R_{a+1}[d] and
-// R_{a+1}[d-1] along its path.  Pattern masks are not tabulated: PM[c] = ~ballot(reversed pattern char == c) is one
-// compare per text character and works for ANY byte values (the reference family compares raw bytes).
+// Mapping.  A pair of 100 kb reads is ~2 500 dependent windows, so what matters is the LATENCY of one window, and the
+// parallelism has to come from inside it. Lane d owns error level d. GenASM-DC (Algorithm 1), columns a = n-1 .. 0:
+//     R_a[d] = ((R_{a+1}[d] << 1) | PM[t_a])  &  (R_{a+1}[d-1] << 1)  &  R_{a+1}[d-1]  &  (R_a[d-1] << 1)
+//              match                             substitution            text-only edit   pattern-only edit
+// Level d of column a needs level d-1 of the SAME column, so a column-by-column sweep is a 16- (or 64-) deep chain per
+// column (round 2's first version ran it as a prefix-AND-with-shift scan: 4-6 dependent DPP steps per column, ~440 cycles
+// per column). The sweep is instead SKEWED: at step u lane d works on column n-1-(u-d). Everything it needs from lane d-1 is
+// then that lane's value after step u-1 (R_a[d-1]) and after step u-2 (R_{a+1}[d-1]): ONE DPP shift by one lane per step and
+// a remembered copy, n + 15 (or n + 63) steps of ~6 dependent instructions per window. The pattern masks travel the same
+// way: lane j first holds PM of text column j (one ballot per DISTINCT character of the window, any byte values -- the
+// reference family compares raw bytes), lane 0 picks column n-1-u with a v_readlane, and the masks shift one lane per step.
+// Almost every window needs far fewer than 16 edits, so the sweep first runs levels 0..15 only (one 16-lane DPP row, columns
+// kept in LDS: 13 KB per wavefront) and falls back to all 64 levels (wave_shr DPP, columns in an HBM slab) when that finds
+// no alignment. Every column is kept ([a][d]) because the traceback -- a wave-uniform walk of <= ~80 steps per window --
+// reads R_a[d], R_{a+1}[d] and R_{a+1}[d-1] along its path.
 // Integer / bit work only; HBM sees each sequence byte once and the ops once.
 #pragma once
 
@@ -26,23 +30,53 @@ namespace aim {
 
 constexpr int kGaW = 64;        // window
 constexpr int kGaCommit = 40;   // W - O
+// Fast-path column store in LDS: columns -16 .. W+16 (the skewed sweep lets a level run up to 15 columns past either end, its
+// mask prefetch one more; what it computes there is never read), 17 slots of 8 B per column: R_a[0..15] and the column's pattern mask.
+constexpr int kGaPad = 16, kGaSlots = 17, kGaCols = kGaPad + kGaW + 1 + kGaPad;
 
-__device__ __forceinline__ uint64_t ga_shfl_up(uint64_t v, int delta, int lane)
+// lane L receives the value of lane L - 1 (WIDE: of the wavefront, DPP wave_shr:1; otherwise of its own 16-lane row, DPP
+// row_shr:1); lane 0 (of the wavefront / of each row) receives `fill`
+template <bool WIDE>
+__device__ __forceinline__ uint64_t ga_shr1(uint64_t v, uint64_t fill)
 {
-    // lanes < delta receive their own value (they ignore it)
-    const int src = (lane - delta) < 0 ? lane : lane - delta;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)(v >> 32));
+    constexpr int ctrl = WIDE ? 0x138 : 0x111;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, ctrl, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), ctrl, 0xf, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
 }
-// lane L receives the value of lane L - S of its own 16-lane row (DPP row_shr: no LDS crossbar); lanes whose source would
-// lie outside the row receive `fill`
-template <int S>
-__device__ __forceinline__ uint64_t ga_row_shr(uint64_t v, uint64_t fill)
+__device__ __forceinline__ uint64_t ga_readlane(uint64_t v, int src)   // src wave-uniform
 {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x110 + S, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x110 + S, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
+}
+// GenASM-DC of one window, skewed (see the header): levels 0 .. LV-1 in lanes 0 .. LV-1, columns n-1 .. 0; column a of
+// level d is stored at cols[a * LV + d] (column n = the initial ~0 << d included). Returns R_0[lane].
+template <bool WIDE>
+__device__ __forceinline__ uint64_t ga_dc(int n_, int lane, uint64_t mypm, uint64_t *cols)
+{
+    const int n = __builtin_amdgcn_readfirstlane(n_);   // wave-uniform by construction; said so for the v_readlane index below
+    constexpr int LV = WIDE ? 64 : 16;
+    constexpr uint64_t ONES = ~0ull;
+    const bool mine = lane < LV;
+    uint64_t cur = ONES << lane;                         // R_n[d]
+    if (mine) cols[n * LV + lane] = cur;
+    uint64_t nb_prev = ga_shr1<WIDE>(cur, ONES);         // lane d-1 two steps ago
+    uint64_t pmv = ONES;
+    for (int u = 0; u < n + LV - 1; ++u) {
+        const int c0 = n - 1 - u;                        // lane 0's column at this step
+        pmv = ga_shr1<WIDE>(pmv, ga_readlane(mypm, c0 < 0 ? 0 : c0));
+        const uint64_t nb_cur = ga_shr1<WIDE>(cur, ONES);                 // lane d-1 one step ago: R_a[d-1]
+        const int col = c0 + lane;                       // my column
+        uint64_t y = (cur << 1) | pmv;                   // match
+        if (lane > 0) y &= (nb_prev << 1) & nb_prev & (nb_cur << 1);      // substitution, text-only edit, pattern-only edit
+        nb_prev = nb_cur;
+        if (mine && col >= 0 && col < n) {
+            cur = y;
+            cols[col * LV + lane] = y;
+        }
+    }
+    return cur;
 }
 __device__ __forceinline__ uint64_t ga_uniform(uint64_t v)   // value known to be wave-uniform -> SGPRs
 {
@@ -51,18 +85,85 @@ __device__ __forceinline__ uint64_t ga_uniform(uint64_t v)   // value known to b
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The same sweep for levels 0..15 (lanes 0..15), written for the fewest instructions per step: a single wavefront issues
+// one instruction every ~4-5 cycles whatever its type, and a window is n + 15 dependent steps, so the step's instruction
+// count IS the window's latency (stamps: 43 instructions, 232 cycles per step before; BASELINE config 5 is 2 500 windows
+// per pair). No lane tests "is my column inside the window": a level that has not started sees pattern masks of ~0 (stored
+// for columns n .. n+15), which keep it at its initial ~0 << d, and a level that is finished computes on into 15 padding
+// columns below column 0 that nobody reads. The pattern mask of a column is read from the column's 17th LDS slot (no
+// readlane / DPP feed), lane 0's "no level below me" is an OR with a constant, and the sweep stops at the first level whose
+// column 0 reports an alignment: the traceback starts there and only ever moves to lower levels.
+// Returns the ballot of levels (so far) whose R_0 has bit m-1 clear; 0 = no alignment within 15 edits.
+__device__ __forceinline__ int ga_slot(int col) { return (kGaPad + kGaW - col) * kGaSlots; }   // columns are stored in DESCENDING order: the sweep's addresses ascend (immediate offsets)
+__device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t mypm, uint64_t *Rs)
+{
+    constexpr uint64_t ONES = ~0ull;
+    const int n = __builtin_amdgcn_readfirstlane(n_), m = __builtin_amdgcn_readfirstlane(m_);
+    if (lane < n) Rs[ga_slot(lane) + 16] = mypm;
+    uint64_t hit = 0;
+    if (lane < 16) {
+        Rs[ga_slot(n + lane) + 16] = ONES;
+        uint64_t cur = ONES << lane;                     // R_n[d]
+        Rs[ga_slot(n) + lane] = cur;
+        const uint64_t lane0 = lane == 0 ? ONES : 0ull;
+        const uint64_t endbit = 1ull << (m - 1);
+        uint64_t *rp = Rs + ga_slot(n - 1 + lane) + lane;                // my R slot of my column at step 0
+        const uint64_t *pp = Rs + ga_slot(n - 1 + lane) + 16;            // my column's pattern mask
+        auto shr1 = [](uint64_t v) -> uint64_t {         // lane d-1's value; lane 0 receives 0 (bound_ctrl), OR-ed away below
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x111, 0xf, 0xf, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x111, 0xf, 0xf, true);
+            return ((uint64_t)hi << 32) | lo;
+        };
+        // one step; the roles of the two neighbour registers and of the two mask registers alternate (no copies)
+        auto step = [&](const uint64_t &nb_prev, uint64_t &nb_cur, const uint64_t &pm_now, uint64_t &pm_next, int k) {
+            pm_next = pp[(k + 1) * kGaSlots];            // next step's mask: off the dependent chain
+            nb_cur = shr1(cur);                          // lane d-1 one step ago: R_a[d-1]
+            // substitution (R_{a+1}[d-1] << 1), text-only edit (R_{a+1}[d-1]), pattern-only edit (R_a[d-1] << 1); level 0 has none
+            const uint64_t t = (((nb_prev & nb_cur) << 1) & nb_prev) | lane0;
+            cur = ((cur << 1) | pm_now) & t;             // match
+            rp[k * kGaSlots] = cur;
+        };
+        uint64_t nbA = shr1(cur), nbB, pmA = pp[0], pmB;  // nbA: lane d-1 two steps ago
+        int u = 0;
+        for (; u + 2 <= n - 1; u += 2) {                 // no level has reached column 0 yet
+            step(nbA, nbB, pmA, pmB, 0);
+            step(nbB, nbA, pmB, pmA, 1);
+            rp += 2 * kGaSlots;
+            pp += 2 * kGaSlots;
+        }
+        if (u < n - 1) {
+            step(nbA, nbB, pmA, pmB, 0);
+            nbA = nbB; pmA = pmB;
+            rp += kGaSlots; pp += kGaSlots;
+        }
+        for (u = n - 1; u < n + 15; ++u) {               // level u - (n-1) completes column 0 in this step
+            step(nbA, nbB, pmA, pmB, 0);
+            nbA = nbB; pmA = pmB;
+            rp += kGaSlots; pp += kGaSlots;
+            hit = __ballot(lane == u - (n - 1) && !(cur & endbit));
+            if (hit) break;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
+}
+#ifdef AIM_GA_STAMPS   // diagnostic builds only: s_memtime per phase of a window, summed per pair, dumped into the pair's ops row
+#define AIM_GASTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); gsum[i] += t_ - glast; glast = t_; } while (0)
+#else
+#define AIM_GASTAMP(i) do { } while (0)
+#endif
 template <bool BT>
 __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
-    // Columns of the window for the traceback. The fast path (16 levels) keeps them in LDS, [kGaW + 1][16] = 8.3 KB, so that
+    // Columns of the window for the traceback. The fast path (16 levels) keeps them in LDS, [kGaCols][17] x 8 B = 13 KB, so that
     // 8 wavefronts are resident per CU (all 64 levels in LDS were 33 KB: 4 per CU, one per SIMD, nothing to overlap the
     // dependent column chain with); the rare slow path (a window needing 16..63 edits) writes [kGaW + 1][64] to this
     // wavefront's slab of HBM scratch instead.
     uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);
     uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
-    unsigned char *wops = reinterpret_cast<unsigned char *>(Rs + (kGaW + 1) * 16);   // ops of the current window (<= 128)
+    unsigned char *wops = reinterpret_cast<unsigned char *>(Rs + kGaCols * kGaSlots);   // ops of the current window (<= 128)
     unsigned char *pwin = wops + 192, *twin = wops + 256;                            // the window's characters, for the traceback's run test
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
@@ -78,6 +179,10 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
         char *ops = BT ? a.ops + (uint64_t)pair * 2 * rs : nullptr;
         const int cap = 2 * rs;
         int pi = 0, ti = 0, nops = 0, dist = 0, status = AIM_PAIR_OK;   // wave-uniform
+#ifdef AIM_GA_STAMPS
+        unsigned long long gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(glast) :: "memory");
+#endif
 
         while (pi < plen && ti < tlen) {
             const int m = min(kGaW, plen - pi), n = min(kGaW, tlen - ti);
@@ -88,53 +193,30 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const int tfwd = lane < n ? (int)gT[ti + lane] : 0x300;
             pwin[lane] = (unsigned char)pfwd;
             twin[lane] = (unsigned char)tfwd;
-            // FAST PATH: levels 0..15 only, in lanes 0..15, with DPP row shifts (four scan steps, no LDS crossbar). Level d of a
-            // column depends on levels <= d only, so these 16 levels are exactly the first 16 of the full computation; if the
-            // window aligns within 15 edits (at e = 10 % a 64-character window carries ~6) the traceback never looks further.
-            uint64_t R = ONES << lane;                                           // R_n[d] = ~0 << d
-            if (lane < 16) Rs[n * 16 + lane] = R;
-            const int dl = lane & 15;
-            for (int col = n - 1; col >= 0; --col) {
-                const int c = __builtin_amdgcn_readlane(tfwd, col);
-                const uint64_t pm = ~__ballot(prev == c);                       // bit j = 0 <=> p[m-1-j] == t[col]
-                const uint64_t old = R;
-                const uint64_t oldm1 = ga_row_shr<1>(old, ONES);
-                uint64_t y = (old << 1) | pm;                                   // match
-                if (dl > 0) y &= (oldm1 << 1) & oldm1;                          // substitution, text-only edit (from level d-1)
-                uint64_t up;
-                up = ga_row_shr<1>(y, ONES); if (dl >= 1) y &= up << 1;         // pattern-only edit: prefix-AND with shift
-                up = ga_row_shr<2>(y, ONES); if (dl >= 2) y &= up << 2;
-                up = ga_row_shr<4>(y, ONES); if (dl >= 4) y &= up << 4;
-                up = ga_row_shr<8>(y, ONES); if (dl >= 8) y &= up << 8;
-                R = y;
-                if (lane < 16) Rs[col * 16 + lane] = R;
+            AIM_GASTAMP(0);   // window characters from HBM
+            // lane j: PM of text column j -- bit i = 0 <=> p[m-1-i] == t[j] -- from one ballot per distinct character
+            uint64_t mypm = ONES;
+            for (uint64_t rest = __ballot(lane < n); rest;) {
+                const int c = __builtin_amdgcn_readlane(tfwd, (int)__builtin_ctzll(rest));
+                const uint64_t pm = ~__ballot(prev == c);
+                if (tfwd == c) mypm = pm;
+                rest &= ~__ballot(tfwd == c);
             }
-            uint64_t hit = __ballot(lane < 16 && !((R >> (m - 1)) & 1ull));
+            AIM_GASTAMP(1);   // pattern masks
+            // FAST PATH: levels 0..15 only. Level d of a column depends on levels <= d only, so these are exactly the first 16 of
+            // the full computation; if the window aligns within 15 edits (at e = 10 % a 64-character window carries ~6) the
+            // traceback never looks further.
+            uint64_t hit = ga_dc16(n, m, lane, mypm, Rs);
             const bool slow = !hit;            // wave-uniform
+            AIM_GASTAMP(2);   // DC, 16 levels
             if (slow) {
-                // SLOW PATH (a window that needs 16..63 edits): all 64 levels, one per lane, scan steps through ds_bpermute;
-                // columns go to this wavefront's HBM slab
-                R = ONES << lane;
-                Rg[n * 64 + lane] = R;
-                for (int col = n - 1; col >= 0; --col) {
-                    const int c = __builtin_amdgcn_readlane(tfwd, col);
-                    const uint64_t pm = ~__ballot(prev == c);
-                    const uint64_t old = R;
-                    const uint64_t oldm1 = ga_shfl_up(old, 1, lane);
-                    uint64_t y = (old << 1) | pm;
-                    if (lane > 0) y &= (oldm1 << 1) & oldm1;
-#pragma unroll
-                    for (int s = 1; s < 64; s <<= 1) {
-                        const uint64_t up = ga_shfl_up(y, s, lane);
-                        if (lane >= s) y &= up << s;
-                    }
-                    R = y;
-                    Rg[col * 64 + lane] = R;
-                }
+                // SLOW PATH (a window that needs 16..63 edits): all 64 levels, columns to this wavefront's HBM slab
+                const uint64_t R = ga_dc<true>(n, lane, mypm, Rg);
                 hit = __ballot(!((R >> (m - 1)) & 1ull));
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront reads its own slab back below
             }
-            auto R_at = [&](int col, int lvl) -> uint64_t { return slow ? Rg[col * 64 + lvl] : Rs[col * 16 + lvl]; };
+            AIM_GASTAMP(3);   // DC, 64 levels (rare)
+            auto R_at = [&](int col, int lvl) -> uint64_t { return slow ? Rg[col * 64 + lvl] : Rs[ga_slot(col) + lvl]; };
             // d0 = smallest level whose bit m-1 is clear in column 0
             int d = hit ? (int)__builtin_ctzll(hit) : -1;
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the columns are in LDS (one wavefront: in-order LDS)
@@ -183,6 +265,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                     break;
                 }
             }
+            AIM_GASTAMP(4);   // traceback
             if (BT) {   // the window's ops leave as coalesced byte stores
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 for (int i = lane; i < wn; i += kWave)
@@ -191,8 +274,12 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             nops += wn;
             pi += cb;
             ti += ca;
+            AIM_GASTAMP(5);   // ops stores
             if (status != AIM_PAIR_OK) break;
         }
+#ifdef AIM_GA_STAMPS
+        if (BT && lane == 0) { unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ops); for (int i = 0; i < 8; ++i) dbg[i] = gsum[i]; }
+#endif
         if (status == AIM_PAIR_OK) {   // one sequence is exhausted: the rest of the other is gaps
             const int rp = plen - pi, rt = tlen - ti;
             if (BT) {
@@ -222,7 +309,7 @@ inline void genasm_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid,
 {
     (void)p;
     *block = kWave;
-    *lds = (size_t)(kGaW + 1) * 16 * 8 + 384;
+    *lds = (size_t)kGaCols * kGaSlots * 8 + 384;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
