@@ -24,6 +24,7 @@
 // Integer / bit work only; HBM sees each sequence byte once and the ops once.
 #pragma once
 
+#include <type_traits>
 #include "aim_device.hpp"
 
 namespace aim {
@@ -163,8 +164,6 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
     // wavefront's slab of HBM scratch instead.
     uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);
     uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
-    unsigned char *wops = reinterpret_cast<unsigned char *>(Rs + kGaCols * kGaSlots);   // ops of the current window (<= 128)
-    unsigned char *pwin = wops + 192, *twin = wops + 256;                            // the window's characters, for the traceback's run test
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
     constexpr uint64_t ONES = ~0ull;
@@ -191,8 +190,6 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const int prev = lane < m ? (int)gP[pi + m - 1 - lane] : 0x100;     // 0x100 never equals a byte
             const int pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
             const int tfwd = lane < n ? (int)gT[ti + lane] : 0x300;
-            pwin[lane] = (unsigned char)pfwd;
-            twin[lane] = (unsigned char)tfwd;
             AIM_GASTAMP(0);   // window characters from HBM
             // lane j: PM of text column j -- bit i = 0 <=> p[m-1-i] == t[j] -- from one ballot per distinct character
             uint64_t mypm = ONES;
@@ -216,60 +213,66 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront reads its own slab back below
             }
             AIM_GASTAMP(3);   // DC, 64 levels (rare)
-            auto R_at = [&](int col, int lvl) -> uint64_t { return slow ? Rg[col * 64 + lvl] : Rs[ga_slot(col) + lvl]; };
             // d0 = smallest level whose bit m-1 is clear in column 0
             int d = hit ? (int)__builtin_ctzll(hit) : -1;
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the columns are in LDS (one wavefront: in-order LDS)
             int ca = 0, cb = 0, wn = 0;           // consumed text / pattern characters, ops of this window (uniform)
-            auto emit = [&](unsigned char ch) { if (lane == 0) wops[wn] = ch; ++wn; };
+            // GenASM-TB. The window's ops live in two registers (lane i: ops i and 64 + i), pre-set to 'M': a run of matches costs
+            // nothing to record and an edit is one compare + select.
+            int opsA = 'M', opsB = 'M';
+            auto put = [&](int ch) {
+                opsA = lane == wn ? ch : opsA;
+                opsB = lane + 64 == wn ? ch : opsB;
+                ++wn;
+            };
             if (d < 0) {   // [spec] no alignment of this window within 63 edits: diagonal steps
-                int steps = min(min(m, n), kGaCommit);
-                for (; ca < steps; ++ca, ++cb) {
-                    const bool eq = __builtin_amdgcn_readlane(pfwd, cb) == __builtin_amdgcn_readlane(tfwd, ca);
-                    emit(eq ? 'M' : 'X');
-                    dist += eq ? 0 : 1;
-                }
+                const int steps = min(min(m, n), kGaCommit);
+                const bool x = lane < steps && pfwd != tfwd;
+                opsA = x ? 'X' : opsA;
+                dist += __builtin_popcountll(__ballot(x));
+                ca = cb = wn = steps;
             } else {
-                for (;;) {
-                    // A run of matches in ONE step: lane i tests what the sequential walk would test at (ca+i, cb+i) -- window
-                    // limits, equal characters, and bit (m-2-cb-i) of R_{ca+i+1}[d] clear ('M' never changes d) -- and the run
-                    // is as long as the leading true lanes. The walk below then takes the one non-match step that ends it.
-                    {
+                // One LDS round trip per iteration. Lane i looks at the cell the sequential walk would reach after i matches,
+                // (ca+i, cb+i): the characters (ds_bpermute of the window registers), R_{a+1}[d] for the match test, and
+                // R_{a+1}[d-1], R_a[d-1] for the edit it would take if the run of matches ended on it. The run is the leading
+                // lanes whose match test holds ('M' never changes d); the edit is then read from the first lane where it fails --
+                // the same tests in the same order as the step-by-step walk (oracle/genasm_oracle.c), without a second fetch.
+                auto walk = [&](auto slow_tag) {
+                    constexpr bool SLOW = decltype(slow_tag)::value;
+                    auto Rf = [&](int col, int lvl) -> uint64_t { return SLOW ? Rg[col * 64 + lvl] : Rs[ga_slot(col) + lvl]; };
+                    for (;;) {
                         const int ai = ca + lane, bi = cb + lane;
-                        bool cond = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
-                        const int aic = cond ? ai : 0, bic = cond ? bi : 0;
-                        const uint64_t rr = R_at(aic + 1, d);
-                        cond = cond && pwin[bic] == twin[aic] && (bic + 1 >= m || !((rr >> (m - 2 - bic)) & 1ull));
-                        const uint64_t bad = ~__ballot(cond);
+                        const bool inr = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
+                        const int aic = min(ai, n - 1), bic = min(bi, kGaW - 1);
+                        const int dm1 = d > 0 ? d - 1 : 0;
+                        const uint64_t rn_d = Rf(aic + 1, d), rn_dm1 = Rf(aic + 1, dm1), rc_dm1 = Rf(aic, dm1);
+                        const int pch = __builtin_amdgcn_ds_bpermute(bic << 2, pfwd), tch = __builtin_amdgcn_ds_bpermute(aic << 2, tfwd);
+                        // clear(r, b) := b >= m || bit (m-1-b) of r is 0
+                        const int q1 = m - 2 - bi, q0 = m - 1 - bi;          // bit indices for b = bi + 1 and b = bi
+                        auto clr = [&](uint64_t r, int q) -> bool { return q < 0 || !((r >> (q & 63)) & 1ull); };
+                        const bool cm = inr && pch == tch && clr(rn_d, q1);
+                        int code = 0;                                         // the edit this cell would take
+                        if (d > 0) code = clr(rn_dm1, q1) ? 'X' : clr(rc_dm1, q1) ? 'D' : clr(rn_dm1, q0) ? 'I' : 0;
+                        const uint64_t bad = ~__ballot(cm);
                         const int run = bad ? (int)__builtin_ctzll(bad) : 64;
-                        if (run) {
-                            if (lane < run) wops[wn + lane] = 'M';
-                            wn += run; ca += run; cb += run;
-                        }
+                        wn += run; ca += run; cb += run;
+                        if (cb == m) break;
+                        if (!last && (ca >= kGaCommit || cb >= kGaCommit)) break;
+                        if (ca == n) { put('D'); ++cb; --d; ++dist; continue; }
+                        // here lane `run` is inside the window and its match test failed: its edit is the walk's next step
+                        const int op = __builtin_amdgcn_readlane(code, run);
+                        if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen (the recurrence guarantees one rule applies)
+                        put(op);
+                        ca += op != 'D';
+                        cb += op != 'I';
+                        --d; ++dist;
                     }
-                    if (cb == m) break;
-                    if (!last && (ca >= kGaCommit || cb >= kGaCommit)) break;
-                    if (ca == n) { emit('D'); ++cb; --d; ++dist; continue; }
-                    // the three vectors a step can look at, fetched together (one LDS round trip per step instead of up to four)
-                    const int dm1 = d > 0 ? d - 1 : 0;
-                    const uint64_t r_next_d = ga_uniform(R_at(ca + 1, d));       // R_{a+1}[d]   : match
-                    const uint64_t r_next_dm1 = ga_uniform(R_at(ca + 1, dm1));   // R_{a+1}[d-1] : substitution (b+1), text-only edit (b)
-                    const uint64_t r_cur_dm1 = ga_uniform(R_at(ca, dm1));          // R_a[d-1]     : pattern-only edit (b+1)
-                    auto clear = [&](uint64_t r, int b) -> bool { return b >= m || !((r >> (m - 1 - b)) & 1ull); };
-                    const bool eq = __builtin_amdgcn_readlane(pfwd, cb) == __builtin_amdgcn_readlane(tfwd, ca);
-                    if (eq && clear(r_next_d, cb + 1)) { emit('M'); ++ca; ++cb; continue; }
-                    if (d > 0 && clear(r_next_dm1, cb + 1)) { emit('X'); ++ca; ++cb; --d; ++dist; continue; }
-                    if (d > 0 && clear(r_cur_dm1, cb + 1)) { emit('D'); ++cb; --d; ++dist; continue; }
-                    if (d > 0 && clear(r_next_dm1, cb)) { emit('I'); ++ca; --d; ++dist; continue; }
-                    status = AIM_PAIR_WFA_NO_LINK;   // cannot happen (the recurrence guarantees one rule applies)
-                    break;
-                }
+                };
+                if (slow) walk(std::true_type{}); else walk(std::false_type{});
             }
             AIM_GASTAMP(4);   // traceback
             if (BT) {   // the window's ops leave as coalesced byte stores
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-                for (int i = lane; i < wn; i += kWave)
-                    if (nops + i < cap) ops[nops + i] = (char)wops[i];
+                if (lane < wn && nops + lane < cap) ops[nops + lane] = (char)opsA;
+                if (lane + 64 < wn && nops + 64 + lane < cap) ops[nops + 64 + lane] = (char)opsB;
             }
             nops += wn;
             pi += cb;
@@ -309,7 +312,7 @@ inline void genasm_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid,
 {
     (void)p;
     *block = kWave;
-    *lds = (size_t)kGaCols * kGaSlots * 8 + 384;
+    *lds = (size_t)kGaCols * kGaSlots * 8 + 64;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
