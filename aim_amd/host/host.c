@@ -66,12 +66,16 @@ static void parallel_run(int nthreads, range_fn fn, void *arg)
     job_t jobs[MAX_THREADS];
     memset(jobs, 0, sizeof jobs);
     if (nthreads < 1) nthreads = 1;
+    int started[MAX_THREADS];
     for (int t = 0; t < nthreads; ++t) {
         jobs[t] = (job_t){fn, t, nthreads, arg};
-        if (t) pthread_create(&th[t], NULL, job_tramp, &jobs[t]);
+        started[t] = t && pthread_create(&th[t], NULL, job_tramp, &jobs[t]) == 0;
     }
     job_tramp(&jobs[0]);
-    for (int t = 1; t < nthreads; ++t) pthread_join(th[t], NULL);
+    for (int t = 1; t < nthreads; ++t) {
+        if (started[t]) pthread_join(th[t], NULL);
+        else job_tramp(&jobs[t]);     /* no thread to be had (resource limit): this share runs here */
+    }
 }
 
 /* ---- input: mapped file + line index --------------------------------------------------------------- */
@@ -106,6 +110,7 @@ static void index_lines(input_t *in, int nthreads)
     for (int t = 0; t < nthreads; ++t) in->counts[t + 1] += in->counts[t];
     size_t n_nl = in->counts[nthreads];
     in->line_start = malloc((n_nl + 2) * sizeof(size_t));
+    if (!in->line_start) { fprintf(stderr, "out of host memory\n"); exit(1); }
     in->line_start[0] = 0;
     parallel_run(nthreads, fill_newlines, in);
     /* a final line without '\n' still is a line for getline() */
@@ -314,6 +319,7 @@ static void format_range(int tid, int nt, void *arg)
     /* worst case per pair: "idx, score, \n" (<= 26 bytes) + one "%d%c" per op (<= 2 bytes per op when every run is 1) + '\n' */
     size_t cap = (hi - lo) * (32 + (f->backtrace ? 4 * rs + 16 : 0)) + 64;
     char *o = f->buf[tid] = malloc(cap), *start = o;
+    if (!o) { fprintf(stderr, "out of host memory\n"); exit(1); }
     for (size_t i = lo; i < hi; ++i) {
         /* fprintf(out, "%d, %d, \n", idx, score) */
         const int full = f->full_ops || j->use_full;
@@ -635,6 +641,6 @@ int main(int argc, char *argv[])
     close(fd);
     aim_set_free(set);
     if (dpu_file) fclose(dpu_file);
-    fclose(output_file);
+    if (ferror(output_file) | fclose(output_file)) { fprintf(stderr, "Output file '%s' couldn't be written\n", out); return 1; }
     return 0;
 }
