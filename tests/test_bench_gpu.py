@@ -1,0 +1,55 @@
+"""bench.py's contract on a GPU box: the one-JSON-line output at N = 1, and the N = 2 control flow (rendezvous, barrier,
+max-over-ranks timing, score gather) under torch.distributed.run with both ranks on the one GPU a test box has
+(AIM_BENCH_SHARE_GPU=1: gloo instead of RCCL -- two ranks cannot share a device under RCCL; never set by the driver)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_line(built):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--pairs", "262144", "--steps", "3", "--warmup", "1",
+                        "--verify-pairs", "65536"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["dtype"] == "int16"
+    assert d["vs_baseline"] is None and d["value"] > 0 and d["verified_vs_oracle"] is True
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["unit"] == "GB/s"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert "workload" in d["config"] and "plan" in d["config"]
+    assert d["e2e"]["packed"]["pairs_per_s"] > 0            # PCIe-inclusive leg: reported, never `value`
+
+
+def test_bench_two_ranks_control_flow(built):
+    env = dict(os.environ, AIM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pairs", "131072", "--steps", "3",
+                        "--warmup", "1", "--verify-pairs", "32768"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["verified_vs_oracle"] is True
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1      # rank 0 prints the one line
+    assert d["config"]["pairs_per_gpu"] == 131072 and d["cpu_baseline"] is None and d["e2e"] is None   # rank 0 at N = 1 only
+    assert d["gather_ms"] is not None
+    # a mismatch between --gpus and WORLD_SIZE is refused
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 2
