@@ -185,10 +185,12 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                 else { m0 = v * GD; i0 = 0; }
                 Mrow[cur][v] = (int16_t)m0;
                 if (SWG) Irow[cur][v] = (int16_t)i0;
-                TM[7 + v] = (int16_t)m0;
-                if (SWG) { TI[7 + v] = (int16_t)i0; TD[7 + v] = (int16_t)(v ? m0 : MAXS); }
+                if (BT) {   // the table feeds the traceback only: score-only launches of the row-scan path never touch the slab
+                    TM[7 + v] = (int16_t)m0;
+                    if (SWG) { TI[7 + v] = (int16_t)i0; TD[7 + v] = (int16_t)(v ? m0 : MAXS); }
+                }
             }
-            for (int h = 1 + tid; h <= tlen; h += NT) {   // row-init boundary cells flat[W*h]
+            for (int h = 1 + tid; BT && h <= tlen; h += NT) {   // row-init boundary cells flat[W*h]
                 const size_t at = (size_t)h * S + 7;
                 if (SWG) { TM[at] = (int16_t)(O + h * E); TI[at] = (int16_t)(O + h * E); TD[at] = (int16_t)MAXS; }
                 else TM[at] = (int16_t)(h * GI);
@@ -241,8 +243,10 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                     }
                     Bl[0] = c.M; Bl[1] = c.I; Bl[2] = c.D;
                     const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical home of flat[W*h + W]
-                    TM[tdst] = (int16_t)c.M;
-                    if (SWG) { TI[tdst] = (int16_t)c.I; TD[tdst] = (int16_t)c.D; }
+                    if (BT) {
+                        TM[tdst] = (int16_t)c.M;
+                        if (SWG) { TI[tdst] = (int16_t)c.I; TD[tdst] = (int16_t)c.D; }
+                    }
                 };
                 for (int step = 0; step < nsteps; ++step) {
                     const int base = 1 + (step * NW + wv) * kDpBlock;   // may lie past Rr: the wave still joins the barrier
@@ -347,14 +351,16 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                         const uint4 pm = pack8(Mo);
                         *reinterpret_cast<uint4 *>(&Mrow[nxt][v0]) = pm;
 #ifndef AIM_DPW_DIAG_NO_TABLE
-                        *reinterpret_cast<uint4 *>(&TM[trow + v0]) = pm;
+                        if (BT) *reinterpret_cast<uint4 *>(&TM[trow + v0]) = pm;
 #endif
                         if (SWG) {
                             const uint4 pi = pack8(Iv), pd = pack8(Do);
                             *reinterpret_cast<uint4 *>(&Irow[nxt][v0]) = pi;
 #ifndef AIM_DPW_DIAG_NO_TABLE
-                            *reinterpret_cast<uint4 *>(&TI[trow + v0]) = pi;
-                            *reinterpret_cast<uint4 *>(&TD[trow + v0]) = pd;
+                            if (BT) {
+                                *reinterpret_cast<uint4 *>(&TI[trow + v0]) = pi;
+                                *reinterpret_cast<uint4 *>(&TD[trow + v0]) = pd;
+                            }
 #endif
                         }
                         if (v0 + kDpK - 1 == Rr) {
@@ -367,11 +373,10 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                             const int v = v0 + t;
                             if (v <= Rr) {
                                 Mrow[nxt][v] = (int16_t)Mo[t];
-                                TM[trow + v] = (int16_t)Mo[t];
+                                if (BT) TM[trow + v] = (int16_t)Mo[t];
                                 if (SWG) {
                                     Irow[nxt][v] = (int16_t)Iv[t];
-                                    TI[trow + v] = (int16_t)Iv[t];
-                                    TD[trow + v] = (int16_t)Do[t];
+                                    if (BT) { TI[trow + v] = (int16_t)Iv[t]; TD[trow + v] = (int16_t)Do[t]; }
                                 }
                                 if (v == Rr) {
                                     tailM[0] = (int16_t)Mo[t]; tailM[1] = (int16_t)Do[t];
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                             c.M = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(leftM + GI, up.M + GD));
                         }
                         if (v == W) lastTail = c;
-                        if ((h == tlen || v == W) && lane == 0) {
+                        if (BT && (h == tlen || v == W) && lane == 0) {
                             TM[tdst + (v - W)] = (int16_t)c.M;
                             if (SWG) { TI[tdst + (v - W)] = (int16_t)c.I; TD[tdst + (v - W)] = (int16_t)c.D; }
                         }
@@ -601,12 +606,12 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
 {
     const uint64_t rs = (uint64_t)p.read_size;
     const uint64_t S = (rs + 16) & ~7ull;
-    uint64_t per = 3 * S * (rs + 3) * 2;   // three int16 planes (NW uses the first)
+    const bool swg = p.algo == AIM_ALGO_SWG;
+    uint64_t per = (swg ? 3 : 1) * S * (rs + 3) * 2;   // int16 planes: M, I, D for SWG; NW has the one table
     per = (per + 255) & ~255ull;
     (void)cell8;
     const int nw = dp_wave_nw(p, n_pairs, kn);
     *block = (uint32_t)(kWave * nw);
-    const bool swg = p.algo == AIM_ALGO_SWG;
     const uint64_t rowcap = (rs + 31) & ~7ull;
     *lds = ((rs + 31) & ~15ull) + (size_t)((swg ? 4 : 2) * rowcap + 64) * 2 + 256;
     if (*lds > 160 * 1024) return false;

@@ -31,6 +31,9 @@ CONFIGS = {
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict(backtrace=True)),
     "nw_l1000_e5_cigar": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
+    "swg_l1000_e5_score": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict()),
+    "nw_l1000_e5_score": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict()),
+    "swg_l10000_e1_score_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict()),
     # BASELINE config 5 (parity unpinned: published GenASM algorithm, oracle/genasm_oracle.c)
     "genasm_l100000_e10_cigar": dict(algo="genasm", l=100000, e=0.10, n=1024, kw=dict(backtrace=True)),
     "genasm_l100000_e10_score": dict(algo="genasm", l=100000, e=0.10, n=1024, kw=dict()),
