@@ -599,7 +599,13 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     // the fused score step and the correct LDS granule; sweep on one box (ms at 8 -> best per CU): l=100 e=2% 0.671 -> 0.553
     // (11), e=5% 3.85 -> 2.82 (14), e=10% 6.17 -> 4.10 (16), l=250 e=5% 4.23 -> 3.53 (11), l=150 e=2% 1.94 -> 1.28 (16),
     // l=100 e=5% CIGAR 2.29 -> 1.73 (14); G = 64 (cfg3): 11 / 12 / 13 / 14 per CU = 7.81 / 7.10 / 7.42 / 7.06 ms.
-    uint32_t per_cu = (uint32_t)std::min<size_t>(AIM_GROUP_MAX_PER_CU, lds_fit);
+    // Above 16 per CU the count is kept a multiple of the CU's 4 SIMDs (an odd wavefront makes one SIMD the straggler: l = 100
+    // e = 10 % 18 -> 16 per CU 3.96 -> 3.89 ms, l = 150 e = 2 % 21 -> 20 1.174 -> 1.089 ms); the score-only variants (<= 68 VGPRs, 7
+    // wavefronts per SIMD) may use 24 (cfg3 score-only 20 / 22 / 24 / 25 per CU: 3.32 / 3.25 / 3.18 / 3.67 ms), the CIGAR
+    // variants are register-bound at 5 per SIMD.
+    const size_t cap_per_cu = (p.flags & AIM_FLAG_BACKTRACE) ? AIM_GROUP_MAX_PER_CU : AIM_GROUP_MAX_PER_CU + 4;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(cap_per_cu, lds_fit);
+    if (per_cu > 16) per_cu &= ~3u;
     if (kn.group_per_cu >= 0) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.group_per_cu), lds_fit);   // residency sweeps
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
     uint32_t gr = 256 * per_cu;

@@ -126,7 +126,8 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
     # estimate would say 12 for the 12.8-KB and 13.3-KB workgroups, which measurably breaks into two rounds
     assert G(100, 0.02, AIM_NO_LANE_EXT="1")[2] == 11          # G = 4: 12.8 KB incl. LDS staging rows
     # round 2: groups of >= 8 lanes pack straight from global memory (no staging rows) and up to 20 workgroups per CU are used
-    assert G(250, 0.05)[2] == 14 and G(100, 0.05)[2] == 16 and G(100, 0.10)[2] == 18   # 11.2 KB / 9.4 KB / 8.8 KB workgroups
+    assert G(250, 0.05)[2] == 14 and G(100, 0.05)[2] == 16 and G(100, 0.10)[2] == 16   # 11.2 KB / 9.4 KB / 8.8 KB workgroups (18 fit: kept a multiple of the 4 SIMDs)
+    assert G(1000, 0.05)[2] == 24                  # score-only, 6.4-KB workgroups: 25 fit, 6 per SIMD are used
     assert G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14              # 10.7 KB
 
 
