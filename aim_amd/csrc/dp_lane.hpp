@@ -501,6 +501,10 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     const size_t rows = p.algo == AIM_ALGO_NW ? (size_t)(p.read_size + 1) * kWave * 2
                                               : (size_t)2 * (p.read_size + 1) * kWave * swg_cell_bytes(p);   // SWG: M and I rows, CELL-typed
     *seq_lds = img + rows <= 150 * 1024;
+    // SWG score-only does better with the pattern read from global memory and the LDS spent on residency instead (l = 100, 1 M
+    // pairs, same box: image in LDS, 7 workgroups per CU 7.12 ms; no image, 8 / 10 / 11 per CU 6.66 / 6.28 / 6.30 ms). NW and the
+    // CIGAR variants measure the other way (NW score-only 4.32 vs 5.24 ms, SWG CIGAR 12.5 vs 13.6 ms).
+    if (p.algo == AIM_ALGO_SWG && !(p.flags & AIM_FLAG_BACKTRACE)) *seq_lds = false;
     if (kn.dpl_seq_lds >= 0) *seq_lds = *seq_lds && kn.dpl_seq_lds != 0;   // experiments: 0 = pattern from global memory
     *lds = rows + (*seq_lds ? img : 0);
     if (*lds > 160 * 1024) return false;
