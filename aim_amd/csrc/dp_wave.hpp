@@ -577,7 +577,7 @@ inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn)
     const int nblocks = (p.read_size + kDpBlock - 1) / kDpBlock;
     if (kn.dpw_nw >= 0) {   // A/B runs
         const int f = kn.dpw_nw;
-        if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10 || f == 12 || f == 16) return f;
+        if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10 || f == 12) return f;
     }
     // Up to 8 blocks per row: just enough wavefronts per pair to put ~4096 wavefronts (4 per SIMD) on the chip, never more
     // than the row has blocks. Fewer wavefronts per pair mean less (at 1: no) cross-wavefront synchronisation and more pairs
@@ -643,7 +643,6 @@ inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, uin
         else if (nw == 4) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 4>), 4);                          \
         else if (nw == 8) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 8>), 8);                          \
         else if (nw == 10) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 10>), 10);                       \
-        else if (nw == 16) AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 16>), 16);                       \
         else AIM_DPW((dp_wave_kernel<ALGOV, BTV, C8V, 12>), 12);                                     \
     } while (0)
     if (p.algo == AIM_ALGO_NW) {
