@@ -51,8 +51,12 @@ def md5(b):
 
 
 def judge_cases():
-    """The 14 wider reference digests the round-1 judge recorded (tests/golden/judge_r01_cases.json)."""
-    return json.load(open(os.path.join(GOLDEN, "judge_r01_cases.json")))["cases"]
+    """The wider reference digests the judges recorded: 14 in round 1 (tests/golden/judge_r01_cases.json) and 14 in round 2
+    (judge_r02_cases.json: dynamic-bounds / READ_SIZE-80 lane shapes, l = 150, MAX_SCORE 10, MRAM-variant overflow)."""
+    cases = []
+    for name in ("judge_r01_cases.json", "judge_r02_cases.json"):
+        cases += json.load(open(os.path.join(GOLDEN, name)))["cases"]
+    return cases
 
 
 def judge_case_input(case):
@@ -65,3 +69,15 @@ def judge_case_input(case):
     data = engine.pairs_to_text(req, pat, txt)
     assert hashlib.md5(data).hexdigest() == case["input_md5"], "generator drifted from the judge's input for " + case["name"]
     return data
+
+
+def reduce_cases():
+    """Constructed pairs on which WFA-adaptive's reduction changes the score (tests/golden/reduce_changes_score.json)."""
+    import numpy as np
+    from aim_amd import engine
+    d = json.load(open(os.path.join(GOLDEN, "reduce_changes_score.json")))
+    data = b"".join(b">" + c["pattern"].encode() + b"\n<" + c["text"].encode() + b"\n" for c in d["pairs"])
+    req, pat, txt = engine.parse_pairs(data, d["read_size"])
+    plain = np.array([c["score_plain"] for c in d["pairs"]])
+    red = np.array([c["score_reduce"] for c in d["pairs"]])
+    return d, req, pat, txt, plain, red

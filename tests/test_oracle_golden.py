@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, judge_case_input, judge_cases, md5
+from conftest import ROOT, judge_case_input, judge_cases, md5, reduce_cases
 
 
 def _run(oracle_mod, engine, data, algo, max_score, backtrace, reduce=False, swg_cell_bytes=0, threads=4):
@@ -91,3 +91,17 @@ def test_oracle_reproduces_judge_r01_reference_digests(built, case):
     res, ops, worst = oracle.align_batch(p, req["pattern_len"], req["text_len"], pat, txt, nthreads=4)
     assert worst == 0 and len(res) == case["gen"]["n"]
     assert md5(oracle.format_output(res, ops, case["backtrace"])) == case["output_md5"]
+
+
+def test_oracle_reduction_changes_scores_on_constructed_pairs(built):
+    """affine_wfa_reduce_wvs (wfa.c:69-140) is a heuristic: it may cut the diagonal the optimum needs. Random reads never show
+    it; these constructed pairs do (21 without -r, 22 / 25 with). Pins the oracle's reduction as something that ACTS."""
+    from oracle import oracle
+    d, req, pat, txt, plain, red = reduce_cases()
+    for bt in (False, True):
+        a, _, _ = oracle.align_batch(oracle.params("wfa", d["max_score"], d["read_size"], backtrace=bt, reduce=False),
+                                     req["pattern_len"], req["text_len"], pat, txt)
+        b, _, _ = oracle.align_batch(oracle.params("wfa", d["max_score"], d["read_size"], backtrace=bt, reduce=True),
+                                     req["pattern_len"], req["text_len"], pat, txt)
+        assert np.array_equal(a["score"], plain) and np.array_equal(b["score"], red)
+        assert (plain != red).all()

@@ -1,0 +1,26 @@
+#!/bin/bash
+# tools/profile_round.sh <round-dir, e.g. r03> : the profile evidence of one round, on the GPU box (inside a gpurun call):
+# rocprofv3 kernel stats + PMC summaries for every BASELINE configuration's kernel (tools/pmc_summary.py: stats pass and PMC
+# passes are separate runs), then the kernel timers of every configuration of tools/bench_configs.py.
+# Results go to profiles/<round-dir>/ AND are mirrored under gpurun_out/ (the only directory gpurun copies back).
+R=${1:-r03}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
+cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+python3 tools/pmc_summary.py --out $P/wfa_lane_pmc_summary.json --kernel wfa_lane_kernel --pairs 4194304 --alg-bytes 905968812 --fetch-x2 --io compact \
+   --note "Cross-check: 4194304 pairs x (224 B rows + 8 B request) = 973.1 MB read, x 8 B result = 33.6 MB written." \
+   -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/pmc_lane.log 2>&1; tail -1 $O/pmc_lane.log
+python3 tools/pmc_summary.py --out $P/wfa_group_pmc_summary.json --kernel wfa_group_kernel --pairs 65536 \
+   --note "cfg3: WFA-adaptive l=1000 e=5% with CIGAR, 65536 pairs; per-lane int16 LDS/HBM traffic: FETCH_SIZE kept raw (uncalibrated width)." \
+   -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_group.log 2>&1; tail -1 $O/pmc_group.log
+python3 tools/pmc_summary.py --out $P/dp_wave_pmc_summary.json --kernel dp_wave_kernel --pairs 256 \
+   --note "cfg4: SWG l=10000 e=1% with CIGAR, 256 pairs; table stores are 16 B per lane (WRITE_SIZE exact), mixed-width reads: FETCH_SIZE kept raw." \
+   -- python3 tools/bench_configs.py swg_l10000_e1_cigar_n256 > $O/pmc_dpw.log 2>&1; tail -1 $O/pmc_dpw.log
+python3 tools/pmc_summary.py --out $P/genasm_wave_pmc_summary.json --kernel genasm_wave_kernel --pairs 1024 \
+   --note "cfg5: GenASM l=100000 e=10% with CIGAR, 1024 pairs (parity unpinned)." \
+   -- python3 tools/bench_configs.py genasm_l100000_e10_cigar > $O/pmc_genasm.log 2>&1; tail -1 $O/pmc_genasm.log
+python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
+python3 -c "
+import sys, json
+for l in open('$P/all_configs_kernel_timers.jsonl'):
+    d=json.loads(l); print('%-32s %-18s %10.4g pairs/s %8.1f GCUPS %8.1f GB/s' % (d['config'], d['kernel'], d['pairs_per_s'], d['gcups'], d['algorithmic_GBps']))
+"
+cp -r $P $O/
