@@ -21,6 +21,7 @@
 #include "aim_device.hpp"
 #include "wfa_wave.hpp"
 #include "wfa_lane.hpp"
+#include "wfa_lane_packed.hpp"
 #include "wfa_group.hpp"
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
@@ -51,7 +52,12 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6 };
+
+// What a launch is asked to consume / produce besides the default ABI (ASCII rows in, result_t + ops rows out). A plan
+// honours a mode bit only when its kernel can (Plan::pk / Plan::emits_runs); otherwise the caller runs the conversion
+// kernels of batch_io.hpp around the launch.
+enum : uint32_t { MODE_PACKED_IN = 1u, MODE_RUNS_OUT = 2u };
 
 struct Plan {
     KernelId kid;
@@ -70,6 +76,8 @@ struct Plan {
     size_t hist_bytes;      // K_WFA_GROUP + BACKTRACE: per-pair history slabs between to-do region and fallback scratch
     aim::GroupCfg gcfg;     // K_WFA_GROUP
     int group_g;
+    bool pk;                // the kernel reads the packed rows of the batch itself (no unpack pass)
+    bool emits_runs;        // the kernel writes aim_cigar_t + runs itself (no ops rows, no cigar_rle_kernel)
 };
 
 // The AIM_* environment variables, read HERE and nowhere else (see aim::Knobs, aim_device.hpp).
@@ -90,6 +98,7 @@ aim::Knobs read_knobs()
     k.force_wave = env_flag("AIM_FORCE_WAVE");
     k.no_group = env_flag("AIM_NO_GROUP");
     k.no_lane_ext = env_flag("AIM_NO_LANE_EXT");
+    k.no_lane_pk = env_flag("AIM_NO_LANE_PK");
     k.wfa_no_ring = env_flag("AIM_WFA_NO_RING");
     k.wfa_slotw = env_int("AIM_WFA_SLOTW", -1);
     k.force_dpwave = env_flag("AIM_FORCE_DPWAVE");
@@ -168,7 +177,7 @@ int validate_params(const aim_params_t &p)
 
 inline bool p_is_nw(const aim_params_t *p) { return p->algo == AIM_ALGO_NW; }
 
-int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uint64_t budget, Plan *pl)
+int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uint64_t budget, uint32_t mode, Plan *pl)
 {
     int rc = AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
@@ -177,6 +186,16 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         aim::genasm_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
         pl->scratch_per_wg = aim::kGaSlabBytes;
         pl->scratch_total = (size_t)pl->grid * aim::kGaSlabBytes;   // slow-path columns, one slab per wavefront
+        return AIM_OK;
+    }
+    if (p.algo == AIM_ALGO_WFA && (mode & MODE_PACKED_IN) && !kn.force_wave && !kn.no_lane_pk && !pl->no_lane &&
+        aim::wfa_lane_packed_supported(p, !kn.no_lane_ext) && (!bt || (mode & MODE_RUNS_OUT))) {
+        // packed rows in, {idx, score} or compact CIGAR out: one kernel per batch, no scratch (wfa_lane_packed.hpp)
+        pl->kid = K_WFA_LANE_PK;
+        aim::wfa_lane_packed_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+        pl->scratch_total = 256;
+        pl->pk = true;
+        pl->emits_runs = bt;
         return AIM_OK;
     }
     if (p.algo == AIM_ALGO_WFA) {
@@ -203,7 +222,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             Plan fb;
             memset(&fb, 0, sizeof fb);
             fb.no_lane = true;
-            rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), kn, budget, &fb);
+            rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), kn, budget, 0u, &fb);
             if (rc) return rc;
             *pl = fb;
             pl->fb_grid = fb.grid;
@@ -300,6 +319,7 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
     switch (pl.kid) {
     case K_WFA_WAVE: return "wfa_wave_kernel";
     case K_WFA_LANE: return "wfa_lane_kernel";
+    case K_WFA_LANE_PK: return "wfa_lane_packed_kernel";
     case K_WFA_GROUP: return "wfa_group_kernel";
     case K_DP_LANE: return p_is_nw(&p) ? "nw_lane_kernel" : "swg_lane_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
@@ -320,12 +340,12 @@ int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint6
                     pl.block, pl.lds, pl.scratch_total, (unsigned long long)budget, extra);
 }
 
-int make_plan(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uint64_t budget, Plan *pl)
+int make_plan(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uint64_t budget, Plan *pl, uint32_t mode = 0u)
 {
     int rc = validate_params(p);
     if (rc) return rc;
     memset(pl, 0, sizeof *pl);
-    rc = make_plan_inner(p, n_pairs, kn, budget, pl);
+    rc = make_plan_inner(p, n_pairs, kn, budget, mode, pl);
     if (rc == AIM_OK && kn.plan_debug) {
         char line[384];
         describe_plan(*pl, p, n_pairs, budget, line, sizeof line);
@@ -343,16 +363,26 @@ void launch_wfa_wave(const Plan &pl, const aim::KArgs &ka, hipStream_t s)
         hipLaunchKernelGGL((aim::wfa_wave_kernel<BT, RED, false>), dim3(pl.grid), dim3(64), pl.lds, s, ka);
 }
 
+// The fused batch I/O of a launch (Plan::pk / Plan::emits_runs): packed rows in, compact CIGAR out.
+struct FusedIo {
+    const uint32_t *packedP = nullptr, *packedT = nullptr;
+    aim_cigar_t *cig = nullptr;
+    uint32_t *runs = nullptr, *cursor = nullptr;
+    uint32_t runs_cap = 0, run_slot = 0;
+};
+
 // Enqueue one alignment launch that follows plan `pl` (made for >= n_pairs pairs under the caller's knobs and budget).
 int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t n_pairs, const void *d_req,
            const char *d_pat, const char *d_txt, void *d_res, char *d_ops, void *d_scratch, size_t scratch_bytes,
-           hipStream_t stream)
+           hipStream_t stream, const FusedIo *fio = nullptr)
 {
     if (n_pairs == 0) return AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const bool red = p.flags & AIM_FLAG_REDUCE;
-    if (!d_req || !d_pat || !d_txt || !d_res) return fail(AIM_EINVAL, "null device buffer");
-    if (bt && !d_ops) return fail(AIM_EINVAL, "AIM_FLAG_BACKTRACE needs an ops buffer");
+    if (pl.pk && (!fio || !fio->packedP || !fio->packedT)) return fail(AIM_EINVAL, "plan reads packed rows but none were given");
+    if (pl.emits_runs && (!fio || !fio->cig || !fio->runs || !fio->cursor)) return fail(AIM_EINVAL, "plan emits the compact CIGAR but no buffers were given");
+    if (!d_req || (!pl.pk && (!d_pat || !d_txt)) || (!pl.emits_runs && !d_res)) return fail(AIM_EINVAL, "null device buffer");
+    if (bt && !pl.emits_runs && !d_ops) return fail(AIM_EINVAL, "AIM_FLAG_BACKTRACE needs an ops buffer");
     if (scratch_bytes < pl.scratch_total || (!d_scratch && pl.scratch_total))
         return fail(AIM_EINVAL, "scratch too small: need %zu bytes, got %zu", pl.scratch_total, scratch_bytes);
     aim::KArgs ka;
@@ -372,6 +402,12 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     ka.todo = nullptr;
     ka.dbg_poison_lds = kn.poison_lds >= 0 ? (0x100u | (uint32_t)(kn.poison_lds & 0xff)) : 0u;
     ka.dbg_lds_bytes = (uint32_t)pl.lds;
+    ka.packedP = fio ? fio->packedP : nullptr;
+    ka.packedT = fio ? fio->packedT : nullptr;
+    ka.cig = fio ? fio->cig : nullptr;
+    ka.runs = fio ? fio->runs : nullptr;
+    ka.runs_cap = fio ? fio->runs_cap : 0u;
+    ka.cursor = fio ? fio->cursor : nullptr;
     switch (pl.kid) {
     case K_WFA_WAVE:
         if (bt && red) launch_wfa_wave<true, true>(pl, ka, stream);
@@ -382,6 +418,9 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     case K_WFA_LANE:
         ka.scratch_per_wave = 256;
         aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
+        break;
+    case K_WFA_LANE_PK:
+        aim::wfa_lane_packed_launch(p, pl.grid, pl.lds, ka, fio->run_slot, stream);
         break;
     case K_WFA_GROUP: {
         // [to-do region | history slabs | general kernel scratch]: count zeroed per launch, fast kernel, then the drain
@@ -436,7 +475,11 @@ struct aim_slot {
     char *d_rawP = nullptr, *d_rawT = nullptr;
     aim_cigar_t *d_cig = nullptr;                                    // compact CIGAR
     uint32_t *d_runs = nullptr, *d_cursor = nullptr, *h_cursor = nullptr;
+    void *d_rawreq = nullptr, *d_rawres = nullptr;                   // raw side pass (fused packed batches): the side list as a batch of its own
+    char *d_rawops = nullptr;
+    aim_cigar_t *d_rawcig = nullptr;
     uint32_t n_pairs = 0;
+    uint32_t runs_sent = 0;  // runs of the batch in flight whose D2H copy aim_set_submit already enqueued (slotted run buffer)
     bool pushed = false, launched = false, submitted = false;
     Plan plan_last;          // the plan the last launch followed (the configure-time plan re-made for the pushed pair count)
     aim_batch_io_t io;       // the batch in flight (aim_set_submit .. aim_set_wait)
@@ -447,6 +490,7 @@ struct aim_device_ctx {
     std::vector<aim_slot> slots;
     Plan plan;               // made at configure time for max_pairs under the set's knobs and this device's budget
     uint64_t budget = 0;     // scratch bound of one slot of this device, frozen at configure time
+    float h2d_ms = 0.f, kernel_ms = 0.f, d2h_ms = 0.f;   // aim_set_submit / aim_set_wait: phase times of this device's batches, summed
 };
 
 struct aim_set {
@@ -465,7 +509,7 @@ inline size_t res_size(const aim_params_t &p) { return (p.flags & AIM_FLAG_RES8)
 void free_slot(aim_slot &s)
 {
     void *bufs[] = {s.d_req, s.d_pat, s.d_txt, s.d_ops, s.d_res, s.d_scratch, s.d_packP, s.d_packT, s.d_rawidx, s.d_rawP, s.d_rawT,
-                    s.d_cig, s.d_runs, s.d_cursor};
+                    s.d_cig, s.d_runs, s.d_cursor, s.d_rawreq, s.d_rawres, s.d_rawops, s.d_rawcig};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (s.h_cursor) (void)hipHostFree(s.h_cursor);
@@ -509,16 +553,26 @@ int status_error(uint32_t idx, int status)
 // the configure-time plan re-made for this batch's pair count (smaller grids for smaller batches) under the SAME frozen
 // knobs and budget; should that ever need more scratch than configure allocated, the configure-time plan itself is
 // followed (every kernel tolerates a grid larger than its work)
-int launch_on_slot(aim_set *set, aim_device_ctx &d, aim_slot &s)
+Plan plan_for_batch(aim_set *set, aim_device_ctx &d, aim_slot &s, uint32_t n_pairs, uint32_t mode)
 {
     Plan pl;
     aim::Knobs quiet = set->knobs;
     quiet.plan_debug = false;   // the configure-time plan was printed; per-launch re-plans are not
-    int rc = s.n_pairs ? make_plan(set->params, s.n_pairs, quiet, d.budget, &pl) : AIM_OK;
-    if (rc || !s.n_pairs || pl.scratch_total > s.scratch_bytes) pl = d.plan;
+    int rc = n_pairs ? make_plan(set->params, n_pairs, quiet, d.budget, &pl, mode) : AIM_OK;
+    if (rc || !n_pairs || pl.scratch_total > s.scratch_bytes) pl = d.plan;
+    return pl;
+}
+
+int launch_on_slot(aim_set *set, aim_device_ctx &d, aim_slot &s, uint32_t mode = 0u, FusedIo *fio = nullptr)
+{
+    const Plan pl = plan_for_batch(set, d, s, s.n_pairs, mode);
     s.plan_last = pl;
+    if (fio && pl.emits_runs) {   // slotted run buffer: pair p owns runs[4p, 4p + 4), the cursor starts behind the slots (wfa_lane_packed.hpp)
+        fio->run_slot = ((uint64_t)s.n_pairs * aim::kRunSlot <= fio->runs_cap) ? aim::kRunSlot : 0u;
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)fio->cursor, (int)(s.n_pairs * fio->run_slot), 1, s.stream));
+    }
     return launch(pl, set->knobs, set->params, s.n_pairs, s.d_req, s.d_pat, s.d_txt, s.d_res, s.d_ops, s.d_scratch,
-                  s.scratch_bytes, s.stream);
+                  s.scratch_bytes, s.stream, fio);
 }
 }  // namespace
 
@@ -602,6 +656,10 @@ int aim_set_configure_slots(aim_set_t *set, const aim_params_t *params, uint32_t
             HIP_TRY(hipMalloc((void **)&s.d_rawidx, (size_t)max_raw * 4));
             HIP_TRY(hipMalloc((void **)&s.d_rawP, (size_t)max_raw * rs));
             HIP_TRY(hipMalloc((void **)&s.d_rawT, (size_t)max_raw * rs));
+            HIP_TRY(hipMalloc(&s.d_rawreq, (size_t)max_raw * req_size(*params)));
+            HIP_TRY(hipMalloc(&s.d_rawres, (size_t)max_raw * res_size(*params)));
+            if (params->flags & AIM_FLAG_BACKTRACE) HIP_TRY(hipMalloc((void **)&s.d_rawops, (size_t)max_raw * 2 * rs + 64));
+            if (max_runs) HIP_TRY(hipMalloc((void **)&s.d_rawcig, (size_t)max_raw * sizeof(aim_cigar_t)));
         }
         if (max_runs) {
             HIP_TRY(hipMalloc((void **)&s.d_cig, (size_t)max_pairs * sizeof(aim_cigar_t)));
@@ -801,6 +859,7 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
     HIP_TRY(hipSetDevice(d.dev));
     s.io = *io;
     s.n_pairs = n;
+    s.runs_sent = 0;
     s.pushed = s.launched = false;
     // Everything below only enqueues work on the slot's stream. Should an enqueue fail half-way, the copies already queued
     // still reference the caller's buffers: the stream is drained before the error is returned, so that a failed submit
@@ -832,7 +891,13 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
             ka.req = static_cast<const aim_request_t *>(s.d_req);
             ka.res = static_cast<aim_result_t *>(s.d_res);
             ka.ops = s.d_ops;
-            if (packed) {   // expand into the reference's char[n][READ_SIZE] layout (batch_io.hpp), then run as usual
+            // Does the alignment kernel of this configuration take the batch as it arrived and deliver what was asked for?
+            // (wfa_lane_packed_kernel: packed rows in, {idx, score} or compact CIGAR out.) Then this batch is ONE kernel;
+            // otherwise the conversion kernels of batch_io.hpp run around the default-ABI kernel.
+            const uint32_t mode = (packed ? MODE_PACKED_IN : 0u) | ((io->cigars && !io->results && !io->ops) ? MODE_RUNS_OUT : 0u);
+            const Plan pl = plan_for_batch(set, d, s, n, mode);
+            const uint32_t runs_cap = std::min(io->runs_cap, set->max_runs);
+            if (packed && !pl.pk) {   // expand into the reference's char[n][READ_SIZE] layout (batch_io.hpp), then run as usual
                 const uint64_t threads = (uint64_t)n * (rs / 8);
                 hipLaunchKernelGGL(aim::unpack_rows_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, s.stream, ka, s.d_packP,
                                    s.d_packT, s.d_pat, s.d_txt);
@@ -843,12 +908,43 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
                 }
                 HIP_TRY(hipGetLastError());
             }
-            rc = launch_on_slot(set, d, s);
+            FusedIo fio;
+            if (pl.pk) { fio.packedP = s.d_packP; fio.packedT = s.d_packT; }
+            if (pl.emits_runs) { fio.cig = s.d_cig; fio.runs = s.d_runs; fio.cursor = s.d_cursor; fio.runs_cap = runs_cap; }
+            rc = launch_on_slot(set, d, s, mode, &fio);
             if (rc) return rc;
-            if (io->cigars) {
+            s.runs_sent = pl.emits_runs ? n * fio.run_slot : 0u;   // 0 when the run buffer is bump-allocated: nothing is known before the kernel ran
+            if (io->cigars && !pl.emits_runs) {
                 HIP_TRY(hipMemsetAsync(s.d_cursor, 0, 4, s.stream));
-                hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((n + 63) / 64), dim3(64), 0, s.stream, ka, s.d_cig, s.d_runs,
-                                   std::min(io->runs_cap, set->max_runs), s.d_cursor);
+                hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((n + 63) / 64), dim3(64), 0, s.stream, ka, s.d_cig, s.d_runs, runs_cap, s.d_cursor);
+                HIP_TRY(hipGetLastError());
+            }
+            if (pl.pk && io->n_raw) {
+                // Raw side pass: the pairs of the side list hold a byte outside A/C/G/T (the reference compares raw bytes,
+                // host.c:126-127); what the packed kernel computed for them is void. They are aligned as a batch of their own by
+                // the ASCII kernels -- requests gathered, the side list's rows are its patterns / texts -- and their results
+                // replace the void ones (with the compact CIGAR: their runs are appended to the run buffer).
+                const uint32_t nr = io->n_raw;
+                const uint32_t rq_dw = (uint32_t)req_size(p) / 4, rs_dw = (uint32_t)res_size(p) / 4;
+                auto blocks = [](uint64_t t) { return dim3((unsigned)((t + 255) / 256)); };
+                hipLaunchKernelGGL(aim::gather_elems_kernel, blocks((uint64_t)nr * rq_dw), dim3(256), 0, s.stream, (const uint32_t *)s.d_req,
+                                   s.d_rawidx, nr, rq_dw, (uint32_t *)s.d_rawreq);
+                HIP_TRY(hipGetLastError());
+                const Plan rp = plan_for_batch(set, d, s, nr, 0u);
+                rc = launch(rp, set->knobs, p, nr, s.d_rawreq, s.d_rawP, s.d_rawT, s.d_rawres, s.d_rawops, s.d_scratch, s.scratch_bytes, s.stream);
+                if (rc) return rc;
+                if (io->cigars) {
+                    aim::KArgs kr = ka;
+                    kr.n_pairs = nr;
+                    kr.res = static_cast<aim_result_t *>(s.d_rawres);
+                    kr.ops = s.d_rawops;
+                    hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((nr + 63) / 64), dim3(64), 0, s.stream, kr, s.d_rawcig, s.d_runs, runs_cap, s.d_cursor);
+                    hipLaunchKernelGGL(aim::scatter_elems_kernel, blocks((uint64_t)nr * 4), dim3(256), 0, s.stream, (const uint32_t *)s.d_rawcig,
+                                       s.d_rawidx, nr, 4u, (uint32_t *)s.d_cig);
+                } else {
+                    hipLaunchKernelGGL(aim::scatter_elems_kernel, blocks((uint64_t)nr * rs_dw), dim3(256), 0, s.stream, (const uint32_t *)s.d_rawres,
+                                       s.d_rawidx, nr, rs_dw, (uint32_t *)s.d_res);
+                }
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -858,6 +954,9 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
             if (io->cigars) {
                 HIP_TRY(hipMemcpyAsync(s.h_cursor, s.d_cursor, 4, hipMemcpyDeviceToHost, s.stream));
                 HIP_TRY(hipMemcpyAsync(io->cigars, s.d_cig, (size_t)n * sizeof(aim_cigar_t), hipMemcpyDeviceToHost, s.stream));
+                // slotted run buffer (wfa_lane_packed.hpp): the first 4 n runs are the pairs' own slots, known now -- their copy
+                // overlaps the next batch instead of waiting in aim_set_wait for the cursor; only runs behind the slots follow there
+                if (s.runs_sent) HIP_TRY(hipMemcpyAsync(io->runs, s.d_runs, (size_t)s.runs_sent * 4, hipMemcpyDeviceToHost, s.stream));
             }
             if (io->results) HIP_TRY(hipMemcpyAsync(io->results, s.d_res, (size_t)n * res_size(p), hipMemcpyDeviceToHost, s.stream));
             if (io->ops) HIP_TRY(hipMemcpyAsync(io->ops, s.d_ops, (size_t)n * 2 * rs, hipMemcpyDeviceToHost, s.stream));
@@ -893,19 +992,21 @@ int aim_set_wait(aim_set_t *set, uint32_t device, uint32_t slot, uint32_t *n_run
     uint32_t runs = 0;
     if (io.cigars && s.n_pairs) {   // the run count is only known now: fetch exactly that many
         runs = std::min(std::min(*s.h_cursor, io.runs_cap), set->max_runs);
-        if (runs) {
-            HIP_TRY(hipMemcpyAsync(io.runs, s.d_runs, (size_t)runs * 4, hipMemcpyDeviceToHost, s.stream));
+        if (runs > s.runs_sent) {
+            HIP_TRY(hipMemcpyAsync(io.runs + s.runs_sent, s.d_runs + s.runs_sent, (size_t)(runs - s.runs_sent) * 4, hipMemcpyDeviceToHost, s.stream));
             HIP_TRY(hipStreamSynchronize(s.stream));
         }
+        s.runs_sent = 0;
     }
     if (n_runs) *n_runs = runs;
+    // per DEVICE (devices run concurrently: aim_set_timers reports the slowest device, like aim_set_launch does)
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s.ev[0], s.ev[1]));
-    set->h2d_ms += ms;
+    d.h2d_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, s.ev[2], s.ev[3]));
-    set->kernel_ms += ms;
+    d.kernel_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, s.ev[4], s.ev[5]));
-    set->d2h_ms += ms;
+    d.d2h_ms += ms;
     if (io.cigars) {
         for (uint32_t i = 0; i < s.n_pairs; ++i) {
             if (io.cigars[i].status & AIM_CIGAR_OVERFLOW) return fail(AIM_ENOMEM, "run buffer too small (pair idx %u)", io.cigars[i].idx);
@@ -922,9 +1023,11 @@ int aim_set_wait(aim_set_t *set, uint32_t device, uint32_t slot, uint32_t *n_run
 int aim_set_timers(const aim_set_t *set, float *h2d_ms, float *kernel_ms, float *d2h_ms)
 {
     if (!set) return fail(AIM_EINVAL, "set is NULL");
-    if (h2d_ms) *h2d_ms = set->h2d_ms;
-    if (kernel_ms) *kernel_ms = set->kernel_ms;
-    if (d2h_ms) *d2h_ms = set->d2h_ms;
+    float dh = 0.f, dk = 0.f, dd = 0.f;   // submit / wait path: the slowest device
+    for (const auto &d : set->devs) { dh = std::max(dh, d.h2d_ms); dk = std::max(dk, d.kernel_ms); dd = std::max(dd, d.d2h_ms); }
+    if (h2d_ms) *h2d_ms = set->h2d_ms + dh;
+    if (kernel_ms) *kernel_ms = set->kernel_ms + dk;
+    if (d2h_ms) *d2h_ms = set->d2h_ms + dd;
     return AIM_OK;
 }
 

@@ -30,6 +30,14 @@ struct KArgs {
     const uint32_t *todo; // nullptr: units are pairs 0..n_pairs-1; else {count @0, pair ids @16..} written by wfa_lane
     uint32_t dbg_poison_lds;    // debugging aid (AIM_DEBUG_POISON_LDS): 0 = off, else 0x100 | byte every workgroup fills its
     uint32_t dbg_lds_bytes;     // dynamic LDS with at kernel entry (results must not depend on it)
+    // Fused batch I/O (round 3; aim_hip.h "pipelined batches"): kernels that can, consume the packed image of a batch
+    // directly and emit the compact CIGAR themselves -- no unpack pass, no ops rows, no run-length pass.
+    const uint32_t *packedP;    // [n][ceil(read_size/16)] dwords, 2 bits per base, or nullptr (ASCII rows in patterns / texts)
+    const uint32_t *packedT;
+    aim_cigar_t *cig;           // compact CIGAR headers [n], or nullptr (results in res, ops rows in ops)
+    uint32_t *runs;             // shared run buffer: (length << 8) | op
+    uint32_t runs_cap;          // capacity of runs[], in runs
+    uint32_t *cursor;           // next free run (bump allocated with atomics)
 };
 
 // Request / result access for both wire layouts (aim_hip.h: AIM_FLAG_REQ8 / AIM_FLAG_RES8). The flag tests are wave-uniform.
@@ -75,6 +83,7 @@ struct Knobs {
     bool force_wave = false;      // AIM_FORCE_WAVE=1    WFA: general one-pair-per-wavefront kernel only
     bool no_group = false;        // AIM_NO_GROUP=1      WFA: skip wfa_group_kernel
     bool no_lane_ext = false;     // AIM_NO_LANE_EXT=1   WFA: only the (3,4,1) MAX_SCORE<=5 lane shapes (round-1 behaviour)
+    bool no_lane_pk = false;      // AIM_NO_LANE_PK=1    packed batches: always unpack to ASCII rows first (round-2 behaviour)
     bool wfa_no_ring = false;     // AIM_WFA_NO_RING=1   wfa_wave: no LDS offset ring
     int wfa_slotw = -1;           // AIM_WFA_SLOTW       wfa_wave: diagonals per ring slot
     bool force_dpwave = false;    // AIM_FORCE_DPWAVE=1  NW/SWG: row-scan kernel also for short reads

@@ -63,6 +63,24 @@ __global__ __launch_bounds__(256) void scatter_raw_rows_kernel(int read_size, ui
     reinterpret_cast<uint2 *>((is_text ? outT : outP) + (uint64_t)pair * read_size)[piece] = v;
 }
 
+// Raw side pass of a packed batch whose alignment kernel read the packed rows itself (aim_capi.hip): the pairs of the side
+// list are aligned by the ASCII kernels as a small batch of their own -- requests gathered, results scattered back.
+// Elements are `dw` dwords (requests 2 / 4, results 2 / 6, aim_cigar_t 4).
+__global__ __launch_bounds__(256) void gather_elems_kernel(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t dw, uint32_t *dst)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * dw) return;
+    const uint32_t j = (uint32_t)(t / dw), w = (uint32_t)(t - (uint64_t)j * dw);
+    dst[t] = src[(uint64_t)idx[j] * dw + w];
+}
+__global__ __launch_bounds__(256) void scatter_elems_kernel(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t dw, uint32_t *dst)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * dw) return;
+    const uint32_t j = (uint32_t)(t / dw), w = (uint32_t)(t - (uint64_t)j * dw);
+    dst[(uint64_t)idx[j] * dw + w] = src[t];
+}
+
 // ---- compact CIGAR -------------------------------------------------------------------------------------------------
 // One pair per lane.  Pass 1 counts the runs of ops[begin, end) word-wise (a run starts where a byte differs from its
 // predecessor), the wavefront reserves its runs with ONE atomic add on the batch cursor, pass 2 writes them:
@@ -122,7 +140,9 @@ __global__ __launch_bounds__(64) void cigar_rle_kernel(KArgs a, aim_cigar_t *hdr
     if (lane == 0 && total) base = atomicAdd(cursor, total);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     const uint32_t off = base + incl - n_runs;
-    const bool fits = off + n_runs <= runs_cap;
+    // aim_cigar_t carries n_runs in 16 bits and a run its length in 24: a pair beyond either (GenASM long reads with > 65 535
+    // runs, l >~ 330 kb at e = 10 %) reports AIM_CIGAR_OVERFLOW -- the caller then gathers ops rows -- instead of a truncated count
+    const bool fits = off + n_runs <= runs_cap && n_runs <= 0xffffu && (e - b) < (1 << 24);
     if (walk && fits) {
         uint32_t prev = 0, at = off;
         int start = b;

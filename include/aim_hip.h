@@ -148,7 +148,10 @@ int aim_set_launch(aim_set_t *set);
 int aim_set_pull(aim_set_t *set, uint32_t device, void *results /* aim_result_t[] or, with AIM_FLAG_RES8,
                  aim_result8_t[] */, char *ops);
 /* The three phase timers host.c prints ("CPU-DPU", "DPU Kernel", "DPU-CPU",
- * host.c:270-272, 297-299, 328-330), in milliseconds, accumulated. */
+ * host.c:270-272, 297-299, 328-330), in milliseconds, accumulated. Devices of a set work concurrently: each figure is the
+ * SLOWEST device's (aim_set_launch: per launch; aim_set_submit / aim_set_wait: each device's batches summed, then the
+ * maximum over devices). With several slots the phases of one device's batches overlap each other, so the three figures are
+ * device-time per phase, not a partition of the wall time. */
 int aim_set_timers(const aim_set_t *set, float *h2d_ms, float *kernel_ms, float *d2h_ms);
 /* How many pairs of the last launch on `device` left the short-read fast path
  * (sequences with bytes other than A/C/G/T) and were aligned by the general

@@ -794,7 +794,10 @@ def test_packed_input_and_compact_cigar_match_default_path(gpu, algo, l, err, n,
                 assert np.array_equal(out["cig"]["status"], base_res["status"].astype(np.uint16))
                 if want is not None:
                     assert engine.format_output_runs(out["cig"], out["runs"]) == want
-                assert int(out["cig"]["n_runs"].sum()) == len(out["runs"])
+                if s.plan_describe(0).startswith("wfa_lane_packed_kernel"):   # slotted run buffer: 4 runs per pair, longer CIGARs behind
+                    assert len(out["runs"]) >= 4 * n and len(out["runs"]) >= int(out["cig"]["n_runs"].sum())
+                else:
+                    assert int(out["cig"]["n_runs"].sum()) == len(out["runs"])
 
 
 def test_compact_cigar_bytes_per_pair_and_overflow(gpu):
@@ -995,3 +998,131 @@ def test_host_cli_pipeline_over_two_set_members(gpu, sample_bytes, ref_digests, 
         assert r.returncode == 0, r.stdout + r.stderr
         assert "14 batch(es)" in r.stdout and "2 device(s) x 2 slot(s)" in r.stdout, r.stdout
         assert md5(out.read_bytes()) == ref_digests[key]
+
+
+# ------------------------------------------------------------------ round 3: one kernel per batch (packed rows in, compact CIGAR out)
+def _oracle_text(algo, params, req, pat, txt):
+    from oracle import oracle
+    op = _oracle_params(oracle, params, algo)
+    ores, oops, _ = oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=8)
+    return ores, oracle.format_output(ores, oops, bool(op.backtrace))
+
+
+def _fused(params, req, pat, txt, runs_cap=None, expect_kernel="wfa_lane_packed_kernel", slots=1):
+    """One packed batch through aim_set_submit / aim_set_wait; returns (out, plan line)."""
+    from aim_amd import capi, engine
+    n = len(req)
+    bt = bool(params.flags & capi.FLAG_BACKTRACE)
+    packed = engine.pack_batch(req, pat, txt)
+    if runs_cap is None:
+        runs_cap = 8 * n + 64
+    with engine.DeviceSet(1) as s:
+        s.configure_slots(params, max(n, 1), slots=slots, max_raw=max(n, 1), max_runs=(runs_cap if bt else 0))
+        s.submit(0, 0, req, packed=packed, cigar_runs_cap=(runs_cap if bt else 0))
+        out = s.wait(0, 0, check=False)
+        plan = s.plan_describe(0)
+    if expect_kernel:
+        assert plan.startswith(expect_kernel), plan
+    return out, plan
+
+
+FUSED_SHAPES = [(100, 0.01, 112, 5), (70, 0.01, 80, 4), (100, 0.01, 112, 3), (150, 0.005, 160, 4), (140, 0.005, 144, 5), (170, 0.005, 176, 5)]
+
+
+@pytest.mark.parametrize("l,err,rs,ms", FUSED_SHAPES)
+@pytest.mark.parametrize("bt", [False, True])
+def test_fused_packed_lane_kernel_against_oracle(gpu, l, err, rs, ms, bt):
+    """SURVEY 8f-1 / 8f-2, VERDICT r02 item 1: a packed batch whose configuration wfa_lane_packed_kernel takes is ONE kernel --
+    it reads the 2-bit rows itself and, with BACKTRACE, writes aim_cigar_t + runs itself. Compared with the ORACLE (scores,
+    output text) -- not with the default path -- on every READ_SIZE the kernel is built for, incl. pairs that exceed the cap,
+    pairs with bytes outside A/C/G/T (raw side pass) and a ragged batch tail."""
+    from aim_amd import engine
+    n = 3000 + 37
+    req, pat, txt = engine.gen_pairs(77 + l, 3, n, l, err, rs)
+    r2, p2, t2 = engine.gen_pairs(78 + l, 3, 500, l, min(0.04, (rs - l - 0.5) / l), rs)   # some pairs beyond MAX_SCORE
+    req[1000:1500], pat[1000:1500], txt[1000:1500] = r2, p2, t2
+    req["idx"] = np.arange(n)                                          # the oracle numbers its output 0 .. n-1
+    for i in range(0, n, 11):                                          # pairs that cannot be packed
+        pat[i, i % (l // 2)] = ord("N")
+    for i in range(5, n, 53):
+        j = (3 * i) % (l // 2)
+        pat[i, j] = ord("N"); txt[i, j] = ord("N")
+    params = engine.make_params("wfa", ms, rs, backtrace=bt, reduce=True, req8=True, res8=not bt)
+    ores, want = _oracle_text("wfa", params, req, pat, txt)
+    assert (ores["score"] == ms + 1).any() and (ores["score"] <= ms).any()
+    out, _ = _fused(params, req, pat, txt)
+    if bt:
+        assert np.array_equal(out["cig"]["score"], ores["score"]) and np.array_equal(out["cig"]["idx"], req["idx"])
+        assert (out["cig"]["status"] == 0).all()
+        assert engine.format_output_runs(out["cig"], out["runs"]) == want
+    else:
+        assert np.array_equal(out["res"]["score"], ores["score"]) and np.array_equal(out["res"]["idx"], req["idx"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129, 1000])
+def test_fused_packed_lane_kernel_ragged_and_edge_pairs(gpu, n):
+    from aim_amd import engine
+    req, pat, txt = engine.gen_pairs(5, 0, n, 100, 0.01, 112)
+    for ms in (0, 2, 5):
+        for bt in (False, True):
+            params = engine.make_params("wfa", ms, 112, backtrace=bt, reduce=True)
+            ores, want = _oracle_text("wfa", params, req, pat, txt)
+            out, _ = _fused(params, req, pat, txt)
+            if bt:
+                assert engine.format_output_runs(out["cig"], out["runs"]) == want
+            else:
+                assert np.array_equal(out["res"]["score"], ores["score"])
+    if n == 65:   # the hand-made edge pairs (empty sequences, all-mismatch, lower case, N runs, 112-base rows)
+        req, pat, txt = _mk(EDGE_PAIRS, 112)
+        req["idx"] = np.arange(len(req))
+        for bt in (False, True):
+            params = engine.make_params("wfa", 5, 112, backtrace=bt)
+            ores, want = _oracle_text("wfa", params, req, pat, txt)
+            out, _ = _fused(params, req, pat, txt)
+            if bt:
+                assert engine.format_output_runs(out["cig"], out["runs"]) == want
+            else:
+                assert np.array_equal(out["res"]["score"], ores["score"])
+
+
+def test_fused_packed_lane_kernel_run_lists_equal_the_rle_kernel(gpu, monkeypatch):
+    """The run lists the fused kernel emits are the lists cigar_rle_kernel produces from the ops rows of the default kernel
+    (same runs, same n_runs, same status) -- and a run buffer with fewer than 4 runs per pair switches the fused kernel from
+    its slotted layout to bump allocation without changing them."""
+    from aim_amd import engine
+    n = 20000
+    req, pat, txt = engine.gen_pairs(91, 0, n, 100, 0.01, 112)
+    r2, p2, t2 = engine.gen_pairs(92, 0, 4000, 100, 0.03, 112)
+    req[3000:7000], pat[3000:7000], txt[3000:7000] = r2, p2, t2
+    req["idx"] = np.arange(n)
+    params = engine.make_params("wfa", 5, 112, backtrace=True, reduce=True)
+
+    def lists(out):
+        c, r = out["cig"], out["runs"]
+        return [tuple(r[int(c["run_offset"][i]): int(c["run_offset"][i]) + int(c["n_runs"][i])]) for i in range(len(c))]
+    fused, _ = _fused(params, req, pat, txt)
+    bump, _ = _fused(params, req, pat, txt, runs_cap=3 * n + 4096)          # < 4 n: no slots
+    monkeypatch.setenv("AIM_NO_LANE_PK", "1")
+    unfused, plan = _fused(params, req, pat, txt, expect_kernel="wfa_lane_kernel")
+    a, b, c = lists(fused), lists(bump), lists(unfused)
+    assert a == c and b == c
+    assert np.array_equal(fused["cig"]["status"], unfused["cig"]["status"]) and np.array_equal(fused["cig"]["score"], unfused["cig"]["score"])
+    assert len(bump["runs"]) == int(bump["cig"]["n_runs"].sum())             # bump allocation leaves no holes
+
+
+def test_fused_packed_dynamic_bounds_shape_against_oracle(gpu):
+    """MAX_SCORE 6..10 score-only on packed batches: the dynamic-bounds score loop inside wfa_lane_packed_kernel, READ_SIZE 80 .. 176."""
+    from aim_amd import engine
+    for l, rs in ((100, 112), (70, 80), (150, 160), (130, 144), (165, 176)):
+        for ms, err in ((6, 0.02), (8, 0.05), (10, 0.10), (10, 0.02)):
+            if l + int(np.ceil(l * err)) + 1 > rs:
+                continue
+            n = 4000
+            req, pat, txt = engine.gen_pairs(900 + ms + l, 0, n, l, err, rs)
+            for i in range(0, n, 97):
+                pat[i, i % (l // 2)] = ord("N")
+            for reduce in (True, False):
+                params = engine.make_params("wfa", ms, rs, reduce=reduce, req8=True, res8=True)
+                ores, _ = _oracle_text("wfa", params, req, pat, txt)
+                out, _ = _fused(params, req, pat, txt)
+                assert np.array_equal(out["res"]["score"], ores["score"]), (l, rs, ms, err, reduce)
