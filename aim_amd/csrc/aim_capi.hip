@@ -73,7 +73,8 @@ struct Plan {
     uint32_t fb_grid;       // K_WFA_LANE / K_WFA_GROUP: grid / LDS of the fallback (general) kernel
     size_t fb_lds;
     bool no_lane;
-    size_t hist_bytes;      // K_WFA_GROUP + BACKTRACE: per-pair history slabs between to-do region and fallback scratch
+    size_t hist_bytes;      // K_WFA_GROUP + BACKTRACE: history regions (one per pair of a chunk) between to-do region and fallback scratch
+    uint32_t chunk_pairs;   // K_WFA_GROUP + BACKTRACE: pairs per compute + traceback launch (their history regions fit the scratch bound)
     aim::GroupCfg gcfg;     // K_WFA_GROUP
     int group_g;
     bool pk;                // the kernel reads the packed rows of the batch itself (no unpack pass)
@@ -202,10 +203,22 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         const bool lane_ok = !kn.force_wave && !pl->no_lane && aim::wfa_lane_supported(p, !kn.no_lane_ext);
         aim::GroupCfg gc;
         int gg = 0;
-        uint32_t ggrid = 0;
-        size_t glds = 0, ghist = 0;
+        uint32_t ggrid = 0, gchunk = n_pairs;
+        size_t glds = 0, ghist = 0, ghist_pair = 0;
+        const bool gpk = (mode & MODE_PACKED_IN) && !kn.no_lane_pk;   // the group kernel reads packed rows itself
         bool group_ok = !lane_ok && !kn.force_wave && !pl->no_lane && !kn.no_group &&
-                        aim::wfa_group_plan(p, n_pairs, kn, &gc, &gg, &ggrid, &glds, &ghist) && ghist <= budget / 2;
+                        aim::wfa_group_plan(p, n_pairs, kn, gpk, &gc, &gg, &ggrid, &glds, &ghist_pair);
+        if (group_ok && ghist_pair) {
+            // BACKTRACE: every pair of a launch keeps its history region until the traceback kernel has walked it. Launches are
+            // chunks of the batch whose regions fit half of the scratch bound (one chunk whenever possible).
+            const uint64_t fit = (budget / 2) / ghist_pair;
+            if (fit < 4096 && fit < n_pairs) group_ok = false;   // too few pairs in flight to fill the chip: the general kernel's pools are smaller
+            else {
+                gchunk = (uint32_t)std::min<uint64_t>(n_pairs, fit);
+                if (gchunk < n_pairs) gchunk &= ~63u;
+                ghist = (((size_t)gchunk * ghist_pair) + 255) & ~(size_t)255;
+            }
+        }
         if (lane_ok) {
             // one pair per lane, everything in registers; no scratch, no second kernel (pairs with bytes outside A/C/G/T take
             // the kernel's own raw-byte path)
@@ -235,6 +248,9 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             pl->lds = glds;
             pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
             pl->hist_bytes = ghist;
+            pl->chunk_pairs = gchunk;
+            pl->pk = gpk;
+            pl->emits_runs = bt && (mode & MODE_RUNS_OUT);
             pl->scratch_total = pl->todo_bytes + pl->hist_bytes + fb.scratch_total;
             return AIM_OK;
         }
@@ -331,8 +347,8 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
 // One line that identifies a plan completely: kernel, lanes / wavefronts per pair, grid, block, LDS, scratch.
 int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint64_t budget, char *out, size_t cap)
 {
-    char extra[96] = "";
-    if (pl.kid == K_WFA_GROUP) snprintf(extra, sizeof extra, " G=%d hist=%zu fb_grid=%u", pl.group_g, pl.hist_bytes, pl.fb_grid);
+    char extra[160] = "";
+    if (pl.kid == K_WFA_GROUP) snprintf(extra, sizeof extra, " G=%d hist=%zu chunk=%u fb_grid=%u packed_in=%d runs_out=%d", pl.group_g, pl.hist_bytes, pl.chunk_pairs, pl.fb_grid, (int)pl.pk, (int)pl.emits_runs);
     else if (pl.kid == K_DP_WAVE) snprintf(extra, sizeof extra, " wavefronts_per_pair=%u", pl.block / 64);
     else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
     else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
@@ -381,8 +397,9 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     const bool red = p.flags & AIM_FLAG_REDUCE;
     if (pl.pk && (!fio || !fio->packedP || !fio->packedT)) return fail(AIM_EINVAL, "plan reads packed rows but none were given");
     if (pl.emits_runs && (!fio || !fio->cig || !fio->runs || !fio->cursor)) return fail(AIM_EINVAL, "plan emits the compact CIGAR but no buffers were given");
-    if (!d_req || (!pl.pk && (!d_pat || !d_txt)) || (!pl.emits_runs && !d_res)) return fail(AIM_EINVAL, "null device buffer");
-    if (bt && !pl.emits_runs && !d_ops) return fail(AIM_EINVAL, "AIM_FLAG_BACKTRACE needs an ops buffer");
+    const bool lane_pk = pl.kid == K_WFA_LANE_PK;   // the only plan that never touches ASCII rows, result_t or ops rows
+    if (!d_req || (!lane_pk && (!d_pat || !d_txt)) || (!(lane_pk && pl.emits_runs) && !d_res)) return fail(AIM_EINVAL, "null device buffer");
+    if (bt && !(lane_pk && pl.emits_runs) && !d_ops) return fail(AIM_EINVAL, "AIM_FLAG_BACKTRACE needs an ops buffer");
     if (scratch_bytes < pl.scratch_total || (!d_scratch && pl.scratch_total))
         return fail(AIM_EINVAL, "scratch too small: need %zu bytes, got %zu", pl.scratch_total, scratch_bytes);
     aim::KArgs ka;
@@ -408,6 +425,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     ka.runs = fio ? fio->runs : nullptr;
     ka.runs_cap = fio ? fio->runs_cap : 0u;
     ka.cursor = fio ? fio->cursor : nullptr;
+    ka.pair_base = 0;
     switch (pl.kid) {
     case K_WFA_WAVE:
         if (bt && red) launch_wfa_wave<true, true>(pl, ka, stream);
@@ -423,15 +441,45 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         aim::wfa_lane_packed_launch(p, pl.grid, pl.lds, ka, fio->run_slot, stream);
         break;
     case K_WFA_GROUP: {
-        // [to-do region | history slabs | general kernel scratch]: count zeroed per launch, fast kernel, then the drain
+        // [to-do region | history regions | general kernel scratch]: count zeroed per launch; fast kernel (+ traceback kernel
+        // with BACKTRACE) chunk by chunk; then the general kernel drains the to-do list
         HIP_TRY(hipMemsetAsync(d_scratch, 0, 64, stream));
         ka.scratch_per_wave = pl.todo_bytes;   // (diagnostic builds park their stamps behind the to-do region)
-        aim::wfa_group_launch(p, pl.group_g, pl.gcfg, pl.grid, pl.lds, ka, stream);
-        HIP_TRY(hipGetLastError());
+        const uint32_t chunk = (bt && pl.chunk_pairs) ? pl.chunk_pairs : n_pairs;
+        const size_t rqb = (p.flags & AIM_FLAG_REQ8) ? sizeof(aim_request8_t) : sizeof(aim_request_t);
+        const size_t rsb = (p.flags & AIM_FLAG_RES8) ? sizeof(aim_result8_t) : sizeof(aim_result_t);
+        const size_t npw = aim::packed_row_dwords(p.read_size);
+        for (uint32_t first = 0; first < n_pairs; first += chunk) {
+            aim::KArgs kc = ka;
+            kc.n_pairs = std::min(chunk, n_pairs - first);
+            kc.pair_base = first;
+            kc.req = reinterpret_cast<const aim_request_t *>(static_cast<const char *>(d_req) + (size_t)first * rqb);
+            if (d_pat) { kc.patterns = d_pat + (size_t)first * p.read_size; kc.texts = d_txt + (size_t)first * p.read_size; }
+            if (d_res) kc.res = reinterpret_cast<aim_result_t *>(static_cast<char *>(d_res) + (size_t)first * rsb);
+            if (d_ops) kc.ops = d_ops + (size_t)first * 2 * p.read_size;
+            if (ka.packedP) { kc.packedP = ka.packedP + (size_t)first * npw; kc.packedT = ka.packedT + (size_t)first * npw; }
+            if (ka.cig) kc.cig = ka.cig + first;
+            // a chunk smaller than the plan's grid needs fewer workgroups (the grid stays a multiple of 8)
+            uint32_t grid = pl.grid;
+            {
+                const uint32_t ppw = 64u / (uint32_t)pl.group_g;
+                const uint32_t need = ((((kc.n_pairs + ppw - 1) / ppw) + 7u) / 8u) * 8u;
+                if (grid > need) grid = need < 8u ? 8u : need;
+            }
+            aim::wfa_group_launch(p, pl.group_g, pl.gcfg, grid, pl.lds, kc, stream);
+            if (bt) aim::wfa_group_tb_launch(p, pl.gcfg, kc.n_pairs, kc, stream);
+            HIP_TRY(hipGetLastError());
+        }
         aim::KArgs kb = ka;
+        kb.packedP = kb.packedT = nullptr;
+        kb.cig = nullptr;
         kb.todo = reinterpret_cast<const uint32_t *>(d_scratch);
         kb.scratch = (char *)d_scratch + pl.todo_bytes + pl.hist_bytes;
         kb.scratch_per_wave = pl.scratch_per_wg;
+        if (pl.pk) {   // the general kernel reads ASCII rows: expand the to-do pairs' packed rows in place first
+            hipLaunchKernelGGL(aim::unpack_todo_rows_kernel, dim3(256), dim3(256), 0, stream, ka, kb.todo, ka.packedP, ka.packedT, const_cast<char *>(d_pat), const_cast<char *>(d_txt));
+            HIP_TRY(hipGetLastError());
+        }
         Plan fb = pl;
         fb.grid = pl.fb_grid;
         fb.lds = pl.fb_lds;
@@ -440,6 +488,10 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         else if (bt) launch_wfa_wave<true, false>(fb, kb, stream);
         else if (red) launch_wfa_wave<false, true>(fb, kb, stream);
         else launch_wfa_wave<false, false>(fb, kb, stream);
+        if (pl.emits_runs) {   // the general kernel wrote result_t + ops rows for the to-do pairs: their compact CIGAR
+            hipLaunchKernelGGL(aim::cigar_rle_todo_kernel, dim3(256), dim3(64), 0, stream, kb, kb.todo, ka.cig, ka.runs, ka.runs_cap, ka.cursor);
+            HIP_TRY(hipGetLastError());
+        }
         break;
     }
     case K_DP_LANE:
@@ -568,7 +620,7 @@ int launch_on_slot(aim_set *set, aim_device_ctx &d, aim_slot &s, uint32_t mode =
     const Plan pl = plan_for_batch(set, d, s, s.n_pairs, mode);
     s.plan_last = pl;
     if (fio && pl.emits_runs) {   // slotted run buffer: pair p owns runs[4p, 4p + 4), the cursor starts behind the slots (wfa_lane_packed.hpp)
-        fio->run_slot = ((uint64_t)s.n_pairs * aim::kRunSlot <= fio->runs_cap) ? aim::kRunSlot : 0u;
+        fio->run_slot = (pl.kid == K_WFA_LANE_PK && (uint64_t)s.n_pairs * aim::kRunSlot <= fio->runs_cap) ? aim::kRunSlot : 0u;
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)fio->cursor, (int)(s.n_pairs * fio->run_slot), 1, s.stream));
     }
     return launch(pl, set->knobs, set->params, s.n_pairs, s.d_req, s.d_pat, s.d_txt, s.d_res, s.d_ops, s.d_scratch,
@@ -944,6 +996,11 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
                 } else {
                     hipLaunchKernelGGL(aim::scatter_elems_kernel, blocks((uint64_t)nr * rs_dw), dim3(256), 0, s.stream, (const uint32_t *)s.d_rawres,
                                        s.d_rawidx, nr, rs_dw, (uint32_t *)s.d_res);
+                    if (bt) {   // default output (result_t + ops rows): the side list's ops rows go home too
+                        const uint32_t op_dw = (uint32_t)(2 * rs / 4);
+                        hipLaunchKernelGGL(aim::scatter_elems_kernel, blocks((uint64_t)nr * op_dw), dim3(256), 0, s.stream, (const uint32_t *)s.d_rawops,
+                                           s.d_rawidx, nr, op_dw, (uint32_t *)s.d_ops);
+                    }
                 }
                 HIP_TRY(hipGetLastError());
             }

@@ -38,6 +38,8 @@ struct KArgs {
     uint32_t *runs;             // shared run buffer: (length << 8) | op
     uint32_t runs_cap;          // capacity of runs[], in runs
     uint32_t *cursor;           // next free run (bump allocated with atomics)
+    uint32_t pair_base;         // the launch covers pairs [pair_base, pair_base + n_pairs) of the batch (chunked launches): pair ids
+                                // appended to a to-do list are batch-relative
 };
 
 // Request / result access for both wire layouts (aim_hip.h: AIM_FLAG_REQ8 / AIM_FLAG_RES8). The flag tests are wave-uniform.

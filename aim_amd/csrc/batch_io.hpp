@@ -91,11 +91,10 @@ __device__ __forceinline__ uint32_t nonzero_byte_mask(uint32_t x)   // 0x80 in e
     return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
 }
 
-__global__ __launch_bounds__(64) void cigar_rle_kernel(KArgs a, aim_cigar_t *hdr, uint32_t *runs, uint32_t runs_cap, uint32_t *cursor)
+// one wavefront of 64 pairs: `pair` is this lane's pair (any value when !active); all 64 lanes must call
+__device__ __forceinline__ void cigar_rle_wave(const KArgs &a, uint32_t pair, bool active, int lane, aim_cigar_t *hdr, uint32_t *runs, uint32_t runs_cap,
+                                               uint32_t *cursor)
 {
-    const int lane = threadIdx.x;
-    const uint32_t pair = blockIdx.x * kWave + lane;
-    const bool active = pair < a.n_pairs;
     const int rs = a.p.read_size;
     aim_result_t r;
     r.begin_offset = 0; r.end_offset = 0; r.score = 0; r.status = AIM_PAIR_OK; r.idx = 0; r.max_operations = 0;
@@ -170,6 +169,56 @@ __global__ __launch_bounds__(64) void cigar_rle_kernel(KArgs a, aim_cigar_t *hdr
         h.n_runs = (uint16_t)((walk && fits) ? n_runs : 0u);
         h.status = (uint16_t)((uint32_t)r.status | ((walk && !fits) ? AIM_CIGAR_OVERFLOW : 0u));
         hdr[pair] = h;
+    }
+}
+
+__global__ __launch_bounds__(64) void cigar_rle_kernel(KArgs a, aim_cigar_t *hdr, uint32_t *runs, uint32_t runs_cap, uint32_t *cursor)
+{
+    const int lane = threadIdx.x;
+    const uint32_t pair = blockIdx.x * kWave + lane;
+    cigar_rle_wave(a, pair, pair < a.n_pairs, lane, hdr, runs, runs_cap, cursor);
+}
+
+// The same over a device-side list of pairs (the to-do list of wfa_group_kernel: {count @0, pair ids @16..}, wfa_lane.hpp
+// LANE_TODO_*): the general kernel aligned those pairs into result_t + ops rows; a fused batch wants their compact CIGAR.
+__global__ __launch_bounds__(64) void cigar_rle_todo_kernel(KArgs a, const uint32_t *todo, aim_cigar_t *hdr, uint32_t *runs, uint32_t runs_cap, uint32_t *cursor)
+{
+    const int lane = threadIdx.x;
+    const uint32_t count = todo[0];
+    for (uint32_t base = blockIdx.x * kWave; base < count; base += gridDim.x * kWave) {
+        const uint32_t i = base + lane;
+        const bool active = i < count;
+        const uint32_t pair = active ? todo[16 + i] : 0u;
+        cigar_rle_wave(a, pair, active, lane, hdr, runs, runs_cap, cursor);
+    }
+}
+
+// ... and the expansion of exactly those pairs' packed rows into the ASCII rows the general kernel reads (8 bases per thread).
+__global__ __launch_bounds__(256) void unpack_todo_rows_kernel(KArgs a, const uint32_t *todo, const uint32_t *packedP, const uint32_t *packedT, char *outP, char *outT)
+{
+    const int rs = a.p.read_size;
+    const uint32_t per_row = (uint32_t)rs / 8u;
+    const uint64_t total = (uint64_t)todo[0] * per_row * 2u;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const bool is_text = t & 1u;
+        const uint64_t u = t >> 1;
+        const uint32_t pair = todo[16 + (uint32_t)(u / per_row)], piece = (uint32_t)(u % per_row);
+        const aim_request_t rq = load_request(a, pair);
+        const int len = is_text ? rq.text_len : rq.pattern_len;
+        const uint16_t *src = reinterpret_cast<const uint16_t *>((is_text ? packedT : packedP) + (uint64_t)pair * packed_row_dwords(rs));
+        const uint32_t bits = src[piece];
+        const uint32_t lo = (bits & 3u) | ((bits & 0xCu) << 6) | ((bits & 0x30u) << 12) | ((bits & 0xC0u) << 18);
+        const uint32_t hb = bits >> 8;
+        const uint32_t hi = (hb & 3u) | ((hb & 0xCu) << 6) | ((hb & 0x30u) << 12) | ((hb & 0xC0u) << 18);
+        uint32_t w0 = __builtin_amdgcn_perm(0u, 0x47544341u, lo);
+        uint32_t w1 = __builtin_amdgcn_perm(0u, 0x47544341u, hi);
+        const int rem = len - (int)piece * 8;
+        if (rem < 8) {
+            const uint64_t keep = rem <= 0 ? 0ull : ((1ull << (8 * rem)) - 1ull);
+            w0 &= (uint32_t)keep;
+            w1 &= (uint32_t)(keep >> 32);
+        }
+        reinterpret_cast<uint2 *>((is_text ? outT : outP) + (uint64_t)pair * rs)[piece] = make_uint2(w0, w1);
     }
 }
 

@@ -22,7 +22,7 @@
 #include <cstdio>
 #include "aim_device.hpp"
 #include "wfa_lane.hpp"
-
+#include "wfa_lane_packed.hpp"
 
 #ifndef AIM_GROUP_DIRECT_G
 #define AIM_GROUP_DIRECT_G 8      // groups of at least this many lanes pack their sequences straight from global memory (no LDS staging rows)
@@ -47,7 +47,14 @@ struct GroupCfg {
     int np;           // packed dwords per sequence (READ_SIZE/16 rounded up) + 1 pad
     int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)
     int rows_per_wave;
-    int hist_stride;  // BACKTRACE: int16 entries of one pair's HBM history slab = (MAX_SCORE+2) * (3*wcap + 4)
+    // BACKTRACE: every pair of the launch (chunk) owns a history region in HBM that outlives the compute kernel -- the traceback
+    // is a kernel of its own (wfa_group_tb_kernel):  [TbHead 16 B][TbRow table, (MAX_SCORE+2) x 16 B][pool of int16 offsets:
+    // per score the computed cells {M, I, D, -} of [lo, hi], contiguous][run scratch: (2*MAX_SCORE+16) x 4 B, compact CIGAR only]
+    int hist_pair_bytes;  // bytes of one pair's region (multiple of 256)
+    int pool_off;         // byte offset of the pool inside the region
+    int pool_cap;         // cells {M, I, D, -} (8 B) of the pool: sum over scores of min(2s+1, widest wavefront the plan admits)
+    int runs_off;         // byte offset of the run scratch
+    int runs_cap;         // entries of it
     int wlds;         // entries per ring row IN LDS: wcap (every diagonal has its own home), or a power of two < wcap ("narrow
                       // window": homes are (k + kbias) & wmask; a pair whose wavefront outgrows wlds - 2 diagonals is handed
                       // to the general kernel through the to-do list, like a pair with non-ACGT bytes)
@@ -56,6 +63,11 @@ struct GroupCfg {
 
 enum { GF_PRESENT = 1, GF_MNULL = 2, GF_INULL = 4, GF_DNULL = 8, GF_HASI = 16, GF_HASD = 32 };
 constexpr int kGrpNull = -16384;
+
+// Per-pair history (BACKTRACE): head + one 16-byte descriptor per score + the offsets (see GroupCfg).
+struct TbHead { int32_t final_score; int32_t walk; int32_t pad[2]; };   // walk: 1 = the traceback kernel owns this pair, 0 = to-do list / not computed
+struct TbRow { uint32_t off; int16_t lo, hi, klo, khi, flags, pad; };   // off: pool index of cell lo of this score's row; one cell = {M, I, D, -} int16 (8 B)
+static_assert(sizeof(TbHead) == 16 && sizeof(TbRow) == 16, "history layout");
 
 // minimum over the G lanes of a group (G-aligned inside a 16-lane DPP row); every lane of the group gets it
 template <int G>
@@ -94,7 +106,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
     const int rs = a.p.read_size;
     // raw rows of one array, whole 16-B chunks; a whole-wavefront group (G == 64) packs straight from global memory
     // instead (one pair per ~2 ms of compute: nothing to hide, and 2*READ_SIZE bytes of LDS buy residency)
-    const int rows_dw = G >= AIM_GROUP_DIRECT_G ? 0 : ((PPW * rs + 15) / 16) * 4;
+    const bool pk = a.packedP != nullptr;               // wave-uniform: the batch arrived packed (2 bits per base): no staging, no validation
+    const int rows_dw = (G >= AIM_GROUP_DIRECT_G || pk) ? 0 : ((PPW * rs + 15) / 16) * 4;
     uint32_t *rowsP = reinterpret_cast<uint32_t *>(smem);
     uint32_t *rowsT = rowsP + rows_dw;
     uint32_t *pairmem = rowsT + rows_dw + 1;
@@ -110,19 +123,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
     const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
     const int kb = c.kbias;
     uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
-    // BACKTRACE: every wavefront is also streamed to a per-pair HBM slab [score][M | I | D | klo,khi,flags,-]
-    // (fixed homes, no allocator); the traceback of a pair is walked by the first lane of its group.
-    int16_t *hist = BT ? reinterpret_cast<int16_t *>(a.scratch + a.scratch_per_wave) + ((size_t)blockIdx.x * PPW + q) * c.hist_stride : nullptr;
-    const int hrow = 3 * c.wcap + 4;
-    auto hM = [&](int s) { return hist + (size_t)s * hrow + kb; };
-    auto hI = [&](int s) { return hist + (size_t)s * hrow + c.wcap + kb; };
-    auto hD = [&](int s) { return hist + (size_t)s * hrow + 2 * c.wcap + kb; };
-    auto hMeta = [&](int s) { return hist + (size_t)s * hrow + 3 * c.wcap; };
+    // BACKTRACE: every wavefront is also streamed to the pair's history region in HBM (GroupCfg); wfa_group_tb_kernel walks it.
+    char *hist_base = BT ? a.scratch + a.scratch_per_wave : nullptr;
     const uint32_t n_units = (a.n_pairs + PPW - 1) / PPW;
     const int nchunk_total = (PPW * rs + 15) / 16;       // 16-B chunks per array per unit (the last one may run into the next row / tail slack)
 
     auto dma = [&](uint32_t unit) {
-        if (G >= AIM_GROUP_DIRECT_G) return;
+        if (G >= AIM_GROUP_DIRECT_G || pk) return;
         const uint32_t pair0 = unit * PPW;
         const uint32_t rows = min((uint32_t)PPW, a.n_pairs - pair0);
         const int nchunks = (int)((rows * rs + 15) / 16);
@@ -175,7 +182,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         const int plen = rq.pattern_len, tlen = rq.text_len;
         // ---- validate + pack: the G lanes of a group split the packed dwords of their pair ------------------------
         uint32_t bad = 0;
-        {
+        if (pk) {   // the wire image IS the LDS image: the group's lanes copy the ceil(READ_SIZE/16) dwords of each row
+            const int npw = (rs + 15) / 16;
+            const uint32_t *gp = a.packedP + (uint64_t)pair * npw, *gt = a.packedT + (uint64_t)pair * npw;
+            for (int j = g; j < npw; j += G) {
+                pkP[j] = active ? __builtin_nontemporal_load(gp + j) : 0u;
+                pkT[j] = active ? __builtin_nontemporal_load(gt + j) : 0u;
+            }
+            if (g == 0) { pkP[c.np - 1] = 0u; pkT[c.np - 1] = 0u; }
+        } else {
             const uint32_t *rp = G >= AIM_GROUP_DIRECT_G ? reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs) : rowsP + (q * rs) / 4;
             const uint32_t *rt = G >= AIM_GROUP_DIRECT_G ? reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs) : rowsT + (q * rs) / 4;
             const int npw = (rs + 15) / 16;
@@ -253,13 +268,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
         // Every later wavefront is extended by the lane that computes it (below); score 0 has no compute step.
         int part = 0x7fffffff;                     // min over my diagonals of the distance to the end (for the reduction)
+        // history region of this pair (BACKTRACE): descriptor table + pool; h_off / h_lo / h_hi describe the current score's row
+        char *hreg = BT ? hist_base + (size_t)(active ? pair : 0u) * (size_t)c.hist_pair_bytes : nullptr;
+        TbRow *htab = reinterpret_cast<TbRow *>(hreg + sizeof(TbHead));
+        uint2 *hpool = reinterpret_cast<uint2 *>(hreg + c.pool_off);   // cells {M, I, D, -}: ONE 8-byte store per computed cell
+        int htop = 1, h_off = 0, h_lo = 0, h_hi = 0;   // score 0: cell 0 of the pool
         if (g == 0) {
             const int m00 = done ? 0 : extend(0, 0);
             mrow_at(0)[H(0)] = (int16_t)m00;
-            if (BT && !done) hM(0)[0] = (int16_t)m00;
+            if (BT && !done) hpool[0] = make_uint2((uint32_t)(uint16_t)m00, 0u);
             meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
         }
-        if (BT && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465
+        if (BT && a.cig == nullptr && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465 (ops-row output only)
             uint4 *orow = reinterpret_cast<uint4 *>(a.ops + (uint64_t)pair * 2 * rs);
             const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
             for (int j = g; j < (2 * rs) / 16; j += G) orow[j] = mm;
@@ -297,9 +317,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     }
                     fence();
                 }
-                if (BT && g == 0) {   // final descriptor of this score (after reduction)
-                    int16_t *hm = hMeta(score);
-                    hm[0] = (int16_t)klo; hm[1] = (int16_t)khi; hm[2] = (int16_t)flags;
+                if (BT && g == 0) {   // final descriptor of this score (after reduction): one 16-byte store
+                    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                    aim_u32x4 d4;
+                    d4.x = (uint32_t)h_off;
+                    d4.y = (uint32_t)(uint16_t)h_lo | ((uint32_t)(uint16_t)h_hi << 16);
+                    d4.z = (uint32_t)(uint16_t)klo | ((uint32_t)(uint16_t)khi << 16);
+                    d4.w = (uint32_t)(uint16_t)flags;
+                    *reinterpret_cast<aim_u32x4 *>(htab + score) = d4;
                 }
                 // affine_wfa_end_reached, wfa.c:210-230
                 if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[H(ak)] >= tlen) {
@@ -344,6 +369,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                 AIM_GSTAMP(2);   // score++, source descriptors
                 if (m_sub_null && i_out_null && d_out_null) {
                     flags = 0; klo = 0; khi = -1;
+                    if (BT) { h_off = 0; h_lo = 0; h_hi = -1; }
                 } else {
                     if (m_sub_null) { sub_lo = 1; sub_hi = -1; }
                     if (m_o_null) { o_lo = 1; o_hi = -1; }
@@ -352,10 +378,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     const int hi = max(max(sub_hi, o_hi), e_hi) + 1;
                     flags = GF_PRESENT | (i_out_null ? GF_INULL : GF_HASI) | (d_out_null ? GF_DNULL : GF_HASD);
                     klo = lo; khi = hi;
+                    int hi_run = hi;                   // the cells this step computes: [lo, hi_run]
                     if (hi - lo + 1 > c.wlds - 2) {   // narrow window outgrown (never true in linear mode): the general kernel takes the pair
                         bad = 1u;
                         done = true;
+                        hi_run = lo - 1;               // nothing more is computed or stored for it (its history pool is sized for admitted widths only)
                     }
+                    const int hw = hi_run - lo + 1;    // BACKTRACE: this score's row in the pool: hw cells
+                    uint2 *hrow = hpool + htop - lo;   // cell of diagonal k: hrow[k]
+                    if (BT) { h_off = htop; h_lo = lo; h_hi = hi_run; htop += (hw > 0 ? hw : 0); }
 #ifdef AIM_GROUP_COUNT_WIDTHS
                     dbg_wsum += hi - lo + 1; dbg_w32 += (hi - lo + 1) > 32; dbg_w64 += (hi - lo + 1) > 64;
 #endif
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     const int16_t *r_ie = islot(s_e < 0 ? 0 : s_e), *r_de = dslot(s_e < 0 ? 0 : s_e);
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
                     part = 0x7fffffff;
-                    for (int k = lo + g; k <= hi; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
+                    for (int k = lo + g; k <= hi_run; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
                         // The five source cells are fetched TOGETHER and unconditionally (every row is a valid LDS row of
                         // wcap = 2*MAX_SCORE+3 entries and |k +- 1| <= MAX_SCORE+1, so the addresses are always in bounds);
                         // AFFINE_WAVEFRONT_COND_FETCH's range / null tests then select. Guarded reads compiled to one
@@ -379,7 +410,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                             if (!i_out_null) {
                                 ins = v;
                                 oi[hk] = (int16_t)ins;
-                                if (BT) hI(score)[k] = (int16_t)ins;
                             }
                         }
                         int del = -10;
@@ -389,7 +419,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                             if (!d_out_null) {
                                 del = max(del_g, del_d);
                                 od[hk] = (int16_t)del;
-                                if (BT) hD(score)[k] = (int16_t)del;
                             }
                         }
                         int sub = -10;
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
                         const int ext = extend(k, (int)(int16_t)max(del, max(sub, ins)));
                         om[hk] = (int16_t)ext;
-                        if (BT) hM(score)[k] = (int16_t)ext;
+                        if (BT) hrow[k] = make_uint2((uint32_t)(uint16_t)ext | ((uint32_t)(uint16_t)ins << 16), (uint32_t)(uint16_t)del);   // I / D: -10 when absent (never selected)
                         part = min(part, max(plen - (ext - k), tlen - ext));
                     }
                 }
@@ -412,103 +441,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
             AIM_GSTAMP(4);   // descriptor store
         }
         AIM_GSTAMP(6);   // exit
-        int begin_offset = plen + tlen - 1, status = AIM_PAIR_OK;
-        if (BT) {
-            __syncthreads();   // the history stores of the whole wave have landed
-            if (active && g == 0 && bad == 0u && final_score <= MS) {
-                // affine_wavefronts_backtrace (wfa_backtracing.c:210-351) over the HBM history; ops row pre-filled with 'M'
-                char *ops = a.ops + (uint64_t)pair * 2 * rs;
-                const int cap = 2 * rs;
-                enum { BT_M = 0, BT_I = 1, BT_D = 2 };
-                auto put = [&](char ch) {
-                    if (begin_offset >= 0 && begin_offset < cap) ops[begin_offset] = ch;
-                    --begin_offset;
-                };
-                auto valid_loc = [&](int kk_, int off_) {
-                    const int v_ = off_ - kk_, h_ = off_;
-                    return v_ > 0 && v_ <= plen && h_ > 0 && h_ <= tlen;
-                };
-                int sc = final_score, k = ak;
-                int offset = hM(sc)[k];
-                bool valid = valid_loc(k, offset);
-                int bt = BT_M;
-                int v = offset - k, h = offset;
-                while (v > 0 && h > 0 && sc > 0) {
-                    if (!valid) {
-                        valid = valid_loc(k, offset);
-                        if (valid) {
-                            if (k < ak) for (int i = k; i < ak; ++i) put('I');
-                            else if (k > ak) for (int i = ak; i < k; ++i) put('D');
-                        }
-                    }
-                    const int s_o = sc - OE, s_e = sc - E, s_x = sc - X;
-                    // Every address of this step depends on (sc, k) only -- the descriptors decide validity, not location,
-                    // and each (score, diagonal) has a fixed home in the slab -- so the three descriptors and the five
-                    // candidate offsets are fetched together (one HBM round trip per step instead of a chain of guarded
-                    // loads); the range tests of the reference then select. A stale home is never selected.
-                    const int so_c = max(s_o, 0), se_c = max(s_e, 0), sx_c = max(s_x, 0);
-                    const int16_t *mo = hMeta(so_c), *me_ = hMeta(se_c), *mx = hMeta(sx_c);
-                    int o_lo = mo[0], o_hi = mo[1], o_f = mo[2], e_lo = me_[0], e_hi = me_[1], e_f = me_[2];
-                    int x_lo = mx[0], x_hi = mx[1], x_f = mx[2];
-                    const int v_de = hD(se_c)[k + 1], v_do = hM(so_c)[k + 1];
-                    const int v_ie = hI(se_c)[k - 1], v_io = hM(so_c)[k - 1], v_mx = hM(sx_c)[k];
-                    if (s_o < 0) { o_lo = 1; o_hi = -1; o_f = 0; }
-                    if (s_e < 0) { e_lo = 1; e_hi = -1; e_f = 0; }
-                    if (s_x < 0 || bt != BT_M) { x_lo = 1; x_hi = -1; x_f = 0; }
-                    int del_ext = kGrpNull, del_open = kGrpNull, ins_ext = kGrpNull, ins_open = kGrpNull, misms = kGrpNull;
-                    if (bt != BT_I) {
-                        if ((e_f & GF_PRESENT) && !(e_f & GF_DNULL) && e_lo <= k + 1 && k + 1 <= e_hi) del_ext = v_de;
-                        if ((o_f & GF_PRESENT) && o_lo <= k + 1 && k + 1 <= o_hi) del_open = v_do;
-                    }
-                    if (bt != BT_D) {
-                        if ((e_f & GF_PRESENT) && (e_f & GF_HASI) && e_lo <= k - 1 && k - 1 <= e_hi) ins_ext = (int16_t)(v_ie + 1);
-                        if ((o_f & GF_PRESENT) && o_lo <= k - 1 && k - 1 <= o_hi) ins_open = (int16_t)(v_io + 1);
-                    }
-                    if (bt == BT_M) {
-                        if ((x_f & GF_PRESENT) && x_lo <= k && k <= x_hi) misms = (int16_t)(v_mx + 1);
-                    }
-                    const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
-                    if (bt == BT_M) {
-                        const int num_matches = offset - max_all;
-                        if (num_matches > 0) begin_offset -= num_matches;
-                        offset = max_all;
-                        v = offset - k;
-                        h = offset;
-                        if (v <= 0 || h <= 0) break;
-                    }
-                    char op;
-                    if (max_all == del_ext) { op = 'D'; sc = s_e; ++k; bt = BT_D; }
-                    else if (max_all == del_open) { op = 'D'; sc = s_o; ++k; bt = BT_M; }
-                    else if (max_all == ins_ext) { op = 'I'; sc = s_e; --k; offset = (int16_t)(offset - 1); bt = BT_I; }
-                    else if (max_all == ins_open) { op = 'I'; sc = s_o; --k; offset = (int16_t)(offset - 1); bt = BT_M; }
-                    else if (max_all == misms) { op = 'X'; sc = s_x; offset = (int16_t)(offset - 1); }
-                    else { status = AIM_PAIR_WFA_NO_LINK; break; }
-                    if (valid) put(op);
-                    v = offset - k;
-                    h = offset;
-                }
-                if (status == AIM_PAIR_OK) {
-                    if (sc == 0) {
-                        if (offset > 0) begin_offset -= offset;
-                    } else {
-                        for (; v > 0; --v) put('D');
-                        for (; h > 0; --h) put('I');
-                    }
-                    ++begin_offset;
-                }
-            }
-        }
         if (active && g == 0) {
+            if (BT) {   // hand the pair to wfa_group_tb_kernel (walk = 0: the to-do list's kernel aligns it instead)
+                TbHead *hd = reinterpret_cast<TbHead *>(hreg);
+                hd->final_score = final_score;
+                hd->walk = bad == 0u ? 1 : 0;
+            }
             if (bad != 0u) {
                 const uint32_t slot = atomicAdd(&todo[LANE_TODO_COUNT], 1u);
-                todo[LANE_TODO_LIST + slot] = pair;
-            } else {
+                todo[LANE_TODO_LIST + slot] = pair + a.pair_base;
+            } else if (!BT) {
                 aim_result_t r;
                 r.max_operations = plen + tlen;
-                r.begin_offset = begin_offset;
+                r.begin_offset = plen + tlen - 1;
                 r.end_offset = plen + tlen;
                 r.score = final_score;
-                r.status = status;
+                r.status = AIM_PAIR_OK;
                 r.idx = rq.idx;
 #ifdef AIM_GROUP_COUNT_WIDTHS
                 r.max_operations = dbg_wsum; r.begin_offset = dbg_w32; r.end_offset = dbg_w64;
@@ -529,7 +477,168 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, GroupCfg *c, int *G, uint32_t *grid, size_t *lds, size_t *hist_bytes)
+// affine_wavefronts_backtrace (wfa_backtracing.c:210-351) as a kernel of its own: ONE PAIR PER LANE over the history regions
+// the compute kernel left in HBM. (Round 2 walked inside the compute kernel: one lane of a group walked while the others
+// idled, and the walk's registers held the CIGAR variants at 87-100 VGPRs.) Every address of a step depends on (score, k)
+// only: the three descriptors come back in one round trip, the five candidate offsets in a second, and the range tests of
+// the reference then select -- a cell outside its row is read at a clamped index and never selected. Output: result_t +
+// edit operations patched into the ops row the compute kernel pre-filled with 'M' (default ABI), or aim_cigar_t + runs
+// (RUNS: the compact CIGAR; runs are collected backwards in the pair's own run scratch and copied out forwards).
+struct OpsSink {
+    char *ops;
+    int cap, pos;
+    __device__ __forceinline__ void put(char ch) { if (pos >= 0 && pos < cap) ops[pos] = ch; --pos; }
+    __device__ __forceinline__ void matches(int n) { pos -= n; }
+};
+
+template <typename Sink>
+__device__ __forceinline__ int group_tb_walk(const TbRow *tab, const int16_t *pool, int final_score, int plen, int tlen, int X, int OE, int E, Sink &sink)
+{
+    enum { BT_M = 0, BT_I = 1, BT_D = 2 };
+    const int ak = tlen - plen;
+    int status = AIM_PAIR_OK;
+    auto valid_loc = [&](int kk_, int off_) {
+        const int v_ = off_ - kk_, h_ = off_;
+        return v_ > 0 && v_ <= plen && h_ > 0 && h_ <= tlen;
+    };
+    struct Row { int off, lo, w, klo, khi, f; };
+    auto row = [&](int s_) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(tab + s_);
+        Row r;
+        r.off = (int)q.x; r.lo = (int16_t)(q.y & 0xffffu); r.w = (int16_t)(q.y >> 16) - r.lo + 1;
+        r.klo = (int16_t)(q.z & 0xffffu); r.khi = (int16_t)(q.z >> 16); r.f = (int)(q.w & 0xffffu);
+        return r;
+    };
+    auto cell = [&](const Row &r, int which, int k_) -> int {   // which: 0 = M, 1 = I, 2 = D; clamped, selected by the caller's range test
+        const int w = r.w > 0 ? r.w : 1;
+        int i = k_ - r.lo;
+        i = i < 0 ? 0 : (i >= w ? w - 1 : i);
+        return pool[4 * (r.off + i) + which];   // cells are {M, I, D, -} int16
+    };
+    int sc = final_score, k = ak;
+    int offset;
+    {
+        const Row r0 = row(sc);
+        offset = cell(r0, 0, k);
+    }
+    bool valid = valid_loc(k, offset);
+    int bt = BT_M;
+    int v = offset - k, h = offset;
+    while (v > 0 && h > 0 && sc > 0) {
+        if (!valid) {
+            valid = valid_loc(k, offset);
+            if (valid) {   // add_trailing_gap, wfa_backtracing.c:48-69
+                if (k < ak) for (int i = k; i < ak; ++i) sink.put('I');
+                else if (k > ak) for (int i = ak; i < k; ++i) sink.put('D');
+            }
+        }
+        const int s_o = sc - OE, s_e = sc - E, s_x = sc - X;
+        const Row ro = row(max(s_o, 0)), re = row(max(s_e, 0)), rx = row(max(s_x, 0));
+        const int v_de = cell(re, 2, k + 1), v_do = cell(ro, 0, k + 1);
+        const int v_ie = cell(re, 1, k - 1), v_io = cell(ro, 0, k - 1), v_mx = cell(rx, 0, k);
+        int o_lo = ro.klo, o_hi = ro.khi, o_f = ro.f, e_lo = re.klo, e_hi = re.khi, e_f = re.f, x_lo = rx.klo, x_hi = rx.khi, x_f = rx.f;
+        if (s_o < 0) { o_lo = 1; o_hi = -1; o_f = 0; }
+        if (s_e < 0) { e_lo = 1; e_hi = -1; e_f = 0; }
+        if (s_x < 0 || bt != BT_M) { x_lo = 1; x_hi = -1; x_f = 0; }
+        int del_ext = kGrpNull, del_open = kGrpNull, ins_ext = kGrpNull, ins_open = kGrpNull, misms = kGrpNull;
+        if (bt != BT_I) {
+            if ((e_f & GF_PRESENT) && !(e_f & GF_DNULL) && e_lo <= k + 1 && k + 1 <= e_hi) del_ext = v_de;
+            if ((o_f & GF_PRESENT) && o_lo <= k + 1 && k + 1 <= o_hi) del_open = v_do;
+        }
+        if (bt != BT_D) {
+            if ((e_f & GF_PRESENT) && (e_f & GF_HASI) && e_lo <= k - 1 && k - 1 <= e_hi) ins_ext = (int16_t)(v_ie + 1);
+            if ((o_f & GF_PRESENT) && o_lo <= k - 1 && k - 1 <= o_hi) ins_open = (int16_t)(v_io + 1);
+        }
+        if (bt == BT_M) {
+            if ((x_f & GF_PRESENT) && x_lo <= k && k <= x_hi) misms = (int16_t)(v_mx + 1);
+        }
+        const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
+        if (bt == BT_M) {
+            const int num_matches = offset - max_all;
+            if (num_matches > 0) sink.matches(num_matches);
+            offset = max_all;
+            v = offset - k;
+            h = offset;
+            if (v <= 0 || h <= 0) break;
+        }
+        char op;
+        if (max_all == del_ext) { op = 'D'; sc = s_e; ++k; bt = BT_D; }
+        else if (max_all == del_open) { op = 'D'; sc = s_o; ++k; bt = BT_M; }
+        else if (max_all == ins_ext) { op = 'I'; sc = s_e; --k; offset = (int16_t)(offset - 1); bt = BT_I; }
+        else if (max_all == ins_open) { op = 'I'; sc = s_o; --k; offset = (int16_t)(offset - 1); bt = BT_M; }
+        else if (max_all == misms) { op = 'X'; sc = s_x; offset = (int16_t)(offset - 1); }
+        else { status = AIM_PAIR_WFA_NO_LINK; break; }
+        if (valid) sink.put(op);
+        v = offset - k;
+        h = offset;
+    }
+    if (status == AIM_PAIR_OK) {
+        if (sc == 0) {
+            if (offset > 0) sink.matches(offset);
+        } else {
+            for (; v > 0; --v) sink.put('D');
+            for (; h > 0; --h) sink.put('I');
+        }
+    }
+    return status;
+}
+
+template <bool RUNS>
+__global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
+{
+    const int lane = threadIdx.x;
+    const uint32_t pair = blockIdx.x * kWave + lane;
+    const bool in_batch = pair < a.n_pairs;
+    const int rs = a.p.read_size;
+    const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
+    char *hreg = a.scratch + a.scratch_per_wave + (size_t)(in_batch ? pair : 0u) * (size_t)c.hist_pair_bytes;
+    const TbHead hd = *reinterpret_cast<const TbHead *>(hreg);
+    const bool active = in_batch && hd.walk == 1;        // pairs on the to-do list belong to the general kernel
+    const TbRow *tab = reinterpret_cast<const TbRow *>(hreg + sizeof(TbHead));
+    const int16_t *pool = reinterpret_cast<const int16_t *>(hreg + c.pool_off);
+    aim_request_t rq;
+    rq.pattern_len = rq.text_len = 0; rq.padding = 0; rq.idx = 0;
+    if (active) rq = load_request(a, pair);
+    const int plen = rq.pattern_len, tlen = rq.text_len;
+    const int final_score = hd.final_score;
+    const bool walk = active && final_score <= MS;      // beyond MAX_SCORE the reference returns without a backtrace (wfa.c:368-376, MRAM variant)
+    int status = AIM_PAIR_OK;
+    if constexpr (RUNS) {
+        RunCollector<1> coll(plen + tlen - 1, reinterpret_cast<uint32_t *>(hreg + c.runs_off), c.runs_cap);
+        if (walk) status = group_tb_walk(tab, pool, final_score, plen, tlen, X, OE, E, coll);
+        coll.flush();
+        if (coll.n == 0) {   // nothing inside [0, end): edit_cigar_print still prints operations[begin_offset] = 'M'
+            coll.cur_op = (uint32_t)'M'; coll.cur_len = 1u;
+            coll.flush();
+        }
+        store_cigar(a, pair, active, rq.idx, final_score, status, coll, 0u, lane);
+    } else {
+        OpsSink sink;
+        sink.ops = a.ops + (uint64_t)(active ? pair : 0u) * 2 * rs;
+        sink.cap = 2 * rs;
+        sink.pos = plen + tlen - 1;                       // edit_cigar_allocate, wfa.c:57-67
+        if (walk) {
+            status = group_tb_walk(tab, pool, final_score, plen, tlen, X, OE, E, sink);
+            if (status == AIM_PAIR_OK) ++sink.pos;
+        }
+        if (active) {
+            aim_result_t r;
+            r.max_operations = plen + tlen;
+            r.begin_offset = sink.pos;
+            r.end_offset = plen + tlen;
+            r.score = final_score;
+            r.status = status;
+            r.idx = rq.idx;
+            store_result(a, pair, r);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hist_pair_bytes: bytes of ONE pair's history region (BACKTRACE; 0 otherwise) -- the caller sizes launches (chunks of pairs)
+// so that their regions fit its scratch bound. packed: the batch arrives packed (no staging rows in LDS).
+inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, bool packed, GroupCfg *c, int *G, uint32_t *grid, size_t *lds,
+                           size_t *hist_pair_bytes)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
     if (p.read_size > 2048 || p.max_score > 400) return false;
@@ -581,7 +690,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
         // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s, each plan at its real LDS fit): 3 per CU
         // 1.56x (l=1000 e=5%), 4 per CU 1.55x (l=400 e=10%); 6 per CU 1.07x / 0.91x / 0.79x; 11 per CU 0.57x; 16 per CU
         // 0.48x. 5 per CU is not measured.
-        const size_t stage = g >= AIM_GROUP_DIRECT_G ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;   // G >= 32 packs from global memory
+        const size_t stage = (g >= AIM_GROUP_DIRECT_G || packed) ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;   // G >= 32 packs from global memory
         const size_t wg = stage + (size_t)(kWave / g) * dw * 4 + 64;
         if (lds_workgroups_per_cu(wg) < 6 && (size_t)dw * 4 <= 48 * 1024) g = 64;
     }
@@ -591,7 +700,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     }
     *G = g;
     c->rows_per_wave = kWave / g;
-    const size_t rows_bytes = g >= AIM_GROUP_DIRECT_G ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
+    const size_t rows_bytes = (g >= AIM_GROUP_DIRECT_G || packed) ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;
     *lds = rows_bytes + (size_t)(kWave / g) * dw * 4 + 64;
     if (*lds > 64 * 1024) return false;   // beyond the dynamic-LDS limit of a plain launch (only a forced AIM_GROUP_G gets here)
     const size_t lds_fit = lds_workgroups_per_cu(*lds);
@@ -603,7 +712,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     // e = 10 % 18 -> 16 per CU 3.96 -> 3.89 ms, l = 150 e = 2 % 21 -> 20 1.174 -> 1.089 ms); the score-only variants (<= 68 VGPRs, 7
     // wavefronts per SIMD) may use 24 (cfg3 score-only 20 / 22 / 24 / 25 per CU: 3.32 / 3.25 / 3.18 / 3.67 ms), the CIGAR
     // variants are register-bound at 5 per SIMD.
-    const size_t cap_per_cu = (p.flags & AIM_FLAG_BACKTRACE) ? AIM_GROUP_MAX_PER_CU : AIM_GROUP_MAX_PER_CU + 4;
+    const size_t cap_per_cu = (p.flags & AIM_FLAG_BACKTRACE) ? AIM_GROUP_MAX_PER_CU : AIM_GROUP_MAX_PER_CU + 4;   // CIGAR variants: 82-96 VGPRs (history addressing) = 5 per SIMD
     uint32_t per_cu = (uint32_t)std::min<size_t>(cap_per_cu, lds_fit);
     if (per_cu > 16) per_cu &= ~3u;
     if (kn.group_per_cu >= 0) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.group_per_cu), lds_fit);   // residency sweeps
@@ -615,9 +724,29 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     if (kn.plan_debug)
         fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u wlds=%d\n", g, ring_m, ring_e,
                 c->wcap, dw * 4, *lds, lds_fit, per_cu, gr, c->wlds);
-    c->hist_stride = (p.max_score + 2) * (3 * c->wcap + 4);
-    *hist_bytes = (p.flags & AIM_FLAG_BACKTRACE) ? (((size_t)gr * (kWave / g) * c->hist_stride * 2 + 255) & ~(size_t)255) : 0;
+    // BACKTRACE: the per-pair history region (GroupCfg). The pool holds, per score, the 3 * width cells the compute kernel
+    // stores; a wavefront is at most 2s+1 diagonals wide and at most what the LDS row admits (a pair beyond that leaves for
+    // the to-do list before anything of the offending score is stored).
+    {
+        const int wmax = c->wlds == c->wcap ? c->wcap : c->wlds - 2;
+        uint64_t cells = 0;
+        for (int sc = 0; sc <= p.max_score + 1; ++sc) cells += (uint64_t)std::min(2 * sc + 1, wmax);
+        c->pool_off = (int)(sizeof(TbHead) + (size_t)(p.max_score + 2) * sizeof(TbRow));
+        c->pool_cap = (int)cells + 2;                         // cells of 8 bytes {M, I, D, -}
+        c->runs_off = (c->pool_off + c->pool_cap * 8 + 15) & ~15;
+        c->runs_cap = 2 * p.max_score + 16;
+        c->hist_pair_bytes = (c->runs_off + c->runs_cap * 4 + 255) & ~255;
+    }
+    *hist_pair_bytes = (p.flags & AIM_FLAG_BACKTRACE) ? (size_t)c->hist_pair_bytes : 0;
     return true;
+}
+
+inline void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pairs, const KArgs &ka, hipStream_t s)
+{
+    (void)p;
+    const uint32_t grid = (n_pairs + kWave - 1) / kWave;
+    if (ka.cig) hipLaunchKernelGGL((wfa_group_tb_kernel<true>), dim3(grid), dim3(kWave), 0, s, ka, c);
+    else hipLaunchKernelGGL((wfa_group_tb_kernel<false>), dim3(grid), dim3(kWave), 0, s, ka, c);
 }
 
 inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)

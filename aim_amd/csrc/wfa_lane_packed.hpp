@@ -209,20 +209,21 @@ __device__ __forceinline__ int wfa_backtrace_static(const int (&Mv)[MAXS + 1][KW
 // counting down from plen + tlen - 1); an operation that would land below position 0 is dropped, exactly like the bounds
 // test of the ops-row kernels and cigar_rle_kernel's clamp of begin_offset to 0. Adjacent operations of one kind merge into
 // a run. The four most recent runs sit in registers as a shift register -- r0 is the newest, i.e. the FIRST run of the
-// printed CIGAR -- older ones spill to a lane-interleaved LDS column (spill[i * 64 + lane]: conflict-free); a short-read
-// alignment with one edit never touches LDS.
-template <int SPILL>
+// printed CIGAR -- older ones spill to a lane-interleaved LDS column (spill[i * 64 + lane]: conflict-free; wfa_group's traceback kernel
+// spills to a private HBM array instead); a short-read alignment with one edit never touches the spill area.
+template <int STRIDE>
 struct RunCollector {
     uint32_t r0 = 0u, r1 = 0u, r2 = 0u, r3 = 0u;   // scalars, not an array: a select chain over array elements becomes a dynamic index (scratch)
     uint32_t cur_op = 0u, cur_len = 0u;
     int n = 0;          // completed runs
     int pos;            // begin_offset
-    uint32_t *spill;    // this lane's column: spill[i * kWave]
-    __device__ __forceinline__ RunCollector(int begin_offset, uint32_t *lane_spill) : pos(begin_offset), spill(lane_spill) {}
+    uint32_t *spill;    // this lane's spill area: spill[i * STRIDE] (STRIDE = 64: lane-interleaved LDS column; 1: a private HBM array)
+    int spill_cap;      // entries of it
+    __device__ __forceinline__ RunCollector(int begin_offset, uint32_t *lane_spill, int cap) : pos(begin_offset), spill(lane_spill), spill_cap(cap) {}
     __device__ __forceinline__ void flush()
     {
         if (cur_len == 0u) return;
-        if (n >= 4 && n - 4 < SPILL) spill[(n - 4) * kWave] = r3;
+        if (n >= 4 && n - 4 < spill_cap) spill[(n - 4) * STRIDE] = r3;
         r3 = r2; r2 = r1; r1 = r0;
         r0 = (cur_len << 8) | cur_op;
         ++n;
@@ -239,8 +240,8 @@ struct RunCollector {
     __device__ __forceinline__ void put(char ch) { emit((uint32_t)(unsigned char)ch, 1); }
     __device__ __forceinline__ void matches(int len) { emit((uint32_t)'M', len); }
     // runs 0 .. 3 of the printed CIGAR are r0 .. r3; run i >= 4 (after the last flush()):
-    __device__ __forceinline__ uint32_t spilled_run(int i) const { return spill[(n - 1 - i) * kWave]; }
-    __device__ __forceinline__ bool overflowed() const { return n - 4 > SPILL; }
+    __device__ __forceinline__ uint32_t spilled_run(int i) const { return spill[(n - 1 - i) * STRIDE]; }
+    __device__ __forceinline__ bool overflowed() const { return n - 4 > spill_cap; }
 };
 
 constexpr int kLaneRunSpill = 12;   // LDS-spilled runs per lane beyond the four in registers (3 KiB per wavefront)
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(64, DYN ? 2 : 1) void wfa_lane_packed_kernel(KArgs 
         }
         if constexpr (BT) {
             uint32_t *spill = reinterpret_cast<uint32_t *>(smem) + lane;
-            RunCollector<kLaneRunSpill> coll(plen + tlen - 1, spill);   // edit_cigar_allocate, wfa.c:57-67
+            RunCollector<kWave> coll(plen + tlen - 1, spill, kLaneRunSpill);   // edit_cigar_allocate, wfa.c:57-67
             int status = AIM_PAIR_OK;
             if (active && done) status = wfa_backtrace_static<X, O, E, MAXS, KW>(Mv, Iv, Dv, score, plen, tlen, coll);
             coll.flush();

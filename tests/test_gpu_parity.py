@@ -794,8 +794,11 @@ def test_packed_input_and_compact_cigar_match_default_path(gpu, algo, l, err, n,
                 assert np.array_equal(out["cig"]["status"], base_res["status"].astype(np.uint16))
                 if want is not None:
                     assert engine.format_output_runs(out["cig"], out["runs"]) == want
-                if s.plan_describe(0).startswith("wfa_lane_packed_kernel"):   # slotted run buffer: 4 runs per pair, longer CIGARs behind
+                plan = s.plan_describe(0)
+                if plan.startswith("wfa_lane_packed_kernel"):   # slotted run buffer: 4 runs per pair, longer CIGARs behind
                     assert len(out["runs"]) >= 4 * n and len(out["runs"]) >= int(out["cig"]["n_runs"].sum())
+                elif "packed_in=1 runs_out=1" in plan:          # fused group path: the void runs of the side list's pairs stay behind as holes
+                    assert len(out["runs"]) >= int(out["cig"]["n_runs"].sum())
                 else:
                     assert int(out["cig"]["n_runs"].sum()) == len(out["runs"])
 
@@ -1126,3 +1129,56 @@ def test_fused_packed_dynamic_bounds_shape_against_oracle(gpu):
                 ores, _ = _oracle_text("wfa", params, req, pat, txt)
                 out, _ = _fused(params, req, pat, txt)
                 assert np.array_equal(out["res"]["score"], ores["score"]), (l, rs, ms, err, reduce)
+
+
+GROUP_FUSED = [(100, 0.05, 3000, dict()), (100, 0.10, 2000, dict()), (150, 0.02, 3000, dict()), (250, 0.05, 1000, dict()),
+               (1000, 0.05, 300, dict()), (100, 0.05, 2000, dict(mismatch=4, gap_o=6, gap_e=2))]
+
+
+@pytest.mark.parametrize("l,err,n,cost", GROUP_FUSED)
+@pytest.mark.parametrize("bt", [False, True])
+def test_fused_group_kernel_against_oracle(gpu, l, err, n, cost, bt):
+    """wfa_group_kernel on a packed batch (it copies the 2-bit rows into its LDS image itself) and, with BACKTRACE, the compact
+    CIGAR straight from wfa_group_tb_kernel -- against the oracle, incl. non-ACGT pairs (raw side pass)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("wfa", l, err, **cost)
+    req, pat, txt = engine.gen_pairs(31 + l, 0, n, l, err, rs)
+    for i in range(0, n, 13):
+        pat[i, i % (l // 2)] = ord("N")
+    for reduce in (True, False):
+        params = engine.make_params("wfa", ms, rs, backtrace=bt, reduce=reduce, req8=True, res8=not bt, **cost)
+        ores, want = _oracle_text("wfa", params, req, pat, txt)
+        out, plan = _fused(params, req, pat, txt, runs_cap=n * (2 * ms + 8), expect_kernel="wfa_group_kernel")
+        assert "packed_in=1" in plan and ("runs_out=%d" % int(bt)) in plan, plan
+        if bt:
+            assert np.array_equal(out["cig"]["score"], ores["score"]) and (out["cig"]["status"] == 0).all()
+            assert engine.format_output_runs(out["cig"], out["runs"]) == want
+            assert len(out["runs"]) >= int(out["cig"]["n_runs"].sum())    # (holes: the void runs the packed kernel wrote for the side list's pairs)
+        else:
+            assert np.array_equal(out["res"]["score"], ores["score"])
+
+
+@pytest.mark.parametrize("env", [dict(AIM_GROUP_WLDS="64"), dict(AIM_SCRATCH_GB="2"), dict(AIM_GROUP_G="64"), dict(AIM_GROUP_G="2")])
+def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
+    """The side roads of the fused group path: a narrow LDS window that pairs outgrow (they reach the general kernel through the
+    to-do list: their packed rows are expanded for it and its ops rows are run-length encoded afterwards), a scratch bound that
+    splits the batch into several compute + traceback launches, and forced lanes-per-pair plans -- default ABI and fused I/O."""
+    from aim_amd import engine
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    l, err, n = 1000, 0.05, (5000 if "AIM_SCRATCH_GB" in env else 1500)   # 5000 history regions of 228 KB do not fit half of 2 GB
+    ms, rs = engine.launcher_sizes("wfa", l, err)
+    req, pat, txt = engine.gen_pairs(17, 0, n, l, err, rs)
+    pat[5, 17] = ord("N")
+    for bt in (True, False):
+        params = engine.make_params("wfa", ms, rs, backtrace=bt, reduce=True)
+        ores, want = _oracle_text("wfa", params, req, pat, txt)
+        out, plan = _fused(params, req, pat, txt, runs_cap=n * (2 * ms + 8), expect_kernel="wfa_group_kernel")
+        if "AIM_SCRATCH_GB" in env and bt:
+            chunk = int(plan.split("chunk=")[1].split()[0])
+            assert chunk < n, plan                                          # the batch really ran in several chunks
+        if bt:
+            assert engine.format_output_runs(out["cig"], out["runs"]) == want
+        else:
+            assert np.array_equal(out["res"]["score"], ores["score"])
+        _compare("wfa", params, req, pat, txt)                              # default ABI (ASCII rows in, result_t + ops rows out)
