@@ -23,6 +23,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12    # 256 CUs x 64 lanes per clock x 2.4 GHz = 39.3 T 32-bit lane-operations / s
+ISSUE_PEAK_GINSTR = 1024 * 2.4e9 / 1e9          # 1 024 SIMDs x one wavefront instruction per clock = 2 458 G instructions / s
+
+# BASELINE.json configs[1..4]. The N = 1 contract line is cfg2 (the configuration the metric is quoted on); the others run the
+# same harness (same static split, same barrier / max-over-ranks timing) so that a multi-GPU run can cover "SWG ... sharded across
+# 8 MI355X" and "GenASM ... 8 MI355X". Each names the roof that bounds ITS kernel: cfg2 streams (HBM), cfg4 is bound by the
+# integer vector rate (lane-operations per DP cell), cfg3 and cfg5 by instruction issue of latency-bound wavefronts.
+CONFIGS = {
+    "cfg2": dict(algo="wfa", l=100, e=0.01, n=1 << 22, bt=False, reduce=True, bound="hbm", pmc="wfa_lane",
+                 name="WFA-adaptive score-only l=100 e=1%"),
+    "cfg3": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, bt=True, reduce=True, bound="issue", pmc="wfa_group",
+                 name="WFA-adaptive with CIGAR l=1000 e=5%"),
+    "cfg4": dict(algo="swg", l=10000, e=0.01, n=128, bt=True, reduce=False, bound="valu", pmc="dp_wave",
+                 name="SWG affine-gap with CIGAR l=10000 e=1%"),
+    "cfg5": dict(algo="genasm", l=100000, e=0.10, n=1024, bt=True, reduce=False, bound="issue", pmc="genasm_wave",
+                 name="GenASM bit-vector edit distance with CIGAR l=100000 e=10% (parity unpinned)"),
+}
+
+
+def pmc_instructions(tag, pairs=None):
+    """Instruction counts per pair of a config's kernel from the newest committed PMC summary (profiles/rNN/<tag>_pmc_summary.json):
+    (VALU wave-instructions per pair, all wave-instructions per pair, source file). The counts are a property of the code and
+    the data, not of the run; the rate they are multiplied with is measured live."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", tag + "_pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+            raw, n = d["raw"], d["pairs_per_launch"]
+            valu = raw["SQ_INSTS_VALU"]["per_launch_mean"] / n
+            allk = sum(raw[k]["per_launch_mean"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
+                                                             "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH") if k in raw) / n
+            best = (valu, allk, os.path.relpath(f, ROOT))
+        except Exception:
+            continue
+    return best
 
 
 def pmc_traffic(kernel, pairs, io):
@@ -114,9 +150,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1 << 22, help="pairs per GPU (BASELINE: 4M)")
-    ap.add_argument("--length", type=int, default=100)
-    ap.add_argument("--error", type=float, default=0.01)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="BASELINE.json configuration (default and contract line: cfg2)")
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (default: the configuration's; cfg2 = 4M)")
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--error", type=float, default=None)
     ap.add_argument("--backtrace", action="store_true", help="also produce CIGAR ops (not the headline config)")
     ap.add_argument("--io", choices=["compact", "default"], default="compact",
                     help="wire layout of requests/results: 'compact' = the reference's own 8-B WFA request_t + 8-B {idx, score} "
@@ -157,11 +194,21 @@ def main():
     from aim_amd import capi, engine, shard
     lib = capi.load()
 
+    cfg = CONFIGS[args.config]
+    algo = cfg["algo"]
+    args.pairs = args.pairs if args.pairs is not None else cfg["n"]
+    args.length = args.length if args.length is not None else cfg["l"]
+    args.error = args.error if args.error is not None else cfg["e"]
+    args.backtrace = args.backtrace or cfg["bt"]
+    headline = args.config == "cfg2"
     n = args.pairs
-    ms, rs = engine.launcher_sizes("wfa", args.length, args.error)
-    compact = args.io == "compact"
+    if algo == "genasm":   # no penalties, no score cap: MAX_SCORE is ignored; READ_SIZE by the launchers' rule
+        ms, rs = 0, int(np.ceil((args.length + args.length * args.error + 7) / 8)) * 8
+    else:
+        ms, rs = engine.launcher_sizes(algo, args.length, args.error)
+    compact = args.io == "compact" and headline
     req8, res8 = compact, compact and not args.backtrace
-    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=args.backtrace, req8=req8, res8=res8)
+    params = engine.make_params(algo, ms, rs, reduce=cfg["reduce"], backtrace=args.backtrace, req8=req8, res8=res8)
     res_dtype = capi.RESULT8_DTYPE if res8 else capi.RESULT_DTYPE
     # static contiguous split: rank r owns global pairs [r*n, (r+1)*n)  (host.c:191-209)
     req, pat, txt = engine.gen_pairs(42, shard.weak_first_index(n, rank), n, args.length, args.error, rs)
@@ -222,8 +269,8 @@ def main():
 
     # correctness of what was timed: re-check a bounded prefix against the CPU oracle (checker only)
     from oracle import oracle
-    nv = min(n, args.verify_pairs)
-    op = oracle.params("wfa", ms, rs, reduce=True, backtrace=False)
+    nv = min(n, args.verify_pairs, max(8, int(2e9 // max(1, (args.length * args.length if algo != "wfa" else args.length * 200)))))
+    op = oracle.params(algo, ms, rs, reduce=cfg["reduce"], backtrace=False)
     ores, _, worst = oracle.align_batch(op, req["pattern_len"][:nv], req["text_len"][:nv], pat[:nv], txt[:nv],
                                         nthreads=os.cpu_count() or 1)
     verified = bool(worst == 0 and np.array_equal(ores["score"], res_host["score"][:nv])
@@ -237,17 +284,19 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         passes, spent = 0, 0.0
+        nb = n if headline else min(n, max(cores, nv))      # long-read configs: a bounded sample of the batch (one pair per thread at least)
         while spent < 3.0 and passes < 64:
             c0 = time.perf_counter()
-            oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=cores)
+            oracle.align_batch(op, req["pattern_len"][:nb], req["text_len"][:nb], pat[:nb], txt[:nb], nthreads=cores)
             spent += time.perf_counter() - c0
             passes += 1
-        cpu_baseline = {"value": passes * n / spent, "unit": "pairs/s", "cores": cores, "kind": "port",
-                        "sample": "%d passes over the same %d-pair batch, %d threads, %.1f s wall (oracle/aim_oracle.c)"
-                                  % (passes, n, cores, spent)}
+        cpu_baseline = {"value": passes * nb / spent, "unit": "pairs/s", "cores": cores, "kind": "port",
+                        "sample": "%d passes over %s %d pairs of the batch, %d threads, %.1f s wall (oracle/%s, score-only)"
+                                  % (passes, "the same" if nb == n else "the first", nb, cores, spent,
+                                     "genasm_oracle.c" if algo == "genasm" else "aim_oracle.c")}
 
     e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if rank == 0 and world == 1 and not args.no_e2e and headline:
         ne = min(n, 1 << 22)
         e2e = {"packed": e2e_leg(lib, capi, engine, local_rank, ms, rs, req[:ne], pat[:ne], txt[:ne], 8, True, args.backtrace),
                "ascii": e2e_leg(lib, capi, engine, local_rank, ms, rs, req[:ne], pat[:ne], txt[:ne], 4, False, args.backtrace),
@@ -262,14 +311,37 @@ def main():
         kname = lib.aim_kernel_name(C.byref(params)).decode()
         plan_buf = C.create_string_buffer(512)
         capi.check(lib.aim_plan_describe(C.byref(params), n, plan_buf, len(plan_buf)))
-        traffic = pmc_traffic(kname, n, args.io) if not args.backtrace else None
+        traffic = pmc_traffic(kname, n, args.io) if (headline and not args.backtrace) else None
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                    "traffic_unit": "bytes/launch", "traffic_source": traffic[1] if traffic else None,
+                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_pair": alg_bytes / n}
+        if cfg["bound"] != "hbm":
+            # not an HBM-bound kernel: price it against the roof that does bound it. Instruction counts per pair come from the
+            # committed PMC summary of this kernel (a property of code + data); the pair rate is this run's.
+            ins = pmc_instructions(cfg["pmc"])
+            rate = n / (kernel_ms * 1e-3)                      # pairs / s of one GPU's kernel
+            hbm = {k: roofline[k] for k in ("achieved", "frac", "algorithmic_bytes_per_pair")}
+            if cfg["bound"] == "valu":
+                ops_per_cell = ins[0] * 64.0 / (cells / n) if ins else None
+                ach = rate * ins[0] * 64.0 / 1e12 if ins else None
+                roofline = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                            "frac": ach / VALU_PEAK_TLANEOPS if ins else None, "lane_ops_per_cell": ops_per_cell,
+                            "instruction_source": ins[2] if ins else None, "traffic": None, "hbm_view": hbm}
+            else:
+                ach = rate * ins[1] / 1e9 if ins else None
+                roofline = {"bound": "issue", "achieved": ach, "peak": ISSUE_PEAK_GINSTR, "unit": "G wavefront-instructions/s",
+                            "frac": ach / ISSUE_PEAK_GINSTR if ins else None, "instructions_per_pair": ins[1] if ins else None,
+                            "instruction_source": ins[2] if ins else None, "traffic": None, "hbm_view": hbm}
         line = {
-            "metric": "aligned pairs/sec WFA-adaptive l=%d e=%g%%" % (args.length, args.error * 100),
+            "metric": ("aligned pairs/sec WFA-adaptive l=%d e=%g%%" % (args.length, args.error * 100)) if headline else
+                      ("aligned pairs/sec %s" % cfg["name"]),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
-            "config": {"workload": "WFA-adaptive %s l=%d e=%g%% %d synthetic pairs per GPU (MAX_SCORE %d, READ_SIZE %d)"
-                                   % ("with CIGAR" if args.backtrace else "score-only", args.length, args.error * 100, n, ms, rs),
+            "config": {"workload": ("WFA-adaptive %s l=%d e=%g%% %d synthetic pairs per GPU (MAX_SCORE %d, READ_SIZE %d)"
+                                    % ("with CIGAR" if args.backtrace else "score-only", args.length, args.error * 100, n, ms, rs)) if headline else
+                                   ("%s: %s, %d synthetic pairs per GPU (MAX_SCORE %d, READ_SIZE %d)" % (args.config, cfg["name"], n, ms, rs)),
                        "pairs_per_gpu": n, "parallelism": "pairs sharded statically, %d rank(s)" % world,
                        "kernel": kname, "plan": plan_buf.value.decode(),
                        "io": ("compact: 8-B WFA request_t (common.h:172-177) + 8-B {idx, score} results" if res8 else
@@ -277,10 +349,7 @@ def main():
                        "wire_bytes_per_pair": 2 * rs + (8 if req8 else 16) + (8 if res8 else 24) + (2 * rs if args.backtrace else 0)},
             "gcups": value * (cells / n) / 1e9,
             "kernel_ms": kernel_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_unit": "bytes/launch", "traffic_source": traffic[1] if traffic else None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_pair": alg_bytes / n},
+            "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "e2e": e2e,
             "gather_ms": gather_ms,

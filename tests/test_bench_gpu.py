@@ -53,3 +53,22 @@ def test_bench_two_ranks_control_flow(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                        timeout=300, cwd=ROOT)
     assert r.returncode == 2
+
+
+def test_bench_other_baseline_configs_run_through_the_same_harness(built):
+    """`bench.py --config cfg3 | cfg4 | cfg5`: the other BASELINE configurations through the same static split / timing / one-line
+    contract, each priced against the roof that bounds its kernel; cfg3 also under two ranks."""
+    for cfg, pairs, bound in (("cfg3", "4096", "issue"), ("cfg4", "16", "valu"), ("cfg5", "64", "issue")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--pairs", pairs, "--steps", "2", "--warmup", "1",
+                            "--length", {"cfg3": "1000", "cfg4": "2000", "cfg5": "5000"}[cfg]], capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (cfg, r.stderr[-2000:])
+        d = _last_json(r.stdout)
+        assert d["verified_vs_oracle"] is True and d["value"] > 0 and d["roofline"]["bound"] == bound and cfg in d["config"]["workload"]
+        assert d["cpu_baseline"]["value"] > 0
+    env = dict(os.environ, AIM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29732", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3", "--pairs", "2048", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["verified_vs_oracle"] is True and d["roofline"]["bound"] == "issue" and d["gather_ms"] is not None
