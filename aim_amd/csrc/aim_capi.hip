@@ -77,6 +77,8 @@ struct Plan {
     uint32_t chunk_pairs;   // K_WFA_GROUP + BACKTRACE: pairs per compute + traceback launch (their history regions fit the scratch bound)
     aim::GroupCfg gcfg;     // K_WFA_GROUP
     int group_g;
+    bool pack_first;        // K_WFA_LANE_PK on a batch of ASCII rows: pack_rows_kernel first (scratch: to-do | flag bits | packed P | packed T | general kernel)
+    size_t pack_bytes;      // ... bytes of the flag bits + both packed arrays
     bool pk;                // the kernel reads the packed rows of the batch itself (no unpack pass)
     bool emits_runs;        // the kernel writes aim_cigar_t + runs itself (no ops rows, no cigar_rle_kernel)
 };
@@ -190,13 +192,13 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         return AIM_OK;
     }
     if (p.algo == AIM_ALGO_WFA && (mode & MODE_PACKED_IN) && !kn.force_wave && !kn.no_lane_pk && !pl->no_lane &&
-        aim::wfa_lane_packed_supported(p, !kn.no_lane_ext) && (!bt || (mode & MODE_RUNS_OUT))) {
-        // packed rows in, {idx, score} or compact CIGAR out: one kernel per batch, no scratch (wfa_lane_packed.hpp)
+        aim::wfa_lane_packed_supported(p, !kn.no_lane_ext)) {
+        // packed rows in; {idx, score}, compact CIGAR or result_t + ops rows out: one kernel per batch, no scratch (wfa_lane_packed.hpp)
         pl->kid = K_WFA_LANE_PK;
         aim::wfa_lane_packed_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
         pl->scratch_total = 256;
         pl->pk = true;
-        pl->emits_runs = bt;
+        pl->emits_runs = bt && (mode & MODE_RUNS_OUT);
         return AIM_OK;
     }
     if (p.algo == AIM_ALGO_WFA) {
@@ -228,6 +230,29 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
 #if AIM_LANE_STAMPS
             pl->scratch_total += (size_t)pl->grid * 64;   // diagnostic builds park their s_memtime sums behind the first 256 bytes
 #endif
+            return AIM_OK;
+        }
+        if (!lane_ok && !kn.force_wave && !kn.no_lane_pk && !pl->no_lane && aim::wfa_lane_packed_supported(p, !kn.no_lane_ext)) {
+            // ASCII rows of a shape only the packed lane kernel takes (READ_SIZE other than 80 / 112: l = 150 and friends; CIGAR at
+            // MAX_SCORE 6..10): pack on the device (batch_io.hpp), run the packed kernel, let the general kernel re-align the
+            // non-ACGT pairs (to-do list)
+            Plan fb;
+            memset(&fb, 0, sizeof fb);
+            fb.no_lane = true;
+            aim::Knobs kq = kn;
+            kq.no_group = true;
+            rc = make_plan_inner(p, std::min<uint32_t>(n_pairs, 1024u * 64u), kq, budget, 0u, &fb);
+            if (rc) return rc;
+            *pl = fb;
+            pl->fb_grid = fb.grid;
+            pl->fb_lds = fb.lds;
+            pl->kid = K_WFA_LANE_PK;
+            aim::wfa_lane_packed_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+            pl->pack_first = true;
+            pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
+            const size_t npw = aim::packed_row_dwords(p.read_size);
+            pl->pack_bytes = ((((size_t)n_pairs + 31) / 32 * 4 + 255) & ~(size_t)255) + 2 * ((((size_t)n_pairs * npw * 4) + 64 + 255) & ~(size_t)255);
+            pl->scratch_total = pl->todo_bytes + pl->pack_bytes + fb.scratch_total;
             return AIM_OK;
         }
         if (group_ok) {
@@ -349,6 +374,7 @@ int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint6
 {
     char extra[160] = "";
     if (pl.kid == K_WFA_GROUP) snprintf(extra, sizeof extra, " G=%d hist=%zu chunk=%u fb_grid=%u packed_in=%d runs_out=%d", pl.group_g, pl.hist_bytes, pl.chunk_pairs, pl.fb_grid, (int)pl.pk, (int)pl.emits_runs);
+    else if (pl.kid == K_WFA_LANE_PK) snprintf(extra, sizeof extra, " pack_first=%d fb_grid=%u", (int)pl.pack_first, pl.fb_grid);
     else if (pl.kid == K_DP_WAVE) snprintf(extra, sizeof extra, " wavefronts_per_pair=%u", pl.block / 64);
     else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
     else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
@@ -395,11 +421,12 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     if (n_pairs == 0) return AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const bool red = p.flags & AIM_FLAG_REDUCE;
-    if (pl.pk && (!fio || !fio->packedP || !fio->packedT)) return fail(AIM_EINVAL, "plan reads packed rows but none were given");
+    if (pl.pk && !pl.pack_first && (!fio || !fio->packedP || !fio->packedT)) return fail(AIM_EINVAL, "plan reads packed rows but none were given");
     if (pl.emits_runs && (!fio || !fio->cig || !fio->runs || !fio->cursor)) return fail(AIM_EINVAL, "plan emits the compact CIGAR but no buffers were given");
-    const bool lane_pk = pl.kid == K_WFA_LANE_PK;   // the only plan that never touches ASCII rows, result_t or ops rows
-    if (!d_req || (!lane_pk && (!d_pat || !d_txt)) || (!(lane_pk && pl.emits_runs) && !d_res)) return fail(AIM_EINVAL, "null device buffer");
-    if (bt && !(lane_pk && pl.emits_runs) && !d_ops) return fail(AIM_EINVAL, "AIM_FLAG_BACKTRACE needs an ops buffer");
+    const bool reads_ascii = !(pl.kid == K_WFA_LANE_PK && !pl.pack_first);   // (wfa_group reads them for its to-do pairs even on packed batches)
+    const bool writes_res = !(pl.kid == K_WFA_LANE_PK && pl.emits_runs);
+    if (!d_req || (reads_ascii && (!d_pat || !d_txt)) || (writes_res && !d_res)) return fail(AIM_EINVAL, "null device buffer");
+    if (bt && writes_res && !d_ops) return fail(AIM_EINVAL, "AIM_FLAG_BACKTRACE needs an ops buffer");
     if (scratch_bytes < pl.scratch_total || (!d_scratch && pl.scratch_total))
         return fail(AIM_EINVAL, "scratch too small: need %zu bytes, got %zu", pl.scratch_total, scratch_bytes);
     aim::KArgs ka;
@@ -438,6 +465,38 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         aim::wfa_lane_launch(p, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_WFA_LANE_PK:
+        if (pl.pack_first) {
+            // [to-do | flag bits | packed P | packed T | general kernel scratch]
+            const size_t npw = aim::packed_row_dwords(p.read_size);
+            const size_t flag_b = (((size_t)n_pairs + 31) / 32 * 4 + 255) & ~(size_t)255, arr_b = (((size_t)n_pairs * npw * 4) + 64 + 255) & ~(size_t)255;
+            char *base = (char *)d_scratch;
+            uint32_t *flags_d = reinterpret_cast<uint32_t *>(base + pl.todo_bytes);
+            uint32_t *pkP = reinterpret_cast<uint32_t *>(base + pl.todo_bytes + flag_b), *pkT = reinterpret_cast<uint32_t *>(base + pl.todo_bytes + flag_b + arr_b);
+            HIP_TRY(hipMemsetAsync(base, 0, 64, stream));
+            HIP_TRY(hipMemsetAsync(flags_d, 0, flag_b, stream));
+            const uint64_t threads = (uint64_t)n_pairs * npw;
+            hipLaunchKernelGGL(aim::pack_rows_kernel, dim3((unsigned)((threads + 255) / 256), 2), dim3(256), 0, stream, ka, pkP, pkT, flags_d,
+                               reinterpret_cast<uint32_t *>(base));
+            HIP_TRY(hipGetLastError());
+            aim::KArgs kp = ka;
+            kp.packedP = pkP;
+            kp.packedT = pkT;
+            aim::wfa_lane_packed_launch(p, pl.grid, pl.lds, kp, 0u, stream);
+            HIP_TRY(hipGetLastError());
+            aim::KArgs kb = ka;
+            kb.todo = reinterpret_cast<const uint32_t *>(base);
+            kb.scratch = base + pl.todo_bytes + pl.pack_bytes;
+            kb.scratch_per_wave = pl.scratch_per_wg;
+            Plan fb = pl;
+            fb.grid = pl.fb_grid;
+            fb.lds = pl.fb_lds;
+            kb.dbg_lds_bytes = (uint32_t)fb.lds;
+            if (bt && red) launch_wfa_wave<true, true>(fb, kb, stream);
+            else if (bt) launch_wfa_wave<true, false>(fb, kb, stream);
+            else if (red) launch_wfa_wave<false, true>(fb, kb, stream);
+            else launch_wfa_wave<false, false>(fb, kb, stream);
+            break;
+        }
         aim::wfa_lane_packed_launch(p, pl.grid, pl.lds, ka, fio->run_slot, stream);
         break;
     case K_WFA_GROUP: {
@@ -1097,7 +1156,7 @@ int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback
     if (!s.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
     *n_fallback = 0;
     const Plan &pl = s.plan_last;   // the plan the launch actually followed, not a re-plan
-    if (pl.kid != K_WFA_GROUP || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
+    if ((pl.kid != K_WFA_GROUP && !pl.pack_first) || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
     HIP_TRY(hipSetDevice(d.dev));
     HIP_TRY(hipMemcpy(n_fallback, s.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return AIM_OK;

@@ -63,6 +63,47 @@ __global__ __launch_bounds__(256) void scatter_raw_rows_kernel(int read_size, ui
     reinterpret_cast<uint2 *>((is_text ? outT : outP) + (uint64_t)pair * read_size)[piece] = v;
 }
 
+// The inverse of unpack_rows_kernel: ASCII rows -> packed rows on the device, for configurations only the packed lane kernel
+// covers (READ_SIZE other than 80 / 112) when the batch arrived as ASCII rows (the default ABI). One thread packs 16 bases
+// (one output dword) and validates them by decoding back; a pair with a byte outside A/C/G/T inside either sequence is
+// appended ONCE (flag bit per pair) to the to-do list {count @0, pair ids @16..} that the general kernel drains afterwards
+// over the ASCII rows -- the same hand-over wfa_group_kernel uses. grid.y: 0 = patterns, 1 = texts.
+typedef uint32_t pk_in_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void pack_rows_kernel(KArgs a, uint32_t *packedP, uint32_t *packedT, uint32_t *flag_bits, uint32_t *todo)
+{
+    const int rs = a.p.read_size;
+    const uint32_t npw = packed_row_dwords(rs);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)a.n_pairs * npw) return;
+    const uint32_t pair = (uint32_t)(t / npw), j = (uint32_t)(t - (uint64_t)pair * npw);
+    const bool is_text = blockIdx.y != 0;
+    const aim_request_t rq = load_request(a, pair);
+    const int len = is_text ? rq.text_len : rq.pattern_len;
+    const char *row = (is_text ? a.texts : a.patterns) + (uint64_t)pair * rs + 16u * j;   // (the arrays carry >= 16 B of tail slack)
+    const pk_in_u32x4 v = *reinterpret_cast<const pk_in_u32x4 *>(row);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t out = 0, bad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rem = len - (int)(16u * j + 4u * i);
+        const uint32_t mask = rem >= 4 ? ~0u : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+        const uint32_t av = w[i] & mask;
+        const uint32_t c = (av >> 1) & 0x03030303u & mask;
+        const uint32_t rec = __builtin_amdgcn_perm(0u, 0x47544341u, c) & mask;
+        bad |= rec ^ av;
+        out |= __builtin_amdgcn_udot4(c, 0x40100401u, 0u, false) << (8 * i);
+    }
+    (is_text ? packedT : packedP)[t] = out;
+    if (bad) {
+        const uint32_t bit = 1u << (pair & 31u);
+        const uint32_t old = atomicOr(&flag_bits[pair >> 5], bit);
+        if (!(old & bit)) {
+            const uint32_t slot = atomicAdd(&todo[0], 1u);
+            todo[16 + slot] = pair;
+        }
+    }
+}
+
 // Raw side pass of a packed batch whose alignment kernel read the packed rows itself (aim_capi.hip): the pairs of the side
 // list are aligned by the ASCII kernels as a small batch of their own -- requests gathered, results scattered back.
 // Elements are `dw` dwords (requests 2 / 4, results 2 / 6, aim_cigar_t 4).

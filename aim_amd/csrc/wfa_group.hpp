@@ -484,13 +484,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
 // the reference then select -- a cell outside its row is read at a clamped index and never selected. Output: result_t +
 // edit operations patched into the ops row the compute kernel pre-filled with 'M' (default ABI), or aim_cigar_t + runs
 // (RUNS: the compact CIGAR; runs are collected backwards in the pair's own run scratch and copied out forwards).
-struct OpsSink {
-    char *ops;
-    int cap, pos;
-    __device__ __forceinline__ void put(char ch) { if (pos >= 0 && pos < cap) ops[pos] = ch; --pos; }
-    __device__ __forceinline__ void matches(int n) { pos -= n; }
-};
-
 template <typename Sink>
 __device__ __forceinline__ int group_tb_walk(const TbRow *tab, const int16_t *pool, int final_score, int plen, int tlen, int X, int OE, int E, Sink &sink)
 {

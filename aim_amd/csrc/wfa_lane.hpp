@@ -112,6 +112,28 @@ struct WfShape {
     }
 };
 
+// Where the cells of a shape's wavefronts live in a per-lane history column (wfa_scores_dynamic<HIST>): row s of M starts at
+// m[s] (cell of diagonal lo[s]), I at i[s], D at d[s]; after them 3 descriptor words per score (klo, khi, flags) at meta + 3 s.
+template <int X, int O, int E, int MAXS>
+struct WfHist {
+    int m[MAXS + 1], i[MAXS + 1], d[MAXS + 1];
+    int meta, total;
+    constexpr WfHist() : m{}, i{}, d{}, meta(0), total(0)
+    {
+        constexpr WfShape<X, O, E, MAXS> SH{};
+        int at = 0;
+        for (int s = 0; s <= MAXS; ++s) {
+            const int w = SH.present[s] ? SH.hi[s] - SH.lo[s] + 1 : 0;
+            m[s] = at; at += w;
+            i[s] = at; at += (SH.present[s] && SH.hasI[s]) ? w : 0;
+            d[s] = at; at += (SH.present[s] && SH.hasD[s]) ? w : 0;
+        }
+        meta = at;
+        total = at + 3 * (MAXS + 1);
+    }
+};
+enum { LF_PRESENT = 1, LF_MNULL = 2, LF_INULL = 4, LF_DNULL = 8, LF_HASI = 16, LF_HASD = 32 };   // = wfa_group.hpp's GF_*
+
 // first set flag at or after pattern position v in a 2-bit-per-base flag vector (flags on even bits)
 template <int NP>
 __device__ __forceinline__ int first_stop(const uint32_t (&m)[NP], int v)
@@ -331,10 +353,15 @@ __device__ __forceinline__ void raw_diag(const uint4 (&rawP)[NP], const uint4 (&
 // away, above it they are a handful of integer selects. Every fetch is range-gated by the source's klo/khi exactly like
 // AFFINE_WAVEFRONT_COND_FETCH (common.h:121-124), so cells of the static superset that the reference never allocates are
 // computed but never read. Score-only (with CIGAR the history of a 13-wide shape does not fit the register file).
-template <int X, int O, int E, int MAXS, int NP, int KW>
-__device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], int plen, int tlen, int ms_run, bool reduce, bool active)
+// HIST: every computed cell (after extension) and every score's final descriptor are also written to this lane's history
+// column hist[i * kWave] (int16, lane-interleaved LDS) for wfa_backtrace_dynamic.
+template <int X, int O, int E, int MAXS, int NP, int KW, bool HIST = false>
+__device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], int plen, int tlen, int ms_run, bool reduce, bool active,
+                                                  int16_t *hist = nullptr)
 {
     constexpr WfShape<X, O, E, MAXS> SH{};
+    constexpr WfHist<X, O, E, MAXS> HX{};
+    bool hasi[MAXS + 1], hasd[MAXS + 1];
     static_assert(KW == SH.kmax - SH.kmin + 1, "diagonal window");
     static_assert(SH.kmax < 16 && SH.kmin > -16, "diagonal shifts are single-word funnel shifts");
     const int ak = tlen - plen;
@@ -345,9 +372,13 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
     bool done = false;
 #pragma unroll
     for (int s = 0; s <= MAXS; ++s) {
-        if (!SH.present[s]) { pres[s] = false; mnul[s] = inul[s] = dnul[s] = true; klo[s] = 0; khi[s] = -1; continue; }
+        if (!SH.present[s]) {
+            pres[s] = false; mnul[s] = inul[s] = dnul[s] = true; klo[s] = 0; khi[s] = -1; hasi[s] = hasd[s] = false;
+            if (HIST) { hist[(HX.meta + 3 * s) * kWave] = 0; hist[(HX.meta + 3 * s + 1) * kWave] = -1; hist[(HX.meta + 3 * s + 2) * kWave] = 0; }
+            continue;
+        }
         if (s == 0) {   // wavefronts[0] = allocate_new_score(0, 0, 0, 0); M[0] = 0 (wfa.c:347-348)
-            pres[0] = true; mnul[0] = false; inul[0] = dnul[0] = true; klo[0] = khi[0] = 0;
+            pres[0] = true; mnul[0] = false; inul[0] = dnul[0] = true; klo[0] = khi[0] = 0; hasi[0] = hasd[0] = false;
             Mv[0][-SH.kmin] = 0;
         } else {        // affine_wfa_compute_next, wfa.c:268-340
             const int ss = s - X, so = s - O - E, se = s - E;
@@ -364,6 +395,7 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
             klo[s] = min(min(sub_lo, o_lo), e_lo) - 1;
             khi[s] = max(max(sub_hi, o_hi), e_hi) + 1;
             mnul[s] = false; inul[s] = i_out_null; dnul[s] = d_out_null;
+            hasi[s] = !i_out_null; hasd[s] = !d_out_null;
 #pragma unroll
             for (int k = SH.lo[s]; k <= SH.hi[s]; ++k) {   // affine_wfa_compute_offsets, wfa.c:231-266
                 const int kk = k - SH.kmin;
@@ -376,6 +408,7 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
                     const int v = (ins_g == kLaneNull && ins_i == kLaneNull) ? kLaneNull : max(ins_g, ins_i) + 1;
                     ins = i_out_null ? -10 : v;
                     Iv[s][kk] = v;
+                    if (HIST && SH.hasI[s]) hist[(HX.i[s] + k - SH.lo[s]) * kWave] = (int16_t)v;
                 }
                 int del = -10;
                 {
@@ -384,6 +417,7 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
                     const int v = max(del_g, del_d);
                     del = d_out_null ? -10 : v;
                     Dv[s][kk] = v;
+                    if (HIST && SH.hasD[s]) hist[(HX.d[s] + k - SH.lo[s]) * kWave] = (int16_t)v;
                 }
                 int sub = -10;
                 if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? Mv[sss][kk] + 1 : kLaneNull;
@@ -402,6 +436,7 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
                 off += stop - v;
             }
             Mv[s][kk] = off;
+            if (HIST) hist[(HX.m[s] + k - SH.lo[s]) * kWave] = (int16_t)off;
         }
         // affine_wfa_reduce_wvs (WFA-adaptive, wfa.c:69-140): only shapes that can hold >= 10 diagonals get this code
         if (SH.hi[s] - SH.lo[s] + 1 >= 10) {
@@ -435,6 +470,12 @@ __device__ __forceinline__ int wfa_scores_dynamic(const uint32_t (&dk)[KW][NP], 
                 klo[s] = kill ? klo[s] : nklo;
                 khi[s] = kill ? khi[s] : nkhi;
             }
+        }
+        if (HIST) {   // final descriptor of this score (after the reduction)
+            hist[(HX.meta + 3 * s) * kWave] = (int16_t)klo[s];
+            hist[(HX.meta + 3 * s + 1) * kWave] = (int16_t)khi[s];
+            hist[(HX.meta + 3 * s + 2) * kWave] = (int16_t)((pres[s] ? LF_PRESENT : 0) | (mnul[s] ? LF_MNULL : 0) | (inul[s] ? LF_INULL : 0) | (dnul[s] ? LF_DNULL : 0) |
+                                                            (hasi[s] ? LF_HASI : 0) | (hasd[s] ? LF_HASD : 0));
         }
         // affine_wfa_end_reached (wfa.c:210-230); the run-time MAX_SCORE cap is a term of the test (wfa.c:368-376)
         {

@@ -203,6 +203,95 @@ __device__ __forceinline__ int wfa_backtrace_static(const int (&Mv)[MAXS + 1][KW
     return status;
 }
 
+// ---- the same walk for the dynamic-bounds shapes (MAX_SCORE 6..10): history in the lane's LDS column ------------------
+// wfa_scores_dynamic<HIST> left every cell at a compile-time index (WfHist) and every score's final klo / khi / flags behind
+// them; the walk reads them with the range and null tests of the reference's fetchers (wfa_backtracing.c:73-172; the same
+// tests as wfa_group_tb_kernel: del_ext wants !d_null, ins_ext wants the I component to EXIST -- W7's asymmetry).
+template <int X, int O, int E, int MAXS, typename Sink>
+__device__ __forceinline__ int wfa_backtrace_dynamic(const int16_t *hist, int score, int plen, int tlen, Sink &sink)
+{
+    constexpr WfShape<X, O, E, MAXS> SH{};
+    constexpr WfHist<X, O, E, MAXS> HX{};
+    const int ak = tlen - plen;
+    // static row tables, looked up by a per-lane score (select chains over <= MAXS + 1 entries)
+    auto lut = [&](const int (&arr)[MAXS + 1], int s_) { int r = 0;
+#pragma unroll
+        for (int s2 = 0; s2 <= MAXS; ++s2) r = (s_ == s2) ? arr[s2] : r;
+        return r; };
+    struct Row { int klo, khi, f, lo; };
+    auto row = [&](int s_) {
+        Row r;
+        const int sc_ = s_ < 0 ? 0 : s_;
+        r.klo = hist[(HX.meta + 3 * sc_) * kWave]; r.khi = hist[(HX.meta + 3 * sc_ + 1) * kWave]; r.f = hist[(HX.meta + 3 * sc_ + 2) * kWave];
+        r.lo = lut(SH.lo, sc_);
+        if (s_ < 0) { r.klo = 1; r.khi = -1; r.f = 0; }
+        return r;
+    };
+    auto in = [&](const Row &r, int k_) { return r.klo <= k_ && k_ <= r.khi; };
+    auto valid_loc = [&](int kk_, int off_) {
+        const int v_ = off_ - kk_, h_ = off_;
+        return v_ > 0 && v_ <= plen && h_ > 0 && h_ <= tlen;
+    };
+    enum { BT_M = 0, BT_I = 1, BT_D = 2 };
+    int status = AIM_PAIR_OK;
+    int sc = score, k = ak;
+    int offset = hist[(lut(HX.m, sc) + k - lut(SH.lo, sc)) * kWave];
+    bool valid = valid_loc(k, offset);
+    int bt = BT_M;
+    int v = offset - k, h = offset;
+    while (v > 0 && h > 0 && sc > 0) {
+        if (!valid) {
+            valid = valid_loc(k, offset);
+            if (valid) {   // add_trailing_gap, wfa_backtracing.c:48-69
+                if (k < ak) for (int i = k; i < ak; ++i) sink.put('I');
+                else if (k > ak) for (int i = ak; i < k; ++i) sink.put('D');
+            }
+        }
+        const int s_o = sc - (O + E), s_e = sc - E, s_x = sc - X;
+        const Row ro = row(s_o), re = row(s_e), rx = row(s_x);
+        int del_ext = kLaneNull, del_open = kLaneNull, ins_ext = kLaneNull, ins_open = kLaneNull, misms = kLaneNull;
+        if (bt != BT_I) {
+            if ((re.f & LF_PRESENT) && !(re.f & LF_DNULL) && in(re, k + 1)) del_ext = hist[(lut(HX.d, s_e) + k + 1 - re.lo) * kWave];
+            if ((ro.f & LF_PRESENT) && in(ro, k + 1)) del_open = hist[(lut(HX.m, s_o) + k + 1 - ro.lo) * kWave];
+        }
+        if (bt != BT_D) {
+            if ((re.f & LF_PRESENT) && (re.f & LF_HASI) && in(re, k - 1)) ins_ext = hist[(lut(HX.i, s_e) + k - 1 - re.lo) * kWave] + 1;
+            if ((ro.f & LF_PRESENT) && in(ro, k - 1)) ins_open = hist[(lut(HX.m, s_o) + k - 1 - ro.lo) * kWave] + 1;
+        }
+        if (bt == BT_M) {
+            if ((rx.f & LF_PRESENT) && in(rx, k)) misms = hist[(lut(HX.m, s_x) + k - rx.lo) * kWave] + 1;
+        }
+        const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
+        if (bt == BT_M) {
+            const int num_matches = offset - max_all;
+            if (num_matches > 0) sink.matches(num_matches);
+            offset = max_all;
+            v = offset - k;
+            h = offset;
+            if (v <= 0 || h <= 0) break;
+        }
+        char op;
+        if (max_all == del_ext) { op = 'D'; sc = s_e; ++k; bt = BT_D; }
+        else if (max_all == del_open) { op = 'D'; sc = s_o; ++k; bt = BT_M; }
+        else if (max_all == ins_ext) { op = 'I'; sc = s_e; --k; --offset; bt = BT_I; }
+        else if (max_all == ins_open) { op = 'I'; sc = s_o; --k; --offset; bt = BT_M; }
+        else if (max_all == misms) { op = 'X'; sc = s_x; --offset; }
+        else { status = AIM_PAIR_WFA_NO_LINK; break; }
+        if (valid) sink.put(op);
+        v = offset - k;
+        h = offset;
+    }
+    if (status == AIM_PAIR_OK) {
+        if (sc == 0) {
+            if (offset > 0) sink.matches(offset);
+        } else {
+            for (; v > 0; --v) sink.put('D');
+            for (; h > 0; --h) sink.put('I');
+        }
+    }
+    return status;
+}
+
 // ---- run collector ------------------------------------------------------------------------------------------------
 // The backtrace emits operations from the END of the alignment towards its beginning; edit_cigar_print (host.c:69-89)
 // prints ops[begin_offset, end_offset) forwards. `pos` is the reference's begin_offset (the next position written,
@@ -331,13 +420,25 @@ __device__ __forceinline__ void load_packed_row(const uint32_t *row, uint32_t (&
     if (R & 1) out[NP - 1] = __builtin_nontemporal_load(row + NP - 1);
 }
 
-template <int X, int O, int E, int MAXS, int NP, bool BT, bool DYN>
+// the reference's ops row as the backtrace's sink (default ABI): operations[begin_offset--] = ch over the 'M' pre-fill
+struct OpsSink {
+    char *ops;
+    int cap, pos;
+    __device__ __forceinline__ void put(char ch) { if (pos >= 0 && pos < cap) ops[pos] = ch; --pos; }
+    __device__ __forceinline__ void matches(int n) { pos -= n; }
+};
+
+enum { PK_OUT_SCORE = 0, PK_OUT_RUNS = 1, PK_OUT_OPS = 2 };   // what the kernel writes: {idx, score} / result_t; aim_cigar_t + runs; result_t + ops rows
+
+template <int X, int O, int E, int MAXS, int NP, int OUT, bool DYN>
 __global__ __launch_bounds__(64, DYN ? 2 : 1) void wfa_lane_packed_kernel(KArgs a, uint32_t run_slot)
 {
     constexpr WfShape<X, O, E, MAXS> SH{};
+    constexpr WfHist<X, O, E, MAXS> HX{};
+    constexpr bool BT = OUT != PK_OUT_SCORE;
     static_assert(DYN || SH.maxw < 10, "WFA-adaptive reduction could fire: shape needs the dynamic-bounds score loop (DYN)");
-    static_assert(!(DYN && BT), "the dynamic-bounds score loop is score-only");
     constexpr int KW = SH.kmax - SH.kmin + 1;
+    constexpr int kSpillBytes = OUT == PK_OUT_RUNS ? kLaneRunSpill * kWave * 4 : 0;   // LDS: [run spill][history column (DYN + BT)]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
     const int lane = threadIdx.x;
@@ -395,17 +496,47 @@ __global__ __launch_bounds__(64, DYN ? 2 : 1) void wfa_lane_packed_kernel(KArgs 
         int Mv[MAXS + 1][KW], Iv[MAXS + 1][KW], Dv[MAXS + 1][KW];
         int score;
         bool done;
+        int16_t *hist = reinterpret_cast<int16_t *>(smem + kSpillBytes) + lane;   // this lane's history column (DYN + BT)
         if constexpr (DYN) {
-            score = wfa_scores_dynamic<X, O, E, MAXS, NP, KW>(dk, plen, tlen, ms_run, (a.p.flags & AIM_FLAG_REDUCE) != 0, active);
+            score = wfa_scores_dynamic<X, O, E, MAXS, NP, KW, BT>(dk, plen, tlen, ms_run, (a.p.flags & AIM_FLAG_REDUCE) != 0, active, hist);
             done = score <= ms_run;
         } else {
             wfa_scores_static<X, O, E, MAXS, NP, KW>(dk, plen, tlen, ms_run, active, Mv, Iv, Dv, score, done);
         }
-        if constexpr (BT) {
+        if constexpr (OUT == PK_OUT_OPS) {
+            // default ABI: result_t + ops row. memset(cigar->operations, 'M', 2*READ_SIZE) (wfa.c:465), then the walk patches the edits in
+            const int rs = a.p.read_size;
+            OpsSink sink;
+            sink.ops = a.ops + (uint64_t)(active ? pair : 0u) * (2 * rs);
+            sink.cap = 2 * rs;
+            sink.pos = plen + tlen - 1;                 // edit_cigar_allocate, wfa.c:57-67
+            int status = AIM_PAIR_OK;
+            if (active) {
+                uint4 *orow = reinterpret_cast<uint4 *>(sink.ops);
+                const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
+                for (int j = 0; j < (2 * rs) / 16; ++j) orow[j] = mm;
+                if (done) {
+                    if constexpr (DYN) status = wfa_backtrace_dynamic<X, O, E, MAXS>(hist, score, plen, tlen, sink);
+                    else status = wfa_backtrace_static<X, O, E, MAXS, KW>(Mv, Iv, Dv, score, plen, tlen, sink);
+                    if (status == AIM_PAIR_OK) ++sink.pos;
+                }
+                aim_result_t r;
+                r.max_operations = plen + tlen;
+                r.begin_offset = sink.pos;
+                r.end_offset = plen + tlen;
+                r.score = score;
+                r.status = status;
+                r.idx = idx;
+                store_result(a, pair, r);
+            }
+        } else if constexpr (OUT == PK_OUT_RUNS) {
             uint32_t *spill = reinterpret_cast<uint32_t *>(smem) + lane;
             RunCollector<kWave> coll(plen + tlen - 1, spill, kLaneRunSpill);   // edit_cigar_allocate, wfa.c:57-67
             int status = AIM_PAIR_OK;
-            if (active && done) status = wfa_backtrace_static<X, O, E, MAXS, KW>(Mv, Iv, Dv, score, plen, tlen, coll);
+            if (active && done) {
+                if constexpr (DYN) status = wfa_backtrace_dynamic<X, O, E, MAXS>(hist, score, plen, tlen, coll);
+                else status = wfa_backtrace_static<X, O, E, MAXS, KW>(Mv, Iv, Dv, score, plen, tlen, coll);
+            }
             coll.flush();
             if (coll.n == 0) {   // nothing inside [0, end): edit_cigar_print still prints operations[begin_offset] = 'M'
                 coll.cur_op = (uint32_t)'M'; coll.cur_len = 1u;
@@ -448,33 +579,51 @@ inline bool wfa_lane_packed_supported(const aim_params_t &p, bool allow_dynamic 
     if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the reference's default penalties
     if (!wfa_lane_packed_np_ok((p.read_size + 15) / 16)) return false;
     if (p.max_score <= 5) return true;
-    return allow_dynamic && p.max_score <= kLaneDynMaxScore && !(p.flags & AIM_FLAG_BACKTRACE);
+    return allow_dynamic && p.max_score <= kLaneDynMaxScore;
 }
 
 inline void wfa_lane_packed_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
 {
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
-    uint32_t g = 256u * (p.max_score > 5 ? AIM_LANEPK_DYN_WGS_PER_CU : AIM_LANEPK_WGS_PER_CU);
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE, dyn = p.max_score > 5;
+    // LDS: run spill (compact CIGAR output only; reserved whenever BACKTRACE is set) + the dynamic-bounds shape's history column
+    constexpr WfHist<3, 4, 1, kLaneDynMaxScore> HX{};
+    *lds = bt ? (size_t)kLaneRunSpill * kWave * 4 + (dyn ? (size_t)HX.total * kWave * 2 : 0) : 0;
+    // resident single-wave workgroups per CU by the register count of the instantiation (static shapes <= 89 VGPRs; dynamic-bounds
+    // score-only 102 / 126 / 150 / 162 / 173 at 5 / 7 / 9 / 10 / 11 dwords per row, + 23 with CIGAR)
+    const int np = (p.read_size + 15) / 16;
+    uint32_t per_cu = !dyn ? AIM_LANEPK_WGS_PER_CU : ((np <= 7 && !bt) ? 16u : (np <= 9 ? 12u : (np <= 10 && !bt ? 12u : AIM_LANEPK_DYN_WGS_PER_CU)));
+    if (*lds) per_cu = (uint32_t)std::min<size_t>(per_cu, lds_workgroups_per_cu(*lds));
+    uint32_t g = 256u * per_cu;
     const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;
     *block = kWave;
-    *lds = (p.flags & AIM_FLAG_BACKTRACE) ? (size_t)kLaneRunSpill * kWave * 4 : 0;
 }
 
+// Output follows the buffers given: compact CIGAR when ka.cig is set, else (BACKTRACE) result_t + ops rows, else scores.
 inline void wfa_lane_packed_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, uint32_t run_slot, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const int np = (p.read_size + 15) / 16;
-#define AIM_LANEPK_LAUNCH(N)                                                                                                           \
-    if (np == N) {                                                                                                                     \
-        if (p.max_score > 5) hipLaunchKernelGGL((wfa_lane_packed_kernel<3, 4, 1, kLaneDynMaxScore, N, false, true>), dim3(grid), dim3(kWave), lds, s, ka, run_slot); \
-        else if (bt) hipLaunchKernelGGL((wfa_lane_packed_kernel<3, 4, 1, 5, N, true, false>), dim3(grid), dim3(kWave), lds, s, ka, run_slot);   \
-        else hipLaunchKernelGGL((wfa_lane_packed_kernel<3, 4, 1, 5, N, false, false>), dim3(grid), dim3(kWave), lds, s, ka, run_slot);         \
-        return;                                                                                                                        \
+    const int out = !bt ? PK_OUT_SCORE : (ka.cig ? PK_OUT_RUNS : PK_OUT_OPS);
+#define AIM_LANEPK_ONE(N, MS, OUTV, DYNV) hipLaunchKernelGGL((wfa_lane_packed_kernel<3, 4, 1, MS, N, OUTV, DYNV>), dim3(grid), dim3(kWave), lds, s, ka, run_slot)
+#define AIM_LANEPK_LAUNCH(N)                                                                       \
+    if (np == N) {                                                                                 \
+        if (p.max_score > 5) {                                                                     \
+            if (out == PK_OUT_SCORE) AIM_LANEPK_ONE(N, kLaneDynMaxScore, PK_OUT_SCORE, true);      \
+            else if (out == PK_OUT_RUNS) AIM_LANEPK_ONE(N, kLaneDynMaxScore, PK_OUT_RUNS, true);   \
+            else AIM_LANEPK_ONE(N, kLaneDynMaxScore, PK_OUT_OPS, true);                            \
+        } else {                                                                                   \
+            if (out == PK_OUT_SCORE) AIM_LANEPK_ONE(N, 5, PK_OUT_SCORE, false);                    \
+            else if (out == PK_OUT_RUNS) AIM_LANEPK_ONE(N, 5, PK_OUT_RUNS, false);                 \
+            else AIM_LANEPK_ONE(N, 5, PK_OUT_OPS, false);                                          \
+        }                                                                                          \
+        return;                                                                                    \
     }
     AIM_LANEPK_NP_LIST(AIM_LANEPK_LAUNCH)
 #undef AIM_LANEPK_LAUNCH
+#undef AIM_LANEPK_ONE
 }
 
 }  // namespace aim

@@ -82,7 +82,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True))) == b"wfa_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 5, 112, backtrace=True, mismatch=4))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112))) == b"wfa_lane_kernel"          # round 2: dynamic-bounds shape, score-only
-    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112, backtrace=True))) == b"wfa_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 10, 112, backtrace=True))) == b"wfa_lane_packed_kernel"   # round 3: CIGAR at MAX_SCORE 6..10 (rows packed on the device)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 8, 160))) == b"wfa_lane_packed_kernel"                    # round 3: READ_SIZE beyond 80 / 112 (l = 150)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 11, 112, backtrace=True))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 11, 112))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 250, 1064, backtrace=True, reduce=True))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 2000, 8000))) == b"wfa_wave_kernel"

@@ -794,10 +794,7 @@ def test_packed_input_and_compact_cigar_match_default_path(gpu, algo, l, err, n,
                 assert np.array_equal(out["cig"]["status"], base_res["status"].astype(np.uint16))
                 if want is not None:
                     assert engine.format_output_runs(out["cig"], out["runs"]) == want
-                plan = s.plan_describe(0)
-                if plan.startswith("wfa_lane_packed_kernel"):   # slotted run buffer: 4 runs per pair, longer CIGARs behind
-                    assert len(out["runs"]) >= 4 * n and len(out["runs"]) >= int(out["cig"]["n_runs"].sum())
-                elif "packed_in=1 runs_out=1" in plan:          # fused group path: the void runs of the side list's pairs stay behind as holes
+                if pk is not None:   # fused kernels: slotted run buffer (lane) / void runs of the side list's pairs left behind as holes (group)
                     assert len(out["runs"]) >= int(out["cig"]["n_runs"].sum())
                 else:
                     assert int(out["cig"]["n_runs"].sum()) == len(out["runs"])
@@ -1182,3 +1179,54 @@ def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
         else:
             assert np.array_equal(out["res"]["score"], ores["score"])
         _compare("wfa", params, req, pat, txt)                              # default ABI (ASCII rows in, result_t + ops rows out)
+
+
+LANE_SHAPES = [(150, 0.01), (150, 0.02), (125, 0.01), (100, 0.02), (70, 0.03), (160, 0.01), (100, 0.01)]
+
+
+@pytest.mark.parametrize("l,err", LANE_SHAPES)
+@pytest.mark.parametrize("bt", [False, True])
+def test_lane_shapes_through_the_default_abi(gpu, l, err, bt):
+    """the one-pair-per-lane kernels on the shapes real short reads have -- READ_SIZE 136 .. 176 (l = 125 .. 160)
+    and CIGAR at MAX_SCORE 6..10 -- through the DEFAULT ABI (ASCII rows in, result_t + ops rows out): the rows are packed on the
+    device, wfa_lane_packed_kernel aligns them (dynamic-bounds score loop + LDS history for the walk at MAX_SCORE > 5), pairs with
+    non-ACGT bytes reach the general kernel through the to-do list. Bit-exact against the oracle incl. begin_offset and ops."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    ms, rs = engine.launcher_sizes("wfa", l, err)
+    if ms > 10:
+        ms = 10          # run-time cap inside the shape (pairs beyond it report MAX_SCORE + 1)
+    n = 5000 + 13
+    req, pat, txt = engine.gen_pairs(400 + l, 0, n, l, err, rs)
+    for i in range(0, n, 101):
+        pat[i, i % (l // 2)] = ord("N")
+    for reduce in (True, False):
+        params = engine.make_params("wfa", ms, rs, backtrace=bt, reduce=reduce)
+        want = b"wfa_lane_kernel" if (rs in (80, 112) and (ms <= 5 or not bt)) else b"wfa_lane_packed_kernel"
+        assert capi.load().aim_kernel_name(C.byref(params)) == want
+        res, _, ores = _compare("wfa", params, req, pat, txt)
+        assert (ores["score"] <= ms).any()
+    with engine.DeviceSet(1) as s:       # the non-ACGT pairs went through the to-do list
+        s.configure(params, n)
+        s.push(0, req, pat, txt)
+        s.launch()
+        if want == b"wfa_lane_packed_kernel":
+            assert s.fallback_pairs(0) == len(range(0, n, 101))
+
+
+@pytest.mark.parametrize("l,err,rs", [(100, 0.02, 112), (100, 0.05, 112), (70, 0.03, 80), (150, 0.02, 160), (165, 0.03, 176)])
+def test_fused_packed_dynamic_bounds_shape_with_cigar(gpu, l, err, rs):
+    """MAX_SCORE 6..10 WITH the compact CIGAR on packed batches: wfa_scores_dynamic<HIST> + wfa_backtrace_dynamic inside
+    wfa_lane_packed_kernel, against the oracle's output text (reduction on and off, pairs beyond the cap, non-ACGT pairs)."""
+    from aim_amd import engine
+    n = 4000 + 9
+    req, pat, txt = engine.gen_pairs(1300 + l, 0, n, l, err, rs)
+    for i in range(0, n, 89):
+        pat[i, i % (l // 2)] = ord("N")
+    for ms in (6, 8, 10):
+        for reduce in (True, False):
+            params = engine.make_params("wfa", ms, rs, backtrace=True, reduce=reduce, req8=True)
+            ores, want = _oracle_text("wfa", params, req, pat, txt)
+            out, _ = _fused(params, req, pat, txt, runs_cap=24 * n)
+            assert np.array_equal(out["cig"]["score"], ores["score"]) and (out["cig"]["status"] == 0).all()
+            assert engine.format_output_runs(out["cig"], out["runs"]) == want, (l, ms, reduce)

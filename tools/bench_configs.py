@@ -19,6 +19,8 @@ CONFIGS = {
     "wfa_l100_e10_score": dict(algo="wfa", l=100, e=0.10, n=1 << 19, kw=dict(reduce=True)),
     "wfa_l250_e5_score": dict(algo="wfa", l=250, e=0.05, n=1 << 18, kw=dict(reduce=True)),
     "wfa_l150_e2_score": dict(algo="wfa", l=150, e=0.02, n=1 << 20, kw=dict(reduce=True)),
+    "wfa_l150_e1_score": dict(algo="wfa", l=150, e=0.01, n=1 << 20, kw=dict(reduce=True)),
+    "wfa_l150_e1_cigar": dict(algo="wfa", l=150, e=0.01, n=1 << 20, kw=dict(backtrace=True, reduce=True)),
     "wfa_l100_e5_score_nored": dict(algo="wfa", l=100, e=0.05, n=1 << 20, kw=dict()),
     "wfa_l100_e5_cigar": dict(algo="wfa", l=100, e=0.05, n=1 << 19, kw=dict(backtrace=True, reduce=True)),
     "wfa_l1000_e5_cigar": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(backtrace=True, reduce=True)),
