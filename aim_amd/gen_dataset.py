@@ -12,6 +12,28 @@ import sys
 from . import engine
 
 
+def write_packed(out, seed, num_pairs, length, error, batch):
+    """Packed batch file (aim_amd/host/host.c, pkfile_hdr_t): 64-byte header, then per batch {n, ascii = 0, n_raw, READ_SIZE} +
+    aim_request8_t[n] + packed patterns + packed texts + raw side list (indices, ASCII patterns, ASCII texts)."""
+    import math
+    import numpy as np
+    read_size = int(math.ceil((length + length * error + 7) / 8)) * 8          # run-*-pim-*.py: READ_SIZE
+    batch = max(1, min(batch, max(num_pairs, 1)))
+    hdr = np.zeros(64, dtype=np.uint8)
+    hdr[:8] = np.frombuffer(b"AIMPK\0\0\1", dtype=np.uint8)
+    hdr[8:24] = np.array([1, read_size, 8, batch], dtype="<u4").view(np.uint8)
+    hdr[24:32] = np.array([num_pairs], dtype="<u8").view(np.uint8)
+    out.write(hdr.tobytes())
+    for first in range(0, num_pairs, batch):
+        n = min(batch, num_pairs - first)
+        req, pat, txt = engine.gen_pairs(seed, first, n, length, error, read_size)
+        pp, pt, raw, rawp, rawt = engine.pack_batch(req, pat, txt)
+        out.write(np.array([n, 0, len(raw), read_size], dtype="<u4").tobytes())
+        out.write(engine.to_request8(req).tobytes())
+        for arr in (pp, pt, raw.astype("<u4"), rawp, rawt):
+            out.write(np.ascontiguousarray(arr).tobytes())
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="aim_amd.gen_dataset", description=__doc__.split("\n\n")[0])
     ap.add_argument("-n", "--num-pairs", type=int, required=True)
@@ -20,6 +42,10 @@ def main(argv=None):
     ap.add_argument("-s", "--seed", type=int, default=42)
     ap.add_argument("-o", "--output", required=True, help="output file ('-' for stdout)")
     ap.add_argument("--chunk", type=int, default=1 << 16, help="pairs generated per chunk (memory bound)")
+    ap.add_argument("--packed", action="store_true",
+                    help="write a packed batch file (2 bits per base + raw side list, the format `host --packed-input` reads and "
+                         "`host --pack-only` writes) instead of text; READ_SIZE by the launchers' rule for (-l, -e)")
+    ap.add_argument("--batch", type=int, default=1 << 20, help="--packed: pairs per batch of the file")
     a = ap.parse_args(argv)
     if a.num_pairs < 0 or a.length <= 0 or not (0.0 <= a.error < 1.0):
         ap.error("need num-pairs >= 0, length > 0, 0 <= error < 1")
@@ -27,6 +53,13 @@ def main(argv=None):
     edits = int(-(-a.length * a.error // 1))
     row = (a.length + edits + 1 + 7) // 8 * 8
     out = sys.stdout.buffer if a.output == "-" else open(a.output, "wb")
+    if a.packed:
+        try:
+            write_packed(out, a.seed, a.num_pairs, a.length, a.error, a.batch)
+        finally:
+            if out is not sys.stdout.buffer:
+                out.close()
+        return 0
     try:
         for first in range(0, a.num_pairs, a.chunk):
             n = min(a.chunk, a.num_pairs - first)

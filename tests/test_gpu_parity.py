@@ -1230,3 +1230,34 @@ def test_fused_packed_dynamic_bounds_shape_with_cigar(gpu, l, err, rs):
             out, _ = _fused(params, req, pat, txt, runs_cap=24 * n)
             assert np.array_equal(out["cig"]["score"], ores["score"]) and (out["cig"]["status"] == 0).all()
             assert engine.format_output_runs(out["cig"], out["runs"]) == want, (l, ms, reduce)
+
+
+def test_host_cli_packed_input_file(gpu, sample_bytes, err_bytes, ref_digests, tmp_path):
+    """`host --packed-input` reads the packed batch file `host --pack-only` writes -- same output file as the text
+    input, byte for byte (reference digests on the sample set; real reads with N through the raw side list; the reference's
+    partition rule ending inside a batch; a file packed for another READ_SIZE is refused like an over-length read)."""
+    import subprocess
+    from conftest import ROOT
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    (tmp_path / "s.seq").write_bytes(sample_bytes)
+    (tmp_path / "e.seq").write_bytes(err_bytes)
+    base = ["--algo", "wfa", "--max-score", "5", "--read-size", "112", "--reduce"]
+    for name, n in (("s", 20000), ("e", 2000)):
+        r = subprocess.run([host, str(tmp_path / (name + ".seq")), str(tmp_path / "x"), str(n)] + base + ["--pack-only", str(tmp_path / (name + ".aimpk"))],
+                           capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stdout + r.stderr
+    for extra, key in ((["--backtrace"], "wfa_reduce_backtrace"), ([], "wfa_score_only")):
+        r = subprocess.run([host, str(tmp_path / "s.aimpk"), str(tmp_path / "p.out"), "20000", "--packed-input"] + base + extra, capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0 and "packed batch file" in r.stdout, r.stdout + r.stderr
+        assert md5((tmp_path / "p.out").read_bytes()) == ref_digests[key]
+        for n_arg, nd in (("2000", "1"), ("1001", "4")):            # the partition rule: ROUND_UP_8(n / d) * d pairs, possibly ending inside the file's batch
+            outs = []
+            for inp, flag in (("e.seq", []), ("e.aimpk", ["--packed-input"])):
+                r = subprocess.run([host, str(tmp_path / inp), str(tmp_path / "q.out"), n_arg, "--nr-dpus", nd] + flag + base + extra, capture_output=True, text=True, cwd=tmp_path)
+                assert r.returncode == 0, r.stdout + r.stderr
+                outs.append((tmp_path / "q.out").read_bytes())
+            assert outs[0] == outs[1] and outs[0].count(b"\n") == (1 + bool(extra)) * min(2000, (int(n_arg) // int(nd) + 7) // 8 * 8 * int(nd))
+    r = subprocess.run([host, str(tmp_path / "s.aimpk"), str(tmp_path / "p.out"), "20000", "--packed-input", "--read-size", "120"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0 and "READ LENGTH less than length of the input reads" in r.stdout and (tmp_path / "p.out").read_bytes() == b""
+    r = subprocess.run([host, str(tmp_path / "s.seq"), str(tmp_path / "p.out"), "20000", "--packed-input"] + base, capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "not a packed batch file" in r.stderr

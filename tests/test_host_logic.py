@@ -164,7 +164,11 @@ def _read_pack_dump(path):
     import numpy as np
     from aim_amd import capi, engine
     raw = open(path, "rb").read()
-    at, jobs = 0, []
+    assert raw[:8] == b"AIMPK\0\0\1" and len(raw) >= 64          # packed batch file: 64-byte header (magic, version, READ_SIZE, request bytes, batch, total)
+    version, frs, rqb, fbatch = np.frombuffer(raw, dtype=np.uint32, count=4, offset=8)
+    total = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=24)[0])
+    assert version == 1 and rqb == 8
+    at, jobs = 64, []
     while at < len(raw):
         n, ascii_, n_raw, rs = np.frombuffer(raw, dtype=np.uint32, count=4, offset=at); at += 16
         n, n_raw, rs = int(n), int(n_raw), int(rs)
@@ -180,7 +184,9 @@ def _read_pack_dump(path):
             job["raw_idx"] = np.frombuffer(raw, dtype=np.uint32, count=n_raw, offset=at); at += 4 * n_raw
             job["rawP"] = np.frombuffer(raw, dtype=np.uint8, count=n_raw * rs, offset=at).reshape(n_raw, rs); at += n_raw * rs
             job["rawT"] = np.frombuffer(raw, dtype=np.uint8, count=n_raw * rs, offset=at).reshape(n_raw, rs); at += n_raw * rs
+        assert rs == frs and n <= fbatch
         jobs.append(job)
+    assert sum(j["n"] for j in jobs) == total
     return jobs
 
 
@@ -245,3 +251,19 @@ def test_host_cli_validates_whole_input_before_writing(built, tmp_path):
     assert out.read_bytes() == b"" and not (tmp_path / "d").exists()
     r = subprocess.run([host, str(inp), str(out), "-5"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 1 and "Invalid nb of reads" in r.stderr
+
+
+def test_gen_dataset_packed_equals_host_pack_only(built, tmp_path):
+    """The packed batch file has ONE definition: `python -m aim_amd.gen_dataset --packed` (numpy packer) and `host --pack-only`
+    (C packer on the text form of the same pairs) write the same bytes."""
+    import subprocess, sys
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    n, l, e = 20000, 100, 0.02
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.check_call([sys.executable, "-m", "aim_amd.gen_dataset", "-n", str(n), "-l", str(l), "-e", str(e), "-s", "9", "-o", str(tmp_path / "t.seq")], env=env)
+    subprocess.check_call([sys.executable, "-m", "aim_amd.gen_dataset", "-n", str(n), "-l", str(l), "-e", str(e), "-s", "9", "-o", str(tmp_path / "g.aimpk"),
+                           "--packed", "--batch", str(n)], env=env)
+    r = subprocess.run([host, str(tmp_path / "t.seq"), str(tmp_path / "o"), str(n), "--read-size", "112", "--threads", "3", "--pack-only", str(tmp_path / "h.aimpk")],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "g.aimpk").read_bytes() == (tmp_path / "h.aimpk").read_bytes()
