@@ -25,6 +25,7 @@
 #include "wfa_group.hpp"
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
+#include "dp_strip.hpp"
 #include "batch_io.hpp"
 #include "genasm_wave.hpp"
 
@@ -52,7 +53,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6, K_DP_STRIP = 7 };
 
 // What a launch is asked to consume / produce besides the default ABI (ASCII rows in, result_t + ops rows out). A plan
 // honours a mode bit only when its kernel can (Plan::pk / Plan::emits_runs); otherwise the caller runs the conversion
@@ -77,6 +78,7 @@ struct Plan {
     uint32_t chunk_pairs;   // K_WFA_GROUP + BACKTRACE: pairs per compute + traceback launch (their history regions fit the scratch bound)
     aim::GroupCfg gcfg;     // K_WFA_GROUP
     int group_g;
+    int strip_k;            // K_DP_STRIP: cells per lane
     bool pack_first;        // K_WFA_LANE_PK on a batch of ASCII rows: pack_rows_kernel first (scratch: to-do | flag bits | packed P | packed T | general kernel)
     size_t pack_bytes;      // ... bytes of the flag bits + both packed arrays
     bool pk;                // the kernel reads the packed rows of the batch itself (no unpack pass)
@@ -105,6 +107,8 @@ aim::Knobs read_knobs()
     k.wfa_no_ring = env_flag("AIM_WFA_NO_RING");
     k.wfa_slotw = env_int("AIM_WFA_SLOTW", -1);
     k.force_dpwave = env_flag("AIM_FORCE_DPWAVE");
+    k.dpw_legacy = env_flag("AIM_DPW_LEGACY");
+    k.strip_k = env_int("AIM_STRIP_K", -1);
     k.dpw_nw = env_int("AIM_DPW_NW", -1);
     k.dpl_seq_lds = env_int("AIM_DPL_SEQ_LDS", -1);
     k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
@@ -341,8 +345,15 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
     }
     // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
     if (p.read_size > 320 || kn.force_dpwave) {
-        pl->kid = K_DP_WAVE;
         const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
+        if (!kn.dpw_legacy && kn.dpw_nw < 0 && aim::dp_strip_supported(p, cell8, kn)) {
+            // column-strip pipeline (dp_strip.hpp): previous row in registers, packed int16 arithmetic, mailboxes instead of barriers
+            pl->kid = K_DP_STRIP;
+            return aim::dp_strip_plan(p, n_pairs, budget, kn, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total, &pl->strip_k)
+                       ? AIM_OK
+                       : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
+        }
+        pl->kid = K_DP_WAVE;
         return aim::dp_wave_plan(p, n_pairs, budget, kn, cell8, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total)
                    ? AIM_OK
                    : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
@@ -364,6 +375,7 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
     case K_WFA_GROUP: return "wfa_group_kernel";
     case K_DP_LANE: return p_is_nw(&p) ? "nw_lane_kernel" : "swg_lane_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
+    case K_DP_STRIP: return "dp_strip_kernel";
     case K_GENASM: return "genasm_wave_kernel";
     }
     return "";
@@ -376,6 +388,7 @@ int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint6
     if (pl.kid == K_WFA_GROUP) snprintf(extra, sizeof extra, " G=%d hist=%zu chunk=%u fb_grid=%u packed_in=%d runs_out=%d", pl.group_g, pl.hist_bytes, pl.chunk_pairs, pl.fb_grid, (int)pl.pk, (int)pl.emits_runs);
     else if (pl.kid == K_WFA_LANE_PK) snprintf(extra, sizeof extra, " pack_first=%d fb_grid=%u", (int)pl.pack_first, pl.fb_grid);
     else if (pl.kid == K_DP_WAVE) snprintf(extra, sizeof extra, " wavefronts_per_pair=%u", pl.block / 64);
+    else if (pl.kid == K_DP_STRIP) snprintf(extra, sizeof extra, " wavefronts_per_pair=%u cells_per_lane=%d", pl.block / 64, pl.strip_k);
     else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
     else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
     return snprintf(out, cap, "%s n=%u grid=%u block=%u lds=%zu scratch=%zu budget=%llu%s", kernel_name(pl, p), n_pairs, pl.grid,
@@ -558,6 +571,9 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         break;
     case K_DP_WAVE:
         aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);
+        break;
+    case K_DP_STRIP:
+        aim::dp_strip_launch(p, pl.strip_k, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_GENASM:
         aim::genasm_launch(p, pl.grid, pl.lds, ka, stream);

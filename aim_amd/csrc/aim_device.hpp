@@ -57,7 +57,9 @@ __device__ __forceinline__ void store_result(const KArgs &a, uint32_t pair, cons
 {
     if (a.p.flags & AIM_FLAG_RES8) {
         aim_result8_t q;
-        q.idx = r.idx; q.score = r.score;
+        // {idx, score} has no status field: a pair that stopped with a status (only AIM_PAIR_NOMEM can occur without BACKTRACE,
+        // and the plans make it impossible -- see make_plan, score-only ring) reports AIM_SCORE_FAILED instead of a partial score
+        q.idx = r.idx; q.score = r.status == AIM_PAIR_OK ? r.score : AIM_SCORE_FAILED;
         reinterpret_cast<aim_result8_t *>(a.res)[pair] = q;
     } else {
         a.res[pair] = r;
@@ -89,7 +91,9 @@ struct Knobs {
     bool wfa_no_ring = false;     // AIM_WFA_NO_RING=1   wfa_wave: no LDS offset ring
     int wfa_slotw = -1;           // AIM_WFA_SLOTW       wfa_wave: diagonals per ring slot
     bool force_dpwave = false;    // AIM_FORCE_DPWAVE=1  NW/SWG: row-scan kernel also for short reads
-    int dpw_nw = -1;              // AIM_DPW_NW          dp_wave: wavefronts per pair
+    bool dpw_legacy = false;      // AIM_DPW_LEGACY=1    NW/SWG long reads: round 2's row-scan dp_wave_kernel instead of the strip pipeline
+    int strip_k = -1;             // AIM_STRIP_K         dp_strip: cells per lane (16 or 32)
+    int dpw_nw = -1;              // AIM_DPW_NW          dp_wave: wavefronts per pair (implies the row-scan kernel)
     int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: 0 = pattern from global memory
     int dpl_per_cu = -1;          // AIM_DPL_PER_CU      dp_lane: residency sweep
     int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs

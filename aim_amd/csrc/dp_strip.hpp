@@ -1,0 +1,643 @@
+// dp_strip.hpp -- long-read NW / SWG (BASELINE config 4) as a COLUMN-STRIP PIPELINE: one pair per workgroup, every wavefront owns
+// a strip of 64 * K consecutive columns, every lane K consecutive cells of it, and the previous row of those cells stays in the
+// lane's REGISTERS as packed int16 pairs. Rows flow through the wavefronts like a systolic array: wavefront w works on row h
+// while wavefront w + 1 is still on row h - 1; what crosses a strip boundary -- the running prefix minimum of the in-row gap
+// chain and one diagonal cell -- travels through small LDS mailboxes guarded by sequence numbers. No workgroup barrier inside
+// the row loop, no LDS row buffers, no int16 pack / unpack, two cells per vector instruction (v_pk_add_i16 / v_pk_min_i16).
+//
+// Same results as nw_compute / swg_compute (NW/DPU-WRAM/dpu/nw.c:109-153, SWG/DPU-WRAM/dpu/swg.c:121-171) by the argument of
+// dp_wave.hpp: the in-row chain  D[v] = min(M[v-1] + o + e, D[v-1] + e)  (NW: R[v] = min(A[v], R[v-1] + g))  is the prefix
+// minimum  D[v] = v e + min_{j < v} G[j],  G[j] = A[j] + o + e - (j + 1) e,  A = min(diag + cost, I)  -- equal to the reference's
+// cell-by-cell int16 arithmetic exactly when no int16 store can wrap, which dp_strip_exact_ok() proves before this path is
+// taken (it also bounds G, so that the PACKED 16-bit arithmetic cannot wrap either). The reference's flat-table aliasing for
+// plen > tlen (dp_wave.hpp, header) makes cell (h, W) the boundary cell of row h + 1: the lane that owns column W - 1 computes
+// it and posts it to the first wavefront, so a "tailed" pair runs its rows strictly one after the other (the dependence is
+// the reference's own) while a pair without tail pipelines freely. Pairs outside the preconditions take dp_wave.hpp's literal
+// single-lane path; the traceback is dp_wave.hpp's walk over the canonical table slab (unchanged layout).
+//
+// round 2's dp_wave_kernel (row scan, three workgroup barriers per row, 42 lane-operations per cell) stays available behind
+// AIM_DPW_LEGACY=1.
+#pragma once
+
+#include "aim_device.hpp"
+#include "dp_wave.hpp"
+
+namespace aim {
+
+typedef short dps2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dps2 dps_from(uint32_t u) { return __builtin_bit_cast(dps2, u); }
+__device__ __forceinline__ uint32_t dps_bits(dps2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ dps2 dps_splat(int x) { dps2 r; r.x = (short)x; r.y = (short)x; return r; }
+__device__ __forceinline__ dps2 dps_min(dps2 a, dps2 b) { return __builtin_elementwise_min(a, b); }
+
+// "characters differ" per 16-bit field as 0 / 1: unsigned minimum of the xor with 1. Inline assembly on purpose: written with
+// __builtin_elementwise_min the compiler canonicalises umin(x, 1) into a compare + select per HALF (v_cmp_ne_u16_sdwa + v_cndmask:
+// four instructions and a scalar mask pair instead of one v_pk_min_u16).
+__device__ __forceinline__ uint32_t pk_ne01(uint32_t a, uint32_t b, uint32_t ones)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a ^ b), "v"(ones));
+    return r;
+}
+// keep a value in its vector register: the optimiser must not re-derive it from the comparison it came from inside the row loop
+__device__ __forceinline__ void opaque(uint32_t &x) { asm volatile("" : "+v"(x)); }
+
+constexpr int kStripDepth = 8;        // mailbox ring slots per strip (rows a strip may run ahead of its slowest reader)
+constexpr int kStripMaxWaves = 16;
+constexpr short kInf16 = 0x7fff;
+
+// Can any int16 store of the row-scan formulation wrap (dp_wave_exact_ok), or any PACKED intermediate (G = A + o + e - (v + 1) e)?
+__host__ __device__ inline bool dp_strip_exact_ok(const aim_params_t &p, bool swg_int8)
+{
+    if (!dp_wave_exact_ok(p, swg_int8)) return false;
+    const long rs = p.read_size;
+    const long ge = p.algo == AIM_ALGO_NW ? (p.gap_i > p.gap_d ? p.gap_i : p.gap_d) : p.gap_e;
+    const long lo = (long)p.match * rs - (rs + 2) * ge - 4L * (p.gap_o + p.gap_e);   // smallest G (match <= 0)
+    return lo > -32000;
+}
+
+__host__ __device__ inline int dp_strip_stride(int rs, int k) { return (rs + k + 16) & ~7; }
+
+// one 8-byte mailbox word {value, sequence number}; written with one ds_write_b64, polled until the sequence number matches.
+// The pointers are LDS-typed (address_space(3)) on purpose: a volatile access through a GENERIC pointer compiles to a flat
+// instruction with system-scope cache policy and a full s_waitcnt vmcnt(0) -- i.e. every mailbox operation waited for all of the
+// wavefront's outstanding table stores (the first version of this kernel did exactly that).
+struct StripMsg { int val; int seq; };
+typedef int dp_i2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) volatile dp_i2 *lds_msg_p;
+typedef __attribute__((address_space(3))) volatile int *lds_int_p;
+__device__ __forceinline__ void strip_post(lds_msg_p m, int val, int seq)
+{
+    dp_i2 v; v.x = val; v.y = seq;
+    *m = v;
+}
+__device__ __forceinline__ int strip_wait(lds_msg_p m, int seq)
+{
+    for (;;) {
+        const dp_i2 v = *m;
+        if (v.y == seq) return v.x;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// swg_traceback (swg.c:45-119) over the strip kernel's COMPACT table: the M plane (int16, canonical slab) plus two bits per cell --
+// "M != D" and "M != I" -- instead of the I and D planes (2.25 instead of 6 bytes per cell: with all three planes config 4 was bound
+// by its 157 GB of table writes). Everything the reference's walk compares follows from those: in layer M it asks m == D, m == I,
+// then compares m with the diagonal M; entering a gap layer it KNOWS the layer's value (it equals m), and along a gap
+// D[v-1] = D[v] - e (I[h-1] = I[h] - e) whenever the "opened here" test D[v] == M[v-1] + o + e fails -- the recurrence itself,
+// exact because no int16 store wraps (dp_strip_exact_ok). Flags: per row and lane one 8-byte word, cell t = 2 j + hi at bits
+// (hi ? 16 : 0) + 2 (j & 7) of word j >> 3 (row h's words at FL[h * FS + lane]); boundary cells (column 0) in BF[row].
+template <int K>
+__device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, int plen, int tlen, int S, int FS, const int16_t *TM, const uint2 *FL,
+                                                         const unsigned char *BF, int16_t *tile, char *ops, int lane, int &begin_offset, int &status)
+{
+    const int rs = p.read_size, W = tlen + 1;
+    const int OE = p.gap_o + p.gap_e, E = p.gap_e, MATCH = p.match, MISMATCH = p.mismatch;
+    auto addr = [&](int f) -> size_t { const int r = f / W; return (size_t)r * S + 7 + (f - r * W); };
+    int sentinel = plen + tlen - 1;
+    int h = tlen, v = plen;
+    const int cap = 2 * rs;
+    auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
+    // kTR-row x 64-column window of M (dp_wave.hpp's tiled walk, taller: the walk moves up one row per step at most, so a window
+    // of 32 rows lasts ~31 steps -- with 8 rows the refills' HBM round trips were the traceback's time) + the flag words of the
+    // lanes that own those columns
+    constexpr int kTR = 32;
+    int16_t *tileM = tile;                                                   // [kTR rows][8 units][8 cells]
+    uint2 *tileF = reinterpret_cast<uint2 *>(tile + kTR * 64);               // [kTR rows][8 words]
+    int tR = -1, tC0 = 0, tG0 = 0;
+    auto refill = [&](int R, int C) {                             // C >= 1
+        const int u0 = ((C - 1) >> 3) - 7;
+        tR = R; tC0 = 8 * u0 + 1;
+        tG0 = ((tC0 > 1 ? tC0 : 1) - 1) / K;
+#pragma unroll
+        for (int q = 0; q < kTR / 8; ++q) {
+            const int rr = 8 * q + (lane >> 3);                   // row of the window this lane fills in round q
+            const int r = R - rr, u = u0 + (lane & 7);
+            if (r >= 0 && u >= -1) {
+                const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);
+                *reinterpret_cast<uint4 *>(&tileM[(rr * 8 + (lane & 7)) * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
+            }
+            const int g = tG0 + (lane & 7);
+            if (r >= 0 && g < FS) tileF[rr * 8 + (lane & 7)] = FL[(size_t)r * FS + g];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - (kTR - 1) && C - 1 >= tC0 && C <= tC0 + 63; };
+    auto tget = [&](int r, int c) { const int cc = c - tC0; return (int)tileM[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)]; };
+    auto flags_of = [&](uint2 w, int t) { const int j = t >> 1; const uint32_t part = j < 8 ? w.x : w.y; return (int)((part >> (((t & 1) ? 16 : 0) + 2 * (j & 7))) & 3u); };
+    enum { L_M, L_I, L_D };
+    int layer = L_M, gapv = 0;                                   // gapv: the value of the gap layer at the current cell (D or I)
+    while (h > 0 && v > 0) {
+        const int at = W * h + v;
+        const int R = at / W, C = at - R * W;
+        int m, mu, ml, mg, ne;
+        if (C >= 1) {
+            if (!in_tile(R, C)) refill(R, C);
+            m = tget(R, C); mu = tget(R, C - 1); ml = tget(R - 1, C); mg = tget(R - 1, C - 1);
+            const int g = (C - 1) / K;
+            ne = flags_of(tileF[(tR - R) * 8 + (g - tG0)], (C - 1) - g * K);
+        } else {
+            m = TM[addr(at)]; mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
+            ne = BF[R];
+        }
+        if (layer == L_D) {
+            put('D');
+            if (gapv == mu + OE) layer = L_M; else gapv -= E;
+            --v;
+        } else if (layer == L_I) {
+            put('I');
+            if (gapv == ml + OE) layer = L_M; else gapv -= E;
+            --h;
+        } else {
+            if (!(ne & 1)) { layer = L_D; gapv = m; }
+            else if (!(ne & 2)) { layer = L_I; gapv = m; }
+            else if (m == mg + MATCH) { put('M'); --h; --v; }
+            else if (m == mg + MISMATCH) { put('X'); --h; --v; }
+            else { status = AIM_PAIR_SWG_NO_OP; break; }
+        }
+    }
+    if (status == AIM_PAIR_OK) {
+        for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
+        if (h > 0) sentinel -= h;
+        for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
+        if (v > 0) sentinel -= v;
+    }
+    begin_offset = sentinel + 1;
+}
+
+// K: cells per lane; NWMAX: the most wavefronts a workgroup of this instantiation is launched with (its register budget:
+// 4 / 8 wavefronts 256 VGPRs, 12 -> 168, 16 -> 128)
+template <int ALGO, bool BT, int K, int NWMAX>
+__global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
+    constexpr bool SWG = (ALGO == AIM_ALGO_SWG);
+    constexpr int KP = K / 2;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int lane = tid & (kWave - 1), wv = tid >> 6, nw = NT >> 6;
+    const int rs = a.p.read_size;
+    // LDS: pattern | text | last-row dump M, I (also the traceback's tile) | mailboxes
+    const int seqcap = (rs + 79) & ~15;
+    unsigned char *ldsP = reinterpret_cast<unsigned char *>(smem);
+    unsigned char *ldsT = ldsP + seqcap;
+    const int rowcap = (rs + 47) & ~7;
+    int16_t *rowM = reinterpret_cast<int16_t *>(ldsT + seqcap);
+    int16_t *rowI = rowM + rowcap;
+    const int rowbytes = (2 * rowcap * 2 > 6 * 1024 ? 2 * rowcap * 2 : 6 * 1024);   // (the tracebacks' tiles live here afterwards: up to 6 KB)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte offset of the dynamic segment
+    const uint32_t mb0 = lds0 + (uint32_t)(2 * seqcap + rowbytes);
+    const lds_msg_p mbC = (lds_msg_p)(uintptr_t)mb0;                                                  // [kStripMaxWaves][kStripDepth]: strip w's minimum of G over its columns, per row
+    const lds_msg_p mbD = mbC + kStripMaxWaves * kStripDepth;                                          // ... diagonal cell M[h-1][c0_w - 1]
+    const lds_int_p cons = (lds_int_p)(uintptr_t)(mb0 + 2 * kStripMaxWaves * kStripDepth * 8);         // [kStripMaxWaves] last row whose messages strip w has consumed
+    const lds_int_p Bl = cons + kStripMaxWaves;                                                        // [kStripDepth] boundary cells {M, I, D, seq} by row (a ring: a strip
+                                                                                                       // may still be waiting for B(h) when the owner posts B(h+1))
+    const lds_int_p tl = Bl + 4 * kStripDepth;                                                                       // last row's tail inputs {M, D of cell W-1, diag} + score
+    // table slab: canonical rows of stride S, layers as planes (dp_wave.hpp); S leaves room for a whole K-cell group that starts
+    // inside the row, so that every lane stores 16-byte vectors (cells beyond the row are written and never read)
+    const int S = dp_strip_stride(rs, K);
+    const size_t plane = (size_t)S * (size_t)(rs + 3);
+    int16_t *tb = reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
+    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;      // (I / D planes: the literal path only)
+    uint2 *FL = reinterpret_cast<uint2 *>(tb + plane);            // SWG row-strip path: the compact table's flag words, [row][FS]
+    unsigned char *BF = reinterpret_cast<unsigned char *>(tb + 2 * plane);   // ... and the boundary cells' flags, [row]
+    const int FS = rs / K + 2;                    // flag words per row: one per lane that can hold a column (8 FS <= 2 S: the words fit the I plane's place)
+    const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
+    const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
+    const int GE = SWG ? E : GD;                 // step of the in-row chain
+    const bool exact_ok = dp_strip_exact_ok(a.p, false);
+    const int v0 = 1 + (wv * kWave + lane) * K;  // first column of this lane
+
+    for (uint32_t it = 0;; ++it) {
+        uint32_t pair;
+        if (!xcd_unit(a.n_pairs, it, &pair)) break;
+        const aim_request_t rq = load_request(a, pair);
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
+        const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
+        char *ops = BT ? a.ops + (uint64_t)pair * 2 * rs : nullptr;
+        const int W = tlen + 1;
+        int score = 0, status = AIM_PAIR_OK;
+        int begin_offset = plen + tlen - 1;
+        const int end_offset = plen + tlen;
+        __syncthreads();                          // the previous pair's traceback is done with the LDS it used
+        if (BT && SWG) {   // memset(cigar->operations, 'M', 2*READ_SIZE), swg.c:261
+            uint32_t *o4 = reinterpret_cast<uint32_t *>(ops);
+            for (int w = tid; w < (rs >> 1); w += NT) o4[w] = 0x4D4D4D4Du;
+        }
+        const bool literal = !exact_ok || plen > 2 * tlen || (min(plen, W - 1) > nw * kWave * K);
+
+        if (literal) {
+            if (tid == 0) { score = dp_literal_fill<SWG, false>(a.p, plen, tlen, gP, gT, TM, TI, TD); tl[3] = score; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SWG's ops prefill by all threads completes before the traceback patches it
+            __syncthreads();
+            score = tl[3];
+        } else {
+            // ---------------------------------------------------------------------------------------- strip pipeline
+            for (int i = tid * 4; i < seqcap; i += NT * 4) {   // sequences into LDS, zero beyond their length (dword granularity)
+                uint32_t wp = 0, wt = 0;
+                for (int b = 0; b < 4; ++b) {
+                    if (i + b < plen) wp |= (uint32_t)gP[i + b] << (8 * b);
+                    if (i + b < tlen) wt |= (uint32_t)gT[i + b] << (8 * b);
+                }
+                *reinterpret_cast<uint32_t *>(ldsP + i) = wp;
+                *reinterpret_cast<uint32_t *>(ldsT + i) = wt;
+            }
+            for (int i = tid; i < 2 * kStripMaxWaves * kStripDepth; i += NT) strip_post(mbC + i, 0, 0);   // (mbD follows mbC)
+            if (tid < kStripMaxWaves) cons[tid] = 0;
+            if (tid < kStripDepth) Bl[4 * tid + 3] = 0;
+            const int Rr = min(plen, W - 1);          // regular columns 1..Rr
+            const bool has_tail = plen >= W;
+            // row 0 in registers (and its table image); boundary column of the table
+            dps2 Mp[KP], Ip[KP], cD[KP], vmask[KP];
+            int nvalid = Rr - v0 + 1;                  // cells of this lane inside the row
+            nvalid = nvalid < 0 ? 0 : (nvalid > K ? K : nvalid);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int va = v0 + 2 * j, vb = va + 1;
+                dps2 m, d;
+                if (SWG) { m.x = (short)(O + va * E); m.y = (short)(O + vb * E); }
+                else { m.x = (short)(va * GD); m.y = (short)(vb * GD); }
+                d.x = (short)(va * GE); d.y = (short)(vb * GE);
+                Mp[j] = m;
+                Ip[j] = dps_splat(MAXS);
+                cD[j] = d;
+                dps2 vm; vm.x = (short)((2 * j < nvalid) ? -1 : 0); vm.y = (short)((2 * j + 1 < nvalid) ? -1 : 0);
+                uint32_t vmb = dps_bits(vm);
+                opaque(vmb);
+                vmask[j] = dps_from(vmb);
+            }
+            if (BT) {
+                for (int v = tid; v <= Rr; v += NT) {
+                    const int m0 = SWG ? (v ? O + v * E : 0) : v * GD;
+                    TM[7 + v] = (int16_t)m0;
+                }
+                for (int h = 1 + tid; h <= tlen; h += NT) {   // row-init boundary cells flat[W*h]: M = I = o + h e, D = MAX_SCORE
+                    const size_t at = (size_t)h * S + 7;
+                    if (SWG) { TM[at] = (int16_t)(O + h * E); BF[h] = (unsigned char)((O + h * E) != MAXS ? 1 : 0); }
+                    else TM[at] = (int16_t)(h * GI);
+                }
+            }
+            // (the row-init stores above vs the tail owner's store to the same boundary cell below: write after write across
+            // wavefronts through HBM -- made explicit exactly as in dp_wave.hpp: every store has completed before the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // this lane's pattern characters as 16-bit fields, two per dword (the cost of a cell is a packed compare away)
+            uint32_t pc16[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) pc16[j] = (uint32_t)ldsP[v0 - 1 + 2 * j] | ((uint32_t)ldsP[v0 + 2 * j] << 16);
+            const bool tail_owner = has_tail && v0 <= Rr && Rr < v0 + K;   // this lane owns column W - 1 = Rr
+            const int tail_t = Rr - v0;                                     // ... as its cell tail_t
+            const int pchW = has_tail ? (int)ldsP[W - 1] : 0;
+            // boundary cell of the current row (flat[W*h]): analytic unless the pair has a tail
+            int BM = 0, BI = 0, BD = 0, BMprev = 0;                          // B(h) and B(h-1).M (column 0 of the previous row; row 0: 0)
+            const dps2 OEp = dps_splat(OE), Ep = dps_splat(E), GIp = dps_splat(GI);
+            dps2 c1[KP];                                                    // G = A - c1: SWG (v+1)e - (o+e); NW v g
+#pragma unroll
+            for (int j = 0; j < KP; ++j) c1[j] = cD[j] + dps_splat(SWG ? (E - OE) : 0);
+            const dps2 costD = dps_splat(MISMATCH - (SWG ? MATCH : 0)), costM = dps_splat(SWG ? MATCH : 0);
+            uint32_t ones = 0x00010001u;
+            opaque(ones);
+            int tailM_M = 0, tailM_D = 0, tail_diag = 0;                    // the tail owner's {M, D} of cell (h, W-1) and M of (h-1, W-1)
+            const bool owner_wave = __ballot(tail_owner) != 0ull;           // wave-uniform: this wavefront holds the tail owner
+            const bool wave_full = __ballot(nvalid != K) == 0ull;           // wave-uniform: every cell of this wavefront lies inside the row
+            int safe_row = 0;                                               // rows up to safe_row + kStripDepth may be posted without asking (lane 0)
+            // cell t of a packed register row, t a per-lane value: a binary select tree over the dwords (a dynamic register index
+            // would go through scratch; a flat chain of K compares keeps K lane masks alive in scalar registers)
+            auto pick = [&](const dps2 (&arr)[KP], int t) {
+                uint32_t v[KP];
+#pragma unroll
+                for (int j = 0; j < KP; ++j) v[j] = dps_bits(arr[j]);
+                const int d = t >> 1;
+#pragma unroll
+                for (int step = 1; step < KP; step <<= 1) {
+                    const bool odd = (d & step) != 0;
+#pragma unroll
+                    for (int j = 0; j + step < KP; j += 2 * step) v[j] = odd ? v[j + step] : v[j];
+                    if ((KP / step) & 1) { /* an unpaired block stays where it is */ }
+                }
+                const uint32_t w = v[0];
+                return (t & 1) ? (int)(int16_t)(w >> 16) : (int)(int16_t)(w & 0xffffu);
+            };
+
+            for (int h = 1; h <= tlen; ++h) {
+                const int slot = h & (kStripDepth - 1);
+                const uint32_t tch2 = (uint32_t)ldsT[h - 1] * 0x00010001u;
+                // ---- diagonal input of this lane's first cell: M[h-1][v0 - 1]
+                int dfirst;
+                {
+                    const int mine_last = (int)Mp[KP - 1].y;
+                    dfirst = __builtin_amdgcn_update_dpp(0, mine_last, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                    if (lane == 0) {
+                        if (wv == 0) dfirst = BMprev;
+                        else if (h == 1) dfirst = SWG ? O + (v0 - 1) * E : (v0 - 1) * GD;
+                        else dfirst = strip_wait(mbD + wv * kStripDepth + slot, h);
+                    }
+                }
+                // ---- pre-carry: I, A, G of this lane's K cells, two per instruction (nothing here depends on this row's carry or
+                // boundary cell: in a tailed pair it runs while the previous row's last strip is still finishing)
+                dps2 A[KP], Iv[KP], G[KP];
+                dps2 gmin = dps_splat(kInf16);
+                auto precarry = [&](auto MASKED) {
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) {
+                        const uint32_t up = dps_bits(Mp[j]);
+                        const uint32_t prev = j ? dps_bits(Mp[j - 1]) : ((uint32_t)(uint16_t)dfirst << 16);
+                        const dps2 diag = dps_from(__builtin_amdgcn_alignbit(up, prev, 16));       // {M[v-1], M[v]} of the previous row
+                        // cost per cell: characters differ -> 1 (unsigned min with 1), times (MISMATCH - MATCH), plus MATCH
+                        const dps2 f = dps_from(pk_ne01(pc16[j], tch2, ones));
+                        const dps2 sub = f * costD + (diag + costM);
+                        dps2 ins;
+                        if (SWG) ins = dps_min(Mp[j] + OEp, Ip[j] + Ep);
+                        else ins = Mp[j] + GIp;
+                        Iv[j] = ins;
+                        A[j] = dps_min(sub, ins);
+                        dps2 g = A[j] - c1[j];
+                        if (decltype(MASKED)::value) g = dps_from((dps_bits(g) & dps_bits(vmask[j])) | (0x7fff7fffu & ~dps_bits(vmask[j])));
+                        G[j] = g;
+                        gmin = dps_min(gmin, g);
+                    }
+                };
+                if (wave_full) precarry(std::false_type{});
+                else precarry(std::true_type{});
+                int lane_min = min((int)gmin.x, (int)gmin.y);
+                if (lane_min == kInf16) lane_min = kDpInf;
+                int total;
+                const int lane_pre = wave_excl_scan_min(lane_min, lane, &total);
+                // ---- this strip's minimum to every strip on its right (a broadcast, not a chain: strip w reads the w totals on
+                // its left in one LDS round trip)
+                if (wv + 1 < nw && lane == 0) {
+                    if (h - safe_row >= kStripDepth) {    // the ring slot of row h was last used by row h - depth: has every strip on the right read it?
+                        for (;;) {
+                            int m = 0x7fffffff;
+                            for (int u = wv + 1; u < nw; ++u) m = min(m, (int)cons[u]);
+                            if (h - m < kStripDepth) { safe_row = m; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    strip_post(mbC + wv * kStripDepth + slot, total, h);
+                }
+                // ---- B(h): the boundary cell of this row
+                if (h == 1 || !has_tail) {
+                    if (SWG) { BM = O + h * E; BI = BM; BD = MAXS; }
+                    else { BM = h * GI; BI = BD = 0; }
+                } else {
+                    const lds_int_p bs = Bl + 4 * slot;
+                    while (bs[3] != h) __builtin_amdgcn_s_sleep(1);     // posted by the lane that owns column W - 1 at the end of row h - 1
+                    BM = bs[0]; BI = bs[1]; BD = bs[2];
+                }
+                // ---- the prefix minimum over everything left of this strip: G[0] and the totals of the strips on the left
+                int carry_in = SWG ? min(BD, BM + O) : BM;             // G[0]
+                if (wv > 0) {
+                    int t_u = kDpInf;
+                    if (lane < wv) t_u = strip_wait(mbC + lane * kStripDepth + slot, h);
+                    carry_in = min(carry_in, wave_min_i32(t_u));
+                    if (lane == 0) cons[wv] = h;                        // every message of row h is read
+                }
+                // ---- post-carry: D / R and M of the K cells; the new row replaces the old one in the registers
+                const int pre = min(carry_in, lane_pre);
+                dps2 c = dps_splat(pre);
+                dps2 Do[KP];
+                const int diag_keep = owner_wave ? pick(Mp, tail_t) : 0;   // M[h-1][W-1] (before the row is replaced)
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    dps2 s_; s_.x = kInf16; s_.y = G[j].x;
+                    const dps2 prej = dps_min(c, s_);                      // {pre(2j), pre(2j+1)}
+                    c = dps_splat(min((int)prej.y, (int)G[j].y));
+                    Do[j] = prej + cD[j];
+                    Mp[j] = dps_min(A[j], Do[j]);
+                    if (SWG) Ip[j] = Iv[j];
+                }
+                // ---- hand the next row's diagonal cell to the next strip
+                if (wv + 1 < nw && lane == kWave - 1) strip_post(mbD + (wv + 1) * kStripDepth + ((h + 1) & (kStripDepth - 1)), (int)Mp[KP - 1].y, h + 1);
+                BMprev = BM;
+                // ---- first tail cell (h, W): the boundary cell of row h + 1 (rows before the last; the last row's tail is walked below)
+                if (owner_wave) {
+                    const int upM = pick(Mp, tail_t), upD = pick(Do, tail_t);
+                    tailM_M = upM; tailM_D = upD; tail_diag = diag_keep;
+                    if (tail_owner && h < tlen) {
+                        const int tch = (int)(tch2 & 0xffu);
+                        int cM, cI, cDd;
+                        if (SWG) {
+                            cDd = min(upM + OE, upD + E);
+                            cI = min(BM + OE, BI + E);
+                            cM = min(diag_keep + ((pchW == tch) ? MATCH : MISMATCH), min(cI, cDd));
+                        } else {
+                            cI = cDd = 0;
+                            cM = min(diag_keep + ((pchW == tch) ? 0 : MISMATCH), min(BM + GI, upM + GD));
+                        }
+                        const lds_int_p bs = Bl + 4 * ((h + 1) & (kStripDepth - 1));
+                        bs[0] = cM; bs[1] = cI; bs[2] = cDd;
+                        bs[3] = h + 1;                                     // (same-wavefront LDS writes complete in order)
+                        if (BT) {
+                            const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical home of flat[W*h + W]
+                            TM[tdst] = (int16_t)cM;
+                            if (SWG) BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0));
+                        }
+                    }
+                }
+                // ---- table (BT): 16-byte stores where the lane's cells are all inside the row (off the critical path: after the posts)
+                if (BT && nvalid > 0) {
+                    const size_t trow = (size_t)h * S + 7 + v0;
+#pragma unroll
+                    for (int q = 0; q < K / 8; ++q)
+                        *reinterpret_cast<uint4 *>(&TM[trow + 8 * q]) = make_uint4(dps_bits(Mp[4 * q]), dps_bits(Mp[4 * q + 1]), dps_bits(Mp[4 * q + 2]), dps_bits(Mp[4 * q + 3]));
+                    if (SWG) {   // two bits per cell instead of the I and D planes: M != D, M != I (unsigned min with 1 of the xor)
+                        uint32_t fw[2] = {0u, 0u};
+#pragma unroll
+                        for (int j = 0; j < KP; ++j) {
+                            const uint32_t nd = pk_ne01(dps_bits(Mp[j]), dps_bits(Do[j]), ones);
+                            const uint32_t ni = pk_ne01(dps_bits(Mp[j]), dps_bits(Iv[j]), ones);
+                            fw[j >> 3] |= (nd | (ni << 1)) << (2 * (j & 7));
+                        }
+                        FL[(size_t)h * FS + wv * kWave + lane] = make_uint2(fw[0], fw[1]);
+                    }
+                }
+            }
+            // ---- after the last row: its regular part into LDS (score; the tail walk reads it), then the reference's tail cells
+            {
+                if (nvalid > 0) {
+#pragma unroll
+                    for (int t = 0; t < K; ++t)
+                        if (t < nvalid) {
+                            rowM[v0 + t] = (t & 1) ? Mp[t >> 1].y : Mp[t >> 1].x;
+                            if (SWG) rowI[v0 + t] = (t & 1) ? Ip[t >> 1].y : Ip[t >> 1].x;
+                        }
+                }
+                if (tail_owner) { tl[0] = tailM_M; tl[1] = tailM_D; tl[2] = tail_diag; }
+                if (tid == 0) { rowM[0] = (int16_t)BM; if (SWG) rowI[0] = (int16_t)BI; }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // table / ops stores of every wavefront before the traceback reads them (dp_wave.hpp)
+            __syncthreads();
+            if (has_tail && tlen >= 1) {
+                if (wv == 0) {
+                    // cells v = W .. plen of the LAST row, sequentially (wave-uniform), with the aliased inputs (dp_wave.hpp)
+                    const int h = tlen;
+                    const int tch = ldsT[h - 1];
+                    // B(tlen): the first wavefront's copy (lane-uniform for wave 0 unless it holds the tail owner)
+                    const int bM = BM, bI = BI;   // every wavefront read B(tlen) at the start of the last row
+                    int upM = tl[0], upD = tl[1];
+                    int lastM = 0;
+                    int tw_g = -1;                    // flag word being assembled for the tail cells
+                    uint32_t tw_x = 0u, tw_y = 0u;
+                    const size_t tdst = (size_t)(h + 1) * S + 7;
+                    for (int v = W; v <= plen; ++v) {
+                        int leftM, leftI, diagM;
+                        if (v == W) { leftM = bM; leftI = bI; diagM = tl[2]; }
+                        else {
+                            leftM = rowM[v - W];
+                            leftI = SWG ? (int)rowI[v - W] : 0;
+                            diagM = (v - 1 == W) ? bM : (int)rowM[v - 1 - W];
+                        }
+                        const int pch = ldsP[v - 1];
+                        int cM, cI, cDd;
+                        if (SWG) {
+                            cDd = min(upM + OE, upD + E);
+                            cI = min(leftM + OE, leftI + E);
+                            cM = min(diagM + ((pch == tch) ? MATCH : MISMATCH), min(cI, cDd));
+                        } else {
+                            cI = cDd = 0;
+                            cM = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(leftM + GI, upM + GD));
+                        }
+                        if (BT) {
+                            if (lane == 0) TM[tdst + (v - W)] = (int16_t)cM;
+                            if (SWG) {   // the flags of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array)
+                                const uint32_t ne = (cM != cDd ? 1u : 0u) | (cM != cI ? 2u : 0u);
+                                const int C = v - W;
+                                if (C == 0) { if (lane == 0) BF[h + 1] = (unsigned char)ne; }
+                                else {
+                                    const int g = (C - 1) / K, t = (C - 1) - g * K, j = t >> 1;
+                                    if (g != tw_g) {
+                                        if (tw_g >= 0 && lane == 0) FL[(size_t)(h + 1) * FS + tw_g] = make_uint2(tw_x, tw_y);
+                                        tw_g = g; tw_x = tw_y = 0u;
+                                    }
+                                    const uint32_t bits = ne << (((t & 1) ? 16 : 0) + 2 * (j & 7));
+                                    if (j < 8) tw_x |= bits; else tw_y |= bits;
+                                }
+                            }
+                        }
+                        upM = cM; upD = cDd;
+                        lastM = cM;
+                    }
+                    if (BT && SWG && tw_g >= 0 && lane == 0) FL[(size_t)(h + 1) * FS + tw_g] = make_uint2(tw_x, tw_y);
+                    if (lane == 0) tl[3] = lastM;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                score = tl[3];
+            } else {
+                score = (plen >= 1 && tlen >= 1) ? (int)rowM[plen] : 0;
+            }
+            if (plen == 0 || tlen == 0) score = 0;
+            __syncthreads();                          // everyone has read rowM / tl before the traceback reuses the area as its tile
+        }
+
+        if (BT && wv == 0) {
+            if (SWG && !literal) dp_traceback_swg_compact<K>(a.p, plen, tlen, S, FS, TM, FL, BF, rowM, ops, lane, begin_offset, status);
+            else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
+        }
+        if (tid == 0) {
+            aim_result_t r;
+            r.max_operations = plen + tlen;
+            r.begin_offset = begin_offset;
+            r.end_offset = end_offset;
+            r.score = score;
+            r.status = status;
+            r.idx = rq.idx;
+            store_result(a, pair, r);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shapes: K cells per lane (16 / 24 / 32) x nw wavefronts covering READ_SIZE columns. A row costs every wavefront a fixed
+// overhead (scan, mailboxes, boundary cell) plus K cells, and the CU's four SIMDs each take ceil(nw / 4) of the wavefronts:
+// the shape with the cheapest BUSIEST SIMD wins (config 4, READ_SIZE 10 112: 16 x 10 -> 3 wavefronts on two SIMDs; 24 x 7 -> 2).
+// AIM_STRIP_K forces K for experiments.
+struct StripShape { int k, nw, nwmax; };
+inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *sh, uint32_t n_pairs = 0)
+{
+    const int rs = p.read_size;
+    int best_k = 0, best_nw = 0;
+    long best_cost = 0;
+    for (int k : {16, 24, 32}) {
+        if (kn.strip_k > 0 && kn.strip_k != k) continue;
+        const int nw = (rs + kWave * k - 1) / (kWave * k);
+        if (nw > (k == 16 ? 12 : 8)) continue;
+        // few pairs (about one per CU, config 4): the busiest SIMD's wavefronts set the time; many pairs: the total work does
+        const long cost = (n_pairs > 1024 ? (long)nw : (long)((nw + 3) / 4)) * (110 + 10L * k);
+        if (!best_k || cost < best_cost) { best_k = k; best_nw = nw; best_cost = cost; }
+    }
+    if (!best_k) return false;
+    sh->k = best_k; sh->nw = best_nw;
+    sh->nwmax = best_k == 16 ? (best_nw <= 4 ? 4 : (best_nw <= 8 ? 8 : 12)) : 8;
+    return true;
+}
+
+inline bool dp_strip_supported(const aim_params_t &p, bool cell8, const Knobs &kn)
+{
+    if (cell8) return false;                                   // int8 SWG cells wrap by design: literal path of dp_wave.hpp
+    StripShape sh;
+    return dp_strip_shape(p, kn, &sh) && dp_strip_exact_ok(p, false);
+}
+
+inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, const Knobs &kn, uint32_t *grid, uint32_t *block, size_t *lds,
+                          uint64_t *scratch_per_wg, size_t *scratch_total, int *k_out)
+{
+    const uint64_t rs = (uint64_t)p.read_size;
+    const bool swg = p.algo == AIM_ALGO_SWG;
+    StripShape sh;
+    if (!dp_strip_shape(p, kn, &sh, n_pairs)) return false;
+    *k_out = sh.k;
+    const uint64_t S = (uint64_t)dp_strip_stride((int)rs, sh.k);
+    uint64_t per = (swg ? 3 : 1) * S * (rs + 3) * 2;              // int16 planes: the traceback's table; score-only launches touch it on the literal path only
+    per = (per + 255) & ~255ull;
+    const int nw = sh.nw;
+    *block = (uint32_t)(kWave * nw);
+    const uint64_t seqcap = (rs + 79) & ~15ull, rowcap = (rs + 47) & ~7ull;
+    const uint64_t rowbytes = std::max<uint64_t>(2 * rowcap * 2, 6 * 1024);
+    *lds = (size_t)(2 * seqcap + rowbytes + 2 * kStripMaxWaves * kStripDepth * sizeof(StripMsg) + kStripMaxWaves * 4 + 16 * kStripDepth + 64);
+    if (*lds > 160 * 1024) return false;
+    // resident workgroups per CU: LDS, and the wavefronts the instantiation's register budget admits (64 * NWMAX threads per CU-quarter...)
+    // (registers: K = 16: NW 82-114, SWG 117, SWG with CIGAR 160 VGPRs; K = 32: 130-240)
+    const bool heavy = swg && (p.flags & AIM_FLAG_BACKTRACE);
+    const uint32_t waves_per_cu = sh.k >= 24 ? 8u : (heavy ? 12u : 16u);
+    const uint32_t per_cu = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves_per_cu / (uint32_t)nw, (uint64_t)lds_workgroups_per_cu(*lds)));
+    uint32_t g = 256 * per_cu;
+    const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
+    if (g > need) g = need < 8u ? 8u : need;
+    while (g > 8 && per * g > budget) g -= 8;
+    if (per * g > budget) return false;
+    *grid = g;
+    *scratch_per_wg = per;
+    *scratch_total = (size_t)(per * g);
+    return true;
+}
+
+// k: the plan's cells per lane (dp_strip_plan); the workgroup size gives the wavefront count
+inline void dp_strip_launch(const aim_params_t &p, int k, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    StripShape sh;
+    sh.k = k; sh.nw = (int)(block / kWave);
+    sh.nwmax = k == 16 ? (sh.nw <= 4 ? 4 : (sh.nw <= 8 ? 8 : 12)) : 8;
+#define AIM_STRIP(KERNEL)                                                                             \
+    do {                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(block), lds, s, ka);                             \
+    } while (0)
+#define AIM_STRIP_K(ALGOV, BTV)                                                                      \
+    do {                                                                                             \
+        if (sh.k == 32) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 32, 8>));                             \
+        else if (sh.k == 24) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 24, 8>));                        \
+        else if (sh.nwmax == 4) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 16, 4>));                     \
+        else if (sh.nwmax == 8) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 16, 8>));                     \
+        else AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 16, 12>));                                       \
+    } while (0)
+    if (p.algo == AIM_ALGO_NW) { if (bt) AIM_STRIP_K(AIM_ALGO_NW, true); else AIM_STRIP_K(AIM_ALGO_NW, false); }
+    else { if (bt) AIM_STRIP_K(AIM_ALGO_SWG, true); else AIM_STRIP_K(AIM_ALGO_SWG, false); }
+#undef AIM_STRIP_K
+#undef AIM_STRIP
+}
+
+}  // namespace aim

@@ -69,6 +69,174 @@ __host__ __device__ inline bool dp_wave_exact_ok(const aim_params_t &p, bool swg
     return hi < 32000 && lo > -32000 && p.max_score < 32000;
 }
 
+// The reference's loops verbatim over a flat table (plane-separated) in the slab: one lane, correct for everything (aliased rows,
+// int8 / wrapping cells), slow, rare. Returns the score (nw.c:109-153, swg.c:121-171).
+template <bool SWG, bool CELL8>
+__device__ __forceinline__ int dp_literal_fill(const aim_params_t &p, int plen, int tlen, const unsigned char *gP, const unsigned char *gT,
+                                               int16_t *TM, int16_t *TI, int16_t *TD)
+{
+    typedef typename std::conditional<CELL8, int8_t, int16_t>::type cell_t;
+    const int O = p.gap_o, E = p.gap_e, OE = O + E, MATCH = p.match, MISMATCH = p.mismatch, GD = p.gap_d, GI = p.gap_i, MAXS = p.max_score;
+    const int W = tlen + 1;
+    int score = 0;
+
+    if (!SWG) {
+        int cell = 0;
+        TM[0] = 0;
+        for (int v = 1; v <= plen; ++v) { cell += GD; TM[v] = (int16_t)cell; }
+        cell = 0;
+        for (int h = 1; h <= tlen; ++h) { cell += GI; TM[(size_t)W * h] = (int16_t)cell; }
+        int16_t sc = 0;
+        for (int h = 1; h <= tlen; ++h) {
+            const int tch = gT[h - 1];
+            const size_t row = (size_t)W * h, prow = row - W;
+            for (int v = 1; v <= plen; ++v) {
+                const int16_t del = (int16_t)(TM[row + v - 1] + GD);
+                const int16_t ins = (int16_t)(TM[prow + v] + GI);
+                const int16_t mm = (int16_t)(TM[prow + v - 1] + ((gP[v - 1] == tch) ? 0 : MISMATCH));
+                sc = TM[row + v] = min(mm, min(ins, del));
+            }
+        }
+        score = sc;
+    } else {
+        TD[0] = (cell_t)MAXS; TI[0] = (cell_t)MAXS; TM[0] = 0;
+        for (int v = 1; v <= plen; ++v) { const cell_t d = (cell_t)(O + v * E); TD[v] = d; TI[v] = (cell_t)MAXS; TM[v] = d; }
+        for (int h = 1; h <= tlen; ++h) {
+            const cell_t i = (cell_t)(O + h * E);
+            TD[(size_t)W * h] = (cell_t)MAXS; TI[(size_t)W * h] = i; TM[(size_t)W * h] = i;
+        }
+        for (int h = 1; h <= tlen; ++h) {
+            const int tch = gT[h - 1];
+            const size_t row = (size_t)W * h, prow = row - W;
+            for (int v = 1; v <= plen; ++v) {
+                const cell_t del = min((cell_t)((cell_t)TM[row + v - 1] + OE), (cell_t)((cell_t)TD[row + v - 1] + E));
+                const cell_t ins = min((cell_t)((cell_t)TM[prow + v] + OE), (cell_t)((cell_t)TI[prow + v] + E));
+                const cell_t mm = (cell_t)((cell_t)TM[prow + v - 1] + ((gP[v - 1] == tch) ? MATCH : MISMATCH));
+                const cell_t m = min(mm, min(ins, del));
+                TD[row + v] = del; TI[row + v] = ins; TM[row + v] = m;
+                score = m;
+            }
+        }
+    }
+    return score;
+}
+
+// nw_traceback / swg_traceback (nw.c:67-107, swg.c:45-119) over flat indices, by ONE wavefront (wave-uniform walk); the table is
+// the canonical slab (flat index f lives at row f / W, column f % W of stride S, + 7) unless `literal` (flat planes). `tile`:
+// 3 x 512 int16 of LDS for the 8-row x 64-column window the walk reads from when use_tile.
+template <bool SWG>
+__device__ __forceinline__ void dp_traceback(const aim_params_t &p, bool literal, int plen, int tlen, int S, const int16_t *TM, const int16_t *TI,
+                                             const int16_t *TD, int16_t *tile, bool use_tile_in, char *ops, int lane, int &begin_offset, int &status)
+{
+    const int rs = p.read_size, W = tlen + 1, end_offset = plen + tlen;
+    const int OE = p.gap_o + p.gap_e, MATCH = p.match, MISMATCH = p.mismatch, GD = p.gap_d, GI = p.gap_i;
+#ifdef AIM_DPW_NO_TILE
+    const bool use_tile = false;     // diagnostic builds: per-step reads only
+#else
+    const bool use_tile = use_tile_in;
+#endif
+
+                // nw_traceback / swg_traceback over flat indices (first wavefront); canonical slab unless literal
+                auto addr = [&](int f) -> size_t {
+                    if (literal) return (size_t)f;
+                    const int r = f / W;
+                    return (size_t)r * S + 7 + (f - r * W);
+                };
+                int sentinel = end_offset - 1;
+                int h = tlen, v = plen;
+    #ifdef AIM_DPW_DIAG_NO_TRACEBACK
+                h = 0; v = 0;      // diagnostic builds only (results are wrong)
+    #endif
+                const int cap = 2 * rs;
+                auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
+                // Tiled walk. The walk is wave-uniform and the slab is canonical -- flat index f lives at (R, C) = (f / W,
+                // f % W) -- so whenever C >= 1 the cells a step compares are (R, C), (R, C-1), (R-1, C), (R-1, C-1). The 64
+                // lanes fetch an 8-row x 64-column window ending at (R, C) with ONE 16-B load per lane and plane into LDS
+                // (the row buffers are dead by now) and the walk reads from it until it leaves: a refill every >= 7 steps
+                // instead of an HBM round trip per step (decomposition: the walk was 27 % / 20 % of NW / SWG at l = 1000).
+                // Steps on the boundary column (C == 0) and the literal path keep the per-step reads.
+                int16_t *tileM = tile, *tileI = tile + 512, *tileD = tile + 1024;   // [8 rows][8 units][8 cells]
+                int tR = -1, tC0 = 0;                                                       // rows tR-7..tR, columns tC0..tC0+63
+                auto refill = [&](int R, int C) {                                           // C >= 1
+                    const int u0 = ((C - 1) >> 3) - 7;                                      // units of 8 columns: unit u = 8u+1 .. 8u+8
+                    tR = R; tC0 = 8 * u0 + 1;
+                    const int r = R - (lane >> 3), u = u0 + (lane & 7);
+                    if (r >= 0 && u >= -1) {                                                // unit -1: column 0 (and row padding)
+                        const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);               // == r*S + 7 + (8u+1), 16-B aligned
+                        *reinterpret_cast<uint4 *>(&tileM[lane * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
+                        if (SWG) {
+                            *reinterpret_cast<uint4 *>(&tileI[lane * 8]) = *reinterpret_cast<const uint4 *>(&TI[e]);
+                            *reinterpret_cast<uint4 *>(&tileD[lane * 8]) = *reinterpret_cast<const uint4 *>(&TD[e]);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // one wavefront: in-order LDS, no barrier
+                };
+                auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - 7 && C - 1 >= tC0 && C <= tC0 + 63; };
+                auto tget = [&](const int16_t *t, int r, int c) {
+                    const int cc = c - tC0;
+                    return (int)t[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)];
+                };
+                if (!SWG) {
+                    // the three neighbours are fetched together (one HBM round trip per step instead of up to three dependent
+                    // ones) and the cell moved to becomes the next step's table[at]: same cells, values and comparison order
+                    int c = (h > 0 && v > 0) ? (int)TM[addr(W * h + v)] : 0;
+                    while (h > 0 && v > 0) {
+                        const int at = W * h + v;
+                        const int R = at / W, C = at - R * W;
+                        int cl, cu, cg;
+                        if (use_tile && C >= 1) {
+                            if (!in_tile(R, C)) refill(R, C);
+                            cl = tget(tileM, R, C - 1); cu = tget(tileM, R - 1, C); cg = tget(tileM, R - 1, C - 1);
+                        } else {
+                            cl = TM[addr(at - 1)]; cu = TM[addr(at - W)]; cg = TM[addr(at - W - 1)];
+                        }
+                        if (c == cl + GD) { put('D'); --v; c = cl; }
+                        else if (c == cu + GI) { put('I'); --h; c = cu; }
+                        else { put((c == cg + MISMATCH) ? 'X' : 'M'); --h; --v; c = cg; }
+                    }
+                } else {
+                    enum { L_M, L_I, L_D };
+                    int layer = L_M;
+                    while (h > 0 && v > 0) {
+                        const int at = W * h + v;
+                        // everything any branch of this step compares, fetched together (one round trip, not a chain)
+                        const int R = at / W, C = at - R * W;
+                        int m, cdd, cii, mu, ml, mg;
+                        if (use_tile && C >= 1) {
+                            if (!in_tile(R, C)) refill(R, C);
+                            m = tget(tileM, R, C); cdd = tget(tileD, R, C); cii = tget(tileI, R, C);
+                            mu = tget(tileM, R, C - 1); ml = tget(tileM, R - 1, C); mg = tget(tileM, R - 1, C - 1);
+                        } else {
+                            const size_t a0 = addr(at);
+                            m = TM[a0]; cdd = TD[a0]; cii = TI[a0];
+                            mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
+                        }
+                        if (layer == L_D) {
+                            put('D');
+                            if (cdd == mu + OE) layer = L_M;
+                            --v;
+                        } else if (layer == L_I) {
+                            put('I');
+                            if (cii == ml + OE) layer = L_M;
+                            --h;
+                        } else {
+                            if (m == cdd) layer = L_D;
+                            else if (m == cii) layer = L_I;
+                            else if (m == mg + MATCH) { put('M'); --h; --v; }
+                            else if (m == mg + MISMATCH) { put('X'); --h; --v; }
+                            else { status = AIM_PAIR_SWG_NO_OP; break; }
+                        }
+                    }
+                }
+                if (status == AIM_PAIR_OK) {
+                    for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
+                    if (h > 0) sentinel -= h;
+                    for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
+                    if (v > 0) sentinel -= v;
+                }
+                begin_offset = sentinel + 1;
+}
+
 #ifdef AIM_DPW_STAMPS   // diagnostic builds only: s_memtime per phase, summed by thread 0, dumped into the pair's ops row
 #define AIM_DPW_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); dpw_sum[i] += t_ - dpw_last; dpw_last = t_; } while (0)
@@ -127,47 +295,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
         if (literal) {
             // ------------------------------------------------------------------ literal single-lane path
             // The reference's loops verbatim over a flat table (plane-separated) in the slab.
-            typedef typename std::conditional<CELL8, int8_t, int16_t>::type cell_t;
-            if (tid == 0) {
-                if (!SWG) {
-                    int cell = 0;
-                    TM[0] = 0;
-                    for (int v = 1; v <= plen; ++v) { cell += GD; TM[v] = (int16_t)cell; }
-                    cell = 0;
-                    for (int h = 1; h <= tlen; ++h) { cell += GI; TM[(size_t)W * h] = (int16_t)cell; }
-                    int16_t sc = 0;
-                    for (int h = 1; h <= tlen; ++h) {
-                        const int tch = gT[h - 1];
-                        const size_t row = (size_t)W * h, prow = row - W;
-                        for (int v = 1; v <= plen; ++v) {
-                            const int16_t del = (int16_t)(TM[row + v - 1] + GD);
-                            const int16_t ins = (int16_t)(TM[prow + v] + GI);
-                            const int16_t mm = (int16_t)(TM[prow + v - 1] + ((gP[v - 1] == tch) ? 0 : MISMATCH));
-                            sc = TM[row + v] = min(mm, min(ins, del));
-                        }
-                    }
-                    score = sc;
-                } else {
-                    TD[0] = (cell_t)MAXS; TI[0] = (cell_t)MAXS; TM[0] = 0;
-                    for (int v = 1; v <= plen; ++v) { const cell_t d = (cell_t)(O + v * E); TD[v] = d; TI[v] = (cell_t)MAXS; TM[v] = d; }
-                    for (int h = 1; h <= tlen; ++h) {
-                        const cell_t i = (cell_t)(O + h * E);
-                        TD[(size_t)W * h] = (cell_t)MAXS; TI[(size_t)W * h] = i; TM[(size_t)W * h] = i;
-                    }
-                    for (int h = 1; h <= tlen; ++h) {
-                        const int tch = gT[h - 1];
-                        const size_t row = (size_t)W * h, prow = row - W;
-                        for (int v = 1; v <= plen; ++v) {
-                            const cell_t del = min((cell_t)((cell_t)TM[row + v - 1] + OE), (cell_t)((cell_t)TD[row + v - 1] + E));
-                            const cell_t ins = min((cell_t)((cell_t)TM[prow + v] + OE), (cell_t)((cell_t)TI[prow + v] + E));
-                            const cell_t mm = (cell_t)((cell_t)TM[prow + v - 1] + ((gP[v - 1] == tch) ? MATCH : MISMATCH));
-                            const cell_t m = min(mm, min(ins, del));
-                            TD[row + v] = del; TI[row + v] = ins; TM[row + v] = m;
-                            score = m;
-                        }
-                    }
-                }
-            }
+            if (tid == 0) score = dp_literal_fill<SWG, CELL8>(a.p, plen, tlen, gP, gT, TM, TI, TD);
             if (tid == 0) sc_sh[0] = score;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SWG's ops prefill by all threads completes before the traceback patches it
             __syncthreads();
@@ -447,112 +575,9 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
             if (plen == 0 || tlen == 0) score = 0;
         }
 
-        if (BT && wv == 0) {
-            // nw_traceback / swg_traceback over flat indices (first wavefront); canonical slab unless literal
-            auto addr = [&](int f) -> size_t {
-                if (literal) return (size_t)f;
-                const int r = f / W;
-                return (size_t)r * S + 7 + (f - r * W);
-            };
-            int sentinel = end_offset - 1;
-            int h = tlen, v = plen;
-#ifdef AIM_DPW_DIAG_NO_TRACEBACK
-            h = 0; v = 0;      // diagnostic builds only (results are wrong)
-#endif
-            const int cap = 2 * rs;
-            auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
-            // Tiled walk. The walk is wave-uniform and the slab is canonical -- flat index f lives at (R, C) = (f / W,
-            // f % W) -- so whenever C >= 1 the cells a step compares are (R, C), (R, C-1), (R-1, C), (R-1, C-1). The 64
-            // lanes fetch an 8-row x 64-column window ending at (R, C) with ONE 16-B load per lane and plane into LDS
-            // (the row buffers are dead by now) and the walk reads from it until it leaves: a refill every >= 7 steps
-            // instead of an HBM round trip per step (decomposition: the walk was 27 % / 20 % of NW / SWG at l = 1000).
-            // Steps on the boundary column (C == 0) and the literal path keep the per-step reads.
-#ifdef AIM_DPW_NO_TILE
-            const bool use_tile = false;     // diagnostic builds: per-step reads only
-#else
-            const bool use_tile = !literal && (size_t)(SWG ? 4 : 2) * rowcap * 2 >= (size_t)(SWG ? 3 : 1) * 1024;
-#endif
-            int16_t *tileM = rowbuf, *tileI = rowbuf + 512, *tileD = rowbuf + 1024;   // [8 rows][8 units][8 cells]
-            int tR = -1, tC0 = 0;                                                       // rows tR-7..tR, columns tC0..tC0+63
-            auto refill = [&](int R, int C) {                                           // C >= 1
-                const int u0 = ((C - 1) >> 3) - 7;                                      // units of 8 columns: unit u = 8u+1 .. 8u+8
-                tR = R; tC0 = 8 * u0 + 1;
-                const int r = R - (lane >> 3), u = u0 + (lane & 7);
-                if (r >= 0 && u >= -1) {                                                // unit -1: column 0 (and row padding)
-                    const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);               // == r*S + 7 + (8u+1), 16-B aligned
-                    *reinterpret_cast<uint4 *>(&tileM[lane * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
-                    if (SWG) {
-                        *reinterpret_cast<uint4 *>(&tileI[lane * 8]) = *reinterpret_cast<const uint4 *>(&TI[e]);
-                        *reinterpret_cast<uint4 *>(&tileD[lane * 8]) = *reinterpret_cast<const uint4 *>(&TD[e]);
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // one wavefront: in-order LDS, no barrier
-            };
-            auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - 7 && C - 1 >= tC0 && C <= tC0 + 63; };
-            auto tget = [&](const int16_t *t, int r, int c) {
-                const int cc = c - tC0;
-                return (int)t[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)];
-            };
-            if (!SWG) {
-                // the three neighbours are fetched together (one HBM round trip per step instead of up to three dependent
-                // ones) and the cell moved to becomes the next step's table[at]: same cells, values and comparison order
-                int c = (h > 0 && v > 0) ? (int)TM[addr(W * h + v)] : 0;
-                while (h > 0 && v > 0) {
-                    const int at = W * h + v;
-                    const int R = at / W, C = at - R * W;
-                    int cl, cu, cg;
-                    if (use_tile && C >= 1) {
-                        if (!in_tile(R, C)) refill(R, C);
-                        cl = tget(tileM, R, C - 1); cu = tget(tileM, R - 1, C); cg = tget(tileM, R - 1, C - 1);
-                    } else {
-                        cl = TM[addr(at - 1)]; cu = TM[addr(at - W)]; cg = TM[addr(at - W - 1)];
-                    }
-                    if (c == cl + GD) { put('D'); --v; c = cl; }
-                    else if (c == cu + GI) { put('I'); --h; c = cu; }
-                    else { put((c == cg + MISMATCH) ? 'X' : 'M'); --h; --v; c = cg; }
-                }
-            } else {
-                enum { L_M, L_I, L_D };
-                int layer = L_M;
-                while (h > 0 && v > 0) {
-                    const int at = W * h + v;
-                    // everything any branch of this step compares, fetched together (one round trip, not a chain)
-                    const int R = at / W, C = at - R * W;
-                    int m, cdd, cii, mu, ml, mg;
-                    if (use_tile && C >= 1) {
-                        if (!in_tile(R, C)) refill(R, C);
-                        m = tget(tileM, R, C); cdd = tget(tileD, R, C); cii = tget(tileI, R, C);
-                        mu = tget(tileM, R, C - 1); ml = tget(tileM, R - 1, C); mg = tget(tileM, R - 1, C - 1);
-                    } else {
-                        const size_t a0 = addr(at);
-                        m = TM[a0]; cdd = TD[a0]; cii = TI[a0];
-                        mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
-                    }
-                    if (layer == L_D) {
-                        put('D');
-                        if (cdd == mu + OE) layer = L_M;
-                        --v;
-                    } else if (layer == L_I) {
-                        put('I');
-                        if (cii == ml + OE) layer = L_M;
-                        --h;
-                    } else {
-                        if (m == cdd) layer = L_D;
-                        else if (m == cii) layer = L_I;
-                        else if (m == mg + MATCH) { put('M'); --h; --v; }
-                        else if (m == mg + MISMATCH) { put('X'); --h; --v; }
-                        else { status = AIM_PAIR_SWG_NO_OP; break; }
-                    }
-                }
-            }
-            if (status == AIM_PAIR_OK) {
-                for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
-                if (h > 0) sentinel -= h;
-                for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
-                if (v > 0) sentinel -= v;
-            }
-            begin_offset = sentinel + 1;
-        }
+        if (BT && wv == 0)
+            dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowbuf, !literal && (size_t)(SWG ? 4 : 2) * rowcap * 2 >= (size_t)(SWG ? 3 : 1) * 1024,
+                              ops, lane, begin_offset, status);
         if (tid == 0) {
             aim_result_t r;
             r.max_operations = plen + tlen;

@@ -55,11 +55,14 @@ extern "C" {
  *  AIM_FLAG_REQ8  requests[] are aim_request8_t = the reference's own WFA request_t, 8 B
  *                 (WFA/DPU-WRAM/common/common.h:172-177: int16 pattern_len, int16 text_len, uint32 idx);
  *  AIM_FLAG_RES8  results[] are aim_result8_t {idx, score}, 8 B -- exactly what the reference host prints in
- *                 score-only mode (host.c:339-341).  Not valid with AIM_FLAG_BACKTRACE (the CIGAR needs the offsets);
- *                 a score-only pair never carries a status other than AIM_PAIR_OK.
+ *                 score-only mode (host.c:339-341).  Not valid with AIM_FLAG_BACKTRACE (the CIGAR needs the offsets).
+ *                 There is no status field: without BACKTRACE the only per-pair failure that exists is AIM_PAIR_NOMEM, which
+ *                 the launch plans rule out (a score-only launch is refused with AIM_ENOMEM rather than given a window that
+ *                 could overflow); should a kernel ever report one all the same, its score reads AIM_SCORE_FAILED.
  * Both apply to every entry point that takes requests / results (aim_set_push / aim_set_pull / aim_align_device). */
 #define AIM_FLAG_REQ8 0x8u
 #define AIM_FLAG_RES8 0x10u
+#define AIM_SCORE_FAILED ((int32_t)0x80000000) /* aim_result8_t.score of a pair that stopped with a status (see above) */
 
 /* Replaces the -D macro set the launchers pass to make
  * (WFA/DPU-WRAM/run-wfa-pim-wram.py:128-131; common.h:63-89). */

@@ -88,7 +88,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 11, 112))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 250, 1064, backtrace=True, reduce=True))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 2000, 8000))) == b"wfa_wave_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 500, 10112, backtrace=True))) == b"dp_wave_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 500, 10112, backtrace=True))) == b"dp_strip_kernel"    # round 3: column-strip pipeline
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 100, 1064, backtrace=True))) == b"dp_wave_kernel"      # int8 cells (MAX_SCORE < 127): row-scan kernel's literal path
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 400, 20000))) == b"dp_wave_kernel"                      # beyond 16 384 columns
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_lane_kernel"
 
 

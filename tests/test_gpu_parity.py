@@ -348,19 +348,31 @@ def test_fast_path_handles_non_acgt_bytes_itself(gpu, sample_bytes, err_bytes):
         _compare("wfa", engine.make_params("wfa", 5, 80, **kw), req, pat, txt)
 
 
-# ------------------------------------------------------------------ long-read NW/SWG kernel (dp_wave)
+# ------------------------------------------------------------------ long-read NW/SWG kernels (dp_strip: column-strip pipeline; dp_wave: row scan)
+DP_KERNELS = [dict(), dict(AIM_DPW_LEGACY="1"), dict(AIM_STRIP_K="32")]
+
+
+def _dp_kernel_name(env, params):
+    from aim_amd import capi
+    int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
+    return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
+
+
+@pytest.mark.parametrize("env", DP_KERNELS)
 @pytest.mark.parametrize("key,algo,ms,kw", [("nw_backtrace", "nw", 4, dict(backtrace=True)),
                                             ("swg_w16_backtrace", "swg", 5, dict(backtrace=True, swg_w16=True)),
                                             ("swg_w8_backtrace", "swg", 5, dict(backtrace=True))])
-def test_dp_wave_on_sample_file_digest(gpu, sample_bytes, ref_digests, monkeypatch, key, algo, ms, kw):
-    """The row-scan kernel (and, for int8 cells, its literal path) forced onto the reference's sample file."""
+def test_dp_wave_on_sample_file_digest(gpu, sample_bytes, ref_digests, monkeypatch, key, algo, ms, kw, env):
+    """The long-read kernels (strip pipeline, row scan; for int8 cells the literal path) forced onto the reference's sample file."""
     from aim_amd import capi, engine
     import ctypes as C
     monkeypatch.setenv("AIM_FORCE_DPWAVE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     req, pat, txt = engine.parse_pairs(sample_bytes, 112)
     n = 20000 if "w8" not in key else 4000
     params = engine.make_params(algo, ms, 112, **kw)
-    assert capi.load().aim_kernel_name(C.byref(params)) == b"dp_wave_kernel"
+    assert capi.load().aim_kernel_name(C.byref(params)) == _dp_kernel_name(env, params)
     if n == 20000:
         res, ops = engine.align(params, req, pat, txt)
         assert md5(engine.format_output(res, ops, True)) == ref_digests[key]
@@ -368,27 +380,33 @@ def test_dp_wave_on_sample_file_digest(gpu, sample_bytes, ref_digests, monkeypat
         _compare(algo, params, req[:n], pat[:n], txt[:n])
 
 
+@pytest.mark.parametrize("env", DP_KERNELS)
 @pytest.mark.parametrize("algo,kw", [("nw", dict(backtrace=True)), ("swg", dict(backtrace=True, swg_w16=True)), ("swg", dict(swg_w16=True))])
 @pytest.mark.parametrize("err", [0.02, 0.10])
-def test_dp_wave_strata_l100(gpu, monkeypatch, algo, kw, err):
-    """plen > tlen (tail cells / boundary aliasing), plen < tlen and plen == tlen through the row-scan path."""
+def test_dp_wave_strata_l100(gpu, monkeypatch, algo, kw, err, env):
+    """plen > tlen (tail cells / boundary aliasing), plen < tlen and plen == tlen through the long-read kernels."""
     from aim_amd import engine
     monkeypatch.setenv("AIM_FORCE_DPWAVE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     ms, rs = engine.launcher_sizes(algo, 100, err)
     req, pat, txt = engine.gen_pairs(4321, 0, 2000, 100, err, rs)
     assert (req["pattern_len"] > req["text_len"] + (2 if err > 0.05 else 0)).any()
     _compare(algo, engine.make_params(algo, ms, rs, **kw), req, pat, txt)
 
 
+@pytest.mark.parametrize("env", DP_KERNELS)
 @pytest.mark.parametrize("algo", ["nw", "swg"])
-@pytest.mark.parametrize("l,err,n", [(600, 0.05, 300), (1000, 0.05, 200), (3000, 0.02, 24)])
-def test_dp_wave_long_reads(gpu, algo, l, err, n):
+@pytest.mark.parametrize("l,err,n", [(600, 0.05, 300), (1000, 0.05, 200), (3000, 0.02, 24), (1500, 0.03, 700)])
+def test_dp_wave_long_reads(gpu, monkeypatch, algo, l, err, n, env):
     from aim_amd import capi, engine
     import ctypes as C
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     ms, rs = engine.launcher_sizes(algo, l, err)
     req, pat, txt = engine.gen_pairs(l, 0, n, l, err, rs)
     params = engine.make_params(algo, ms, rs, backtrace=True)
-    assert capi.load().aim_kernel_name(C.byref(params)) == b"dp_wave_kernel"
+    assert capi.load().aim_kernel_name(C.byref(params)) == _dp_kernel_name(env, params)
     _compare(algo, params, req, pat, txt)
     _compare(algo, engine.make_params(algo, ms, rs), req, pat, txt)
 
@@ -634,7 +652,7 @@ def test_dp_wave_every_wavefront_count_agrees_with_oracle(gpu, monkeypatch):
     for algo, l, e in (("nw", 1000, 0.05), ("swg", 1000, 0.05), ("nw", 2500, 0.02)):
         ms, rs = engine.launcher_sizes(algo, l, e)
         params = engine.make_params(algo, ms, rs, backtrace=True)
-        assert lib.aim_kernel_name(C.byref(params)) == b"dp_wave_kernel"
+        assert lib.aim_kernel_name(C.byref(params)) == b"dp_strip_kernel"
         req, pat, txt = engine.gen_pairs(4321 + l, 0, 96, l, e, rs)
         d = req["pattern_len"].astype(int) - req["text_len"].astype(int)
         assert (d > 0).any() and (d < 0).any()
