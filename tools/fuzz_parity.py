@@ -49,7 +49,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cells", type=float, default=4e8, help="bound on n * l * l per case (oracle time)")
-    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa"], default="all", help="'lane': stay inside wfa_lane_kernel's eligibility window; 'genasm': GenASM only; 'wfa': the general generator restricted to WFA (wfa_group / wfa_wave / wfa_lane)")
+    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa", "fused", "dp"], default="all",
+                    help="'lane': stay inside the one-pair-per-lane kernels' eligibility window (wfa_lane_kernel, wfa_lane_packed_kernel); 'genasm': GenASM only; "
+                         "'wfa': the general generator restricted to WFA (wfa_group / wfa_wave / wfa_lane); 'fused': WFA batches through aim_set_submit as PACKED "
+                         "rows with the compact CIGAR back (one kernel per batch: wfa_lane_packed / wfa_group + traceback kernel), output text against the oracle's; "
+                         "'dp': NW / SWG long reads (dp_strip_kernel with every cells-per-lane shape, dp_wave_kernel)")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     lib = capi.load()
@@ -57,12 +61,13 @@ def main():
     while time.time() - t0 < a.seconds:
         if a.focus == "lane":
             # default penalties, MAX_SCORE 0..5, READ_SIZE 80 or 112, any pair count (partial last groups), non-ACGT bytes
-            rs = rng.choice([80, 112])
+            rs = rng.choice([80, 112, 112, 136, 144, 160, 176])      # 80 / 112: wfa_lane_kernel (ASCII rows); the others: packed on the device
             l = rng.randint(1, rs - 12)
             e = rng.choice([0.0, 0.01, 0.02, 0.03, 0.05, 0.08, 0.10])
-            ms = rng.randint(0, 10)                       # 6..10: the dynamic-bounds shape (score-only; WFA-adaptive's reduction can fire)
+            if l + int(np.ceil(l * e)) + 1 > rs: e = 0.01
+            ms = rng.randint(0, 10)                       # 6..10: the dynamic-bounds shape (WFA-adaptive's reduction can fire; CIGAR through the LDS history)
             n = rng.choice([1, 63, 64, 65, 127, 1000, 4097, 20000])
-            kw = dict(backtrace=rng.random() < 0.6 and ms <= 5, reduce=rng.random() < 0.7)
+            kw = dict(backtrace=rng.random() < 0.6, reduce=rng.random() < 0.7)
             params = engine.make_params("wfa", ms, rs, **kw)
             for k in list(os.environ):
                 if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
@@ -115,8 +120,52 @@ def main():
                 print("MISMATCH:", err, flush=True)
                 return 1
             continue
-        algo = "wfa" if a.focus == "wfa" else rng.choice(["wfa", "wfa", "wfa", "nw", "swg"])
-        l = rng.choice([3, 8, 20, 33, 64, 100, 100, 150, 250, 300, 400, 700, 1000, 1500, 2500, 3500])
+        if a.focus == "fused":
+            # packed rows in, {idx, score} or compact CIGAR out, through aim_set_submit / aim_set_wait; text against the oracle's
+            for k in list(os.environ):
+                if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
+            if rng.random() < 0.5:      # lane shapes
+                rs = rng.choice([80, 112, 136, 144, 160, 176]); l = rng.randint(1, rs - 12); ms = rng.randint(0, 10); cost = {}
+                e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10])
+            else:                       # group shapes
+                l = rng.choice([20, 64, 100, 150, 250, 400, 1000]); e = rng.choice([0.02, 0.05, 0.10])
+                cost = dict(mismatch=rng.randint(1, 9), gap_o=rng.randint(1, 9), gap_e=rng.randint(1, 4)) if rng.random() < 0.4 else {}
+                ms, rs = engine.launcher_sizes("wfa", l, e, **cost)
+                if rng.random() < 0.2: ms = max(1, ms // 2)
+                if rng.random() < 0.2: os.environ["AIM_GROUP_G"] = rng.choice(["1", "4", "16", "64"])
+                if rng.random() < 0.1: os.environ["AIM_GROUP_WLDS"] = "64"
+            if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
+            n = int(min(rng.choice([1, 64, 65, 1000, 5000]), max(1, a.max_cells // (l * l))))
+            bt = rng.random() < 0.7
+            params = engine.make_params("wfa", ms, rs, backtrace=bt, reduce=rng.random() < 0.7, req8=True, res8=not bt, **cost)
+            req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
+            for _ in range(rng.choice([0, 0, 1, 4])):
+                pat[rng.randrange(n), rng.randrange(max(1, l))] = ord(rng.choice("Nn*"))
+            op = oracle.params("wfa", ms, rs, backtrace=bt, reduce=bool(params.flags & capi.FLAG_REDUCE), mismatch=params.mismatch, gap_o=params.gap_o, gap_e=params.gap_e)
+            ores, oops, _ = oracle.align_batch(op, req["pattern_len"], req["text_len"], pat, txt, nthreads=32)
+            err = None
+            try:
+                with engine.DeviceSet(1) as st:
+                    cap = n * (2 * min(ms, l + 8) + 12) + 64
+                    st.configure_slots(params, n, slots=1, max_raw=n, max_runs=(cap if bt else 0))
+                    st.submit(0, 0, req, packed=engine.pack_batch(req, pat, txt), cigar_runs_cap=(cap if bt else 0))
+                    out = st.wait(0, 0, check=False)
+                    kn = st.plan_describe(0).split()[0]
+                if bt:
+                    if not np.array_equal(out["cig"]["score"], ores["score"]): err = "score differs"
+                    elif (ores["status"] == 0).all() and engine.format_output_runs(out["cig"], out["runs"]) != oracle.format_output(ores, oops, True): err = "CIGAR text differs"
+                elif not np.array_equal(out["res"]["score"], ores["score"]): err = "score differs"
+            except Exception as ex:
+                err = "exception: %r" % (ex,); kn = "?"
+            cases += 1
+            kernels[kn] = kernels.get(kn, 0) + 1
+            if err:
+                print(json.dumps(dict(algo="wfa", l=l, e=e, n=n, max_score=ms, read_size=rs, backtrace=int(bt), cost=cost, kernel=kn, env={k: v for k, v in os.environ.items() if k.startswith("AIM_")}, ok=False)), flush=True)
+                print("MISMATCH:", err, flush=True)
+                return 1
+            continue
+        algo = "wfa" if a.focus == "wfa" else (rng.choice(["nw", "swg"]) if a.focus == "dp" else rng.choice(["wfa", "wfa", "wfa", "nw", "swg"]))
+        l = rng.choice([330, 400, 700, 1000, 1500, 2500, 3500, 5000]) if a.focus == "dp" else rng.choice([3, 8, 20, 33, 64, 100, 100, 150, 250, 300, 400, 700, 1000, 1500, 2500, 3500])
         e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15, 0.25])
         cost = {}
         if rng.random() < 0.5:
@@ -143,7 +192,9 @@ def main():
         r = rng.random()
         if algo == "wfa" and r < 0.25: env["AIM_GROUP_G"] = rng.choice(["1", "2", "4", "8", "16", "64"])
         if algo == "wfa" and 0.25 <= r < 0.35: env["AIM_FORCE_WAVE"] = "1"
-        if algo != "wfa" and r < 0.4: env["AIM_DPW_NW"] = rng.choice(["1", "2", "4"])
+        if algo != "wfa" and r < 0.25: env["AIM_DPW_NW"] = rng.choice(["1", "2", "4"])
+        if algo != "wfa" and 0.25 <= r < 0.4: env["AIM_STRIP_K"] = rng.choice(["16", "24", "32"])
+        if algo != "wfa" and 0.7 <= r < 0.75: env["AIM_DPW_LEGACY"] = "1"
         if algo != "wfa" and 0.4 <= r < 0.5: env["AIM_FORCE_DPWAVE"] = "1"
         if algo != "wfa" and 0.5 <= r < 0.6: env["AIM_DPL_SEQ_LDS"] = "0"
         if algo != "wfa" and 0.6 <= r < 0.7: env["AIM_DPL_PER_CU"] = rng.choice(["1", "3", "12"])
@@ -151,7 +202,7 @@ def main():
         if algo == "wfa" and 0.45 <= r < 0.5: env.update(AIM_FORCE_WAVE="1", AIM_WFA_NO_RING="1")
         if rng.random() < 0.15: env["AIM_SCRATCH_GB"] = rng.choice(["0.25", "0.5", "2"])
         for k in ("AIM_GROUP_G", "AIM_FORCE_WAVE", "AIM_DPW_NW", "AIM_FORCE_DPWAVE", "AIM_DPL_SEQ_LDS", "AIM_DPL_PER_CU", "AIM_GROUP_PER_CU",
-                  "AIM_WFA_NO_RING", "AIM_SCRATCH_GB"): os.environ.pop(k, None)
+                  "AIM_WFA_NO_RING", "AIM_SCRATCH_GB", "AIM_STRIP_K", "AIM_DPW_LEGACY", "AIM_GROUP_WLDS"): os.environ.pop(k, None)
         os.environ.update(env)
         req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
         if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")   # non-ACGT byte

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Soak test for the long-read DP kernel (dp_wave_kernel): the family of the one unexplained CLI difference of round 1
-(NW, l=700, e=10 %, CIGAR, 40 pairs, 2 wavefronts per pair; DESIGN.md "open items").
+"""Soak test for the long-read DP kernels: dp_wave_kernel (row scan; the family of the one unexplained CLI difference of round 1:
+NW, l=700, e=10 %, CIGAR, 40 pairs, 2 wavefronts per pair; DESIGN.md "open items") and, since round 3, dp_strip_kernel (the
+column-strip pipeline: its wavefronts synchronise through LDS mailboxes with sequence numbers instead of barriers, which is
+exactly the kind of code a launch-to-launch soak is for; slots with nw = 0 take the default plan = the strip kernel, some with a
+forced AIM_STRIP_K so that 2 .. 4 wavefronts per pair exchange messages).
 
 Every slot owns one configuration (algorithm, READ_SIZE, pair count, forced wavefronts per pair), its own HBM buffers and
 its own stream. A slot's first launch is checked against the CPU oracle (checker only); every later launch of the SAME
@@ -42,7 +45,7 @@ def to_dev(arr, pad=64):
 
 
 class Slot:
-    def __init__(self, algo, l, e, n, nw, seed):
+    def __init__(self, algo, l, e, n, nw, seed, extra_env=None):
         self.algo, self.l, self.e, self.n, self.nw, self.seed = algo, l, e, n, nw, seed
         ms, rs = engine.launcher_sizes(algo, l, e)
         self.rs = rs
@@ -51,7 +54,7 @@ class Slot:
         self.d_req, self.d_pat, self.d_txt = to_dev(self.req), to_dev(self.pat), to_dev(self.txt)
         self.d_res = torch.zeros(n * capi.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
         self.d_ops = torch.zeros(n * 2 * rs + 64, dtype=torch.uint8, device=dev)
-        self.env = {"AIM_DPW_NW": str(nw)} if nw else {}
+        self.env = {"AIM_DPW_NW": str(nw)} if nw else dict(extra_env or {})
         self._setenv()
         self.scratch = torch.zeros(max(256, lib.aim_scratch_bytes(C.byref(self.params), n)), dtype=torch.uint8, device=dev)
         buf = C.create_string_buffer(512)
@@ -64,6 +67,7 @@ class Slot:
 
     def _setenv(self):
         os.environ.pop("AIM_DPW_NW", None)
+        os.environ.pop("AIM_STRIP_K", None)
         os.environ.update(self.env)
 
     def launch(self):
@@ -104,13 +108,14 @@ class Slot:
 
 
 # the failing family first (NW l=700 e=10 % 40 pairs, 2 wavefronts per pair), then its neighbours
-menu = [("nw", 700, 0.10, 40, 2), ("nw", 700, 0.10, 40, 1), ("nw", 700, 0.10, 9, 4), ("swg", 700, 0.10, 40, 2),
-        ("nw", 1000, 0.05, 100, 2), ("swg", 1000, 0.05, 40, 4), ("nw", 700, 0.10, 100, 2), ("nw", 300, 0.10, 40, 2),
-        ("nw", 700, 0.10, 3000, 2), ("swg", 700, 0.05, 9, 1), ("nw", 1000, 0.05, 40, 4), ("swg", 1000, 0.05, 9, 2)]
+menu = [("nw", 700, 0.10, 40, 2, None), ("swg", 3000, 0.02, 24, 0, {"AIM_STRIP_K": "16"}), ("nw", 700, 0.10, 9, 4, None), ("swg", 700, 0.10, 40, 0, None),
+        ("nw", 3500, 0.02, 12, 0, {"AIM_STRIP_K": "16"}), ("swg", 1000, 0.05, 40, 4, None), ("nw", 700, 0.10, 100, 2, None), ("swg", 2500, 0.03, 40, 0, None),
+        ("nw", 700, 0.10, 3000, 2, None), ("swg", 700, 0.05, 9, 1, None), ("nw", 1000, 0.05, 40, 0, None), ("swg", 1000, 0.05, 9, 2, None),
+        ("nw", 700, 0.10, 40, 1, None), ("swg", 700, 0.10, 40, 2, None), ("nw", 1000, 0.05, 100, 2, None), ("nw", 300, 0.10, 40, 2, None)]
 slots = []
 for i in range(a.slots):
-    algo, l, e, n, nw = menu[i % len(menu)]
-    slots.append(Slot(algo, l, e, n, nw, int(rng.randint(1, 1 << 30))))
+    algo, l, e, n, nw, extra = menu[i % len(menu)]
+    slots.append(Slot(algo, l, e, n, nw, int(rng.randint(1, 1 << 30)), extra))
 for s in slots:
     s.first()
 
@@ -122,6 +127,7 @@ breq, bpat, btxt = engine.gen_pairs(99, 0, bg_n, 100, 0.01, rs)
 b_req, b_pat, b_txt = to_dev(breq), to_dev(bpat), to_dev(btxt)
 b_res = torch.zeros(bg_n * capi.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
 os.environ.pop("AIM_DPW_NW", None)
+os.environ.pop("AIM_STRIP_K", None)
 b_scratch = torch.zeros(max(256, lib.aim_scratch_bytes(C.byref(bg_params), bg_n)), dtype=torch.uint8, device=dev)
 bg_stream = torch.cuda.Stream(device=dev)
 
