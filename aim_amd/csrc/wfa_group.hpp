@@ -669,7 +669,10 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     int g = 32;
     for (size_t cap_kb : {12, 24, 48}) {
         size_t cap_bytes = cap_kb * 1024;
-        if (cap_kb == 12 && c->wlds != c->wcap) cap_bytes = 10 * 1024;   // narrow rows: two pairs per wavefront beat four from ~2.8 KB per pair up (same probe)
+        // narrow rows (3.2 KB per pair): FOUR pairs per wavefront. (Round 2 measured two better -- with the traceback inside the
+        // kernel; with the traceback a kernel of its own the step is VALU-issue-bound and 16 lanes per pair waste fewer of them:
+        // l=1000 e=5 % 3.20 -> 2.97 ms score-only, 3.99 -> 3.55 with CIGAR; l=1000 e=2 %, l=500 e=5 %, l=400 / 250 e=10 %: -0 .. -12 %.)
+        if (cap_kb == 12 && c->wlds != c->wcap) cap_bytes = 13 * 1024;
         if (kn.group_lds_kb >= 0) cap_bytes = (size_t)kn.group_lds_kb * 1024;
         g = 1;
         while (g <= 32 && (size_t)(kWave / g) * dw * 4 > cap_bytes) g *= 2;

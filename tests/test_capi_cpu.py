@@ -118,12 +118,12 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
         assert m, line
         return int(m.group(1)), int(m.group(2)), int(m.group(3))
     g, ring_m, per_cu = G(1000, 0.05)            # config 3: 503 diagonals, but WFA-adaptive keeps ~23 alive: narrow 128-entry rows,
-    assert (g, ring_m) == (32, 6) and per_cu >= 12     # two pairs per wavefront (round 2); exact-size ring: max(x, o+e) + 1 = 6 rows
+    assert (g, ring_m) == (16, 6) and per_cu >= 12     # FOUR pairs per wavefront (round 3: the step is VALU-bound once the traceback is a kernel of its own); exact-size ring: max(x, o+e) + 1 = 6 rows
     g, ring_m, per_cu = G(1000, 0.05, AIM_GROUP_WLDS="0")   # one home per diagonal (round-1 layout, 10.7 KB per pair): 7 per CU
     assert (g, ring_m) == (32, 6) and per_cu == 7
     assert G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14
-    assert G(400, 0.10)[0] == 32 and G(400, 0.10, AIM_GROUP_WLDS="0")[0] == 32   # (round-1 layout had no 32: 4 per CU at G = 16 -> a wavefront per pair)
-    assert G(250, 0.10)[0] == 32 and G(250, 0.10, AIM_GROUP_WLDS="0")[0] == 32   # (round 1: 16; 32 lanes per pair exist since round 2)
+    assert G(400, 0.10)[0] == 16 and G(400, 0.10, AIM_GROUP_WLDS="0")[0] == 32   # narrow rows: 4 pairs per wavefront; one home per diagonal: 2
+    assert G(250, 0.10)[0] in (16, 32) and G(250, 0.10, AIM_GROUP_WLDS="0")[0] == 32
     assert G(100, 0.10)[0] == 16 and G(100, 0.02, AIM_NO_LANE_EXT="1")[0] <= 16   # (e = 2 % score-only now runs on wfa_lane_kernel)
     assert G(1000, 0.05, AIM_GROUP_G="16")[0] == 16 and G(100, 0.10, AIM_GROUP_G="64")[0] == 64 and G(1000, 0.05, AIM_GROUP_G="64")[0] == 64
     # residency comes from the 1280-B LDS granule (aim_device.hpp: lds_workgroups_per_cu), capped at 16: a byte-granular
@@ -131,7 +131,7 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
     assert G(100, 0.02, AIM_NO_LANE_EXT="1")[2] == 11          # G = 4: 12.8 KB incl. LDS staging rows
     # round 2: groups of >= 8 lanes pack straight from global memory (no staging rows) and up to 20 workgroups per CU are used
     assert G(250, 0.05)[2] == 14 and G(100, 0.05)[2] == 16 and G(100, 0.10)[2] == 16   # 11.2 KB / 9.4 KB / 8.8 KB workgroups (18 fit: kept a multiple of the 4 SIMDs)
-    assert G(1000, 0.05)[2] == 24                  # score-only, 6.4-KB workgroups: 25 fit, 6 per SIMD are used
+    assert G(1000, 0.05)[2] == 12                  # score-only, 12.7-KB workgroups of four pairs: 12 fit
     assert G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14              # 10.7 KB
 
 

@@ -7,13 +7,19 @@ R=${1:-r03}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 tools/pmc_summary.py --out $P/wfa_lane_pmc_summary.json --kernel wfa_lane_kernel --pairs 4194304 --alg-bytes 905968812 --fetch-x2 --io compact \
    --note "Cross-check: 4194304 pairs x (224 B rows + 8 B request) = 973.1 MB read, x 8 B result = 33.6 MB written." \
-   -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e > $O/pmc_lane.log 2>&1; tail -1 $O/pmc_lane.log
+   -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-default-io > $O/pmc_lane.log 2>&1; tail -1 $O/pmc_lane.log
 python3 tools/pmc_summary.py --out $P/wfa_group_pmc_summary.json --kernel wfa_group_kernel --pairs 65536 \
    --note "cfg3: WFA-adaptive l=1000 e=5% with CIGAR, 65536 pairs; per-lane int16 LDS/HBM traffic: FETCH_SIZE kept raw (uncalibrated width)." \
    -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_group.log 2>&1; tail -1 $O/pmc_group.log
-python3 tools/pmc_summary.py --out $P/dp_wave_pmc_summary.json --kernel dp_wave_kernel --pairs 256 \
-   --note "cfg4: SWG l=10000 e=1% with CIGAR, 256 pairs; table stores are 16 B per lane (WRITE_SIZE exact), mixed-width reads: FETCH_SIZE kept raw." \
-   -- python3 tools/bench_configs.py swg_l10000_e1_cigar_n256 > $O/pmc_dpw.log 2>&1; tail -1 $O/pmc_dpw.log
+python3 tools/pmc_summary.py --out $P/dp_strip_pmc_summary.json --kernel dp_strip_kernel --pairs 256 \
+   --note "cfg4: SWG l=10000 e=1% with CIGAR, 256 pairs, column-strip pipeline; table stores are 16 B per lane (WRITE_SIZE exact), mixed-width reads: FETCH_SIZE kept raw." \
+   -- python3 tools/bench_configs.py swg_l10000_e1_cigar_n256 > $O/pmc_dps.log 2>&1; tail -1 $O/pmc_dps.log
+python3 tools/pmc_summary.py --out $P/wfa_lane_packed_pmc_summary.json --kernel wfa_lane_packed_kernel --pairs 4194304 --fetch-x2 \
+   --note "the drop-in path's kernel on packed batches (bench.py e2e leg, score-only): 4194304 pairs x (2 x 28 B packed rows + 8 B request) read, x 8 B written." \
+   -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_lanepk.log 2>&1; tail -1 $O/pmc_lanepk.log
+python3 tools/pmc_summary.py --out $P/wfa_group_tb_pmc_summary.json --kernel wfa_group_tb_kernel --pairs 65536 \
+   --note "cfg3's traceback kernel (one pair per lane over the compact per-pair history regions)." \
+   -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_grouptb.log 2>&1; tail -1 $O/pmc_grouptb.log
 python3 tools/pmc_summary.py --out $P/genasm_wave_pmc_summary.json --kernel genasm_wave_kernel --pairs 1024 \
    --note "cfg5: GenASM l=100000 e=10% with CIGAR, 1024 pairs (parity unpinned)." \
    -- python3 tools/bench_configs.py genasm_l100000_e10_cigar > $O/pmc_genasm.log 2>&1; tail -1 $O/pmc_genasm.log
