@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -104,6 +105,7 @@ aim::Knobs read_knobs()
     k.no_group = env_flag("AIM_NO_GROUP");
     k.no_lane_ext = env_flag("AIM_NO_LANE_EXT");
     k.no_lane_pk = env_flag("AIM_NO_LANE_PK");
+    k.group_no_overlap = env_flag("AIM_GROUP_NO_OVERLAP");
     k.wfa_no_ring = env_flag("AIM_WFA_NO_RING");
     k.wfa_slotw = env_int("AIM_WFA_SLOTW", -1);
     k.force_dpwave = env_flag("AIM_FORCE_DPWAVE");
@@ -217,12 +219,18 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         if (group_ok && ghist_pair) {
             // BACKTRACE: every pair of a launch keeps its history region until the traceback kernel has walked it. Launches are
             // chunks of the batch whose regions fit half of the scratch bound (one chunk whenever possible).
-            const uint64_t fit = (budget / 2) / ghist_pair;
+            // Two buffers of regions alternate, so that the traceback kernel of one chunk (second stream) overlaps the compute
+            // kernel of the next; a chunk is two rounds of the persistent grid (so that chunking costs no partial rounds).
+            const uint64_t fit = (budget / 4) / ghist_pair;          // per buffer
             if (fit < 4096 && fit < n_pairs) group_ok = false;   // too few pairs in flight to fill the chip: the general kernel's pools are smaller
             else {
-                gchunk = (uint32_t)std::min<uint64_t>(n_pairs, fit);
+                const uint64_t two_rounds = 2ull * ggrid * (uint64_t)(64 / gg);
+                uint64_t chunk = std::min<uint64_t>(fit, std::max<uint64_t>(two_rounds, 4096));
+                if (chunk >= n_pairs || kn.group_no_overlap) chunk = std::min<uint64_t>(n_pairs, 2 * fit);   // one launch (or as few as fit)
+                gchunk = (uint32_t)chunk;
                 if (gchunk < n_pairs) gchunk &= ~63u;
-                ghist = (((size_t)gchunk * ghist_pair) + 255) & ~(size_t)255;
+                const uint32_t nchunks = (n_pairs + gchunk - 1) / gchunk;
+                ghist = ((((size_t)gchunk * ghist_pair) + 255) & ~(size_t)255) * (nchunks > 1 ? 2 : 1);
             }
         }
         if (lane_ok) {
@@ -418,6 +426,35 @@ void launch_wfa_wave(const Plan &pl, const aim::KArgs &ka, hipStream_t s)
         hipLaunchKernelGGL((aim::wfa_wave_kernel<BT, RED, false>), dim3(pl.grid), dim3(64), pl.lds, s, ka);
 }
 
+// A second stream per device for work that only has to be ordered against ONE kernel of a launch, not against the whole stream:
+// wfa_group's traceback kernel of chunk c runs there while chunk c + 1 is computed on the caller's stream (the traceback is a
+// latency-bound walk -- 93 % of its wavefront cycles are waits -- so it costs the compute kernel next to nothing). Events are
+// re-recorded per launch; a hipStreamWaitEvent captures the record that precedes it, so re-use across launches is safe.
+struct AuxStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t computed[2] = {nullptr, nullptr};   // compute kernel of the chunk that uses history buffer b has finished
+    hipEvent_t walked[2] = {nullptr, nullptr};     // traceback of that chunk has finished (buffer b is free again)
+};
+int aux_stream_for_current_device(AuxStream **out)
+{
+    static std::mutex mu;
+    static AuxStream table[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(AIM_ENODEV, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    AuxStream &a = table[dev];
+    if (!a.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&a.computed[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&a.walked[i], hipEventDisableTiming));
+        }
+    }
+    *out = &a;
+    return AIM_OK;
+}
+
 // The fused batch I/O of a launch (Plan::pk / Plan::emits_runs): packed rows in, compact CIGAR out.
 struct FusedIo {
     const uint32_t *packedP = nullptr, *packedT = nullptr;
@@ -521,10 +558,21 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         const size_t rqb = (p.flags & AIM_FLAG_REQ8) ? sizeof(aim_request8_t) : sizeof(aim_request_t);
         const size_t rsb = (p.flags & AIM_FLAG_RES8) ? sizeof(aim_result8_t) : sizeof(aim_result_t);
         const size_t npw = aim::packed_row_dwords(p.read_size);
-        for (uint32_t first = 0; first < n_pairs; first += chunk) {
+        const uint32_t nchunks = (n_pairs + chunk - 1) / chunk;
+        const bool overlap = bt && nchunks > 1;
+        const size_t buf_bytes = overlap ? pl.hist_bytes / 2 : 0;     // two alternating buffers of history regions
+        AuxStream *aux = nullptr;
+        if (overlap) {
+            int arc = aux_stream_for_current_device(&aux);
+            if (arc) return arc;
+        }
+        uint32_t ci = 0;
+        for (uint32_t first = 0; first < n_pairs; first += chunk, ++ci) {
             aim::KArgs kc = ka;
+            const int b = (int)(ci & 1u);
             kc.n_pairs = std::min(chunk, n_pairs - first);
             kc.pair_base = first;
+            kc.scratch_per_wave = pl.todo_bytes + (overlap ? (size_t)b * buf_bytes : 0);   // where this chunk's history regions start
             kc.req = reinterpret_cast<const aim_request_t *>(static_cast<const char *>(d_req) + (size_t)first * rqb);
             if (d_pat) { kc.patterns = d_pat + (size_t)first * p.read_size; kc.texts = d_txt + (size_t)first * p.read_size; }
             if (d_res) kc.res = reinterpret_cast<aim_result_t *>(static_cast<char *>(d_res) + (size_t)first * rsb);
@@ -538,9 +586,23 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
                 const uint32_t need = ((((kc.n_pairs + ppw - 1) / ppw) + 7u) / 8u) * 8u;
                 if (grid > need) grid = need < 8u ? 8u : need;
             }
+            if (overlap && ci >= 2) HIP_TRY(hipStreamWaitEvent(stream, aux->walked[b], 0));   // buffer b: its previous chunk has been walked
             aim::wfa_group_launch(p, pl.group_g, pl.gcfg, grid, pl.lds, kc, stream);
-            if (bt) aim::wfa_group_tb_launch(p, pl.gcfg, kc.n_pairs, kc, stream);
             HIP_TRY(hipGetLastError());
+            if (overlap) {
+                HIP_TRY(hipEventRecord(aux->computed[b], stream));
+                HIP_TRY(hipStreamWaitEvent(aux->stream, aux->computed[b], 0));
+                aim::wfa_group_tb_launch(p, pl.gcfg, kc.n_pairs, kc, aux->stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(aux->walked[b], aux->stream));
+            } else if (bt) {
+                aim::wfa_group_tb_launch(p, pl.gcfg, kc.n_pairs, kc, stream);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (overlap) {   // the caller's stream continues only after both buffers' tracebacks
+            HIP_TRY(hipStreamWaitEvent(stream, aux->walked[0], 0));
+            HIP_TRY(hipStreamWaitEvent(stream, aux->walked[1], 0));
         }
         aim::KArgs kb = ka;
         kb.packedP = kb.packedT = nullptr;

@@ -136,105 +136,105 @@ __device__ __forceinline__ void dp_traceback(const aim_params_t &p, bool literal
     const bool use_tile = use_tile_in;
 #endif
 
-                // nw_traceback / swg_traceback over flat indices (first wavefront); canonical slab unless literal
-                auto addr = [&](int f) -> size_t {
-                    if (literal) return (size_t)f;
-                    const int r = f / W;
-                    return (size_t)r * S + 7 + (f - r * W);
-                };
-                int sentinel = end_offset - 1;
-                int h = tlen, v = plen;
-    #ifdef AIM_DPW_DIAG_NO_TRACEBACK
-                h = 0; v = 0;      // diagnostic builds only (results are wrong)
-    #endif
-                const int cap = 2 * rs;
-                auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
-                // Tiled walk. The walk is wave-uniform and the slab is canonical -- flat index f lives at (R, C) = (f / W,
-                // f % W) -- so whenever C >= 1 the cells a step compares are (R, C), (R, C-1), (R-1, C), (R-1, C-1). The 64
-                // lanes fetch an 8-row x 64-column window ending at (R, C) with ONE 16-B load per lane and plane into LDS
-                // (the row buffers are dead by now) and the walk reads from it until it leaves: a refill every >= 7 steps
-                // instead of an HBM round trip per step (decomposition: the walk was 27 % / 20 % of NW / SWG at l = 1000).
-                // Steps on the boundary column (C == 0) and the literal path keep the per-step reads.
-                int16_t *tileM = tile, *tileI = tile + 512, *tileD = tile + 1024;   // [8 rows][8 units][8 cells]
-                int tR = -1, tC0 = 0;                                                       // rows tR-7..tR, columns tC0..tC0+63
-                auto refill = [&](int R, int C) {                                           // C >= 1
-                    const int u0 = ((C - 1) >> 3) - 7;                                      // units of 8 columns: unit u = 8u+1 .. 8u+8
-                    tR = R; tC0 = 8 * u0 + 1;
-                    const int r = R - (lane >> 3), u = u0 + (lane & 7);
-                    if (r >= 0 && u >= -1) {                                                // unit -1: column 0 (and row padding)
-                        const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);               // == r*S + 7 + (8u+1), 16-B aligned
-                        *reinterpret_cast<uint4 *>(&tileM[lane * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
-                        if (SWG) {
-                            *reinterpret_cast<uint4 *>(&tileI[lane * 8]) = *reinterpret_cast<const uint4 *>(&TI[e]);
-                            *reinterpret_cast<uint4 *>(&tileD[lane * 8]) = *reinterpret_cast<const uint4 *>(&TD[e]);
-                        }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // one wavefront: in-order LDS, no barrier
-                };
-                auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - 7 && C - 1 >= tC0 && C <= tC0 + 63; };
-                auto tget = [&](const int16_t *t, int r, int c) {
-                    const int cc = c - tC0;
-                    return (int)t[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)];
-                };
-                if (!SWG) {
-                    // the three neighbours are fetched together (one HBM round trip per step instead of up to three dependent
-                    // ones) and the cell moved to becomes the next step's table[at]: same cells, values and comparison order
-                    int c = (h > 0 && v > 0) ? (int)TM[addr(W * h + v)] : 0;
-                    while (h > 0 && v > 0) {
-                        const int at = W * h + v;
-                        const int R = at / W, C = at - R * W;
-                        int cl, cu, cg;
-                        if (use_tile && C >= 1) {
-                            if (!in_tile(R, C)) refill(R, C);
-                            cl = tget(tileM, R, C - 1); cu = tget(tileM, R - 1, C); cg = tget(tileM, R - 1, C - 1);
-                        } else {
-                            cl = TM[addr(at - 1)]; cu = TM[addr(at - W)]; cg = TM[addr(at - W - 1)];
-                        }
-                        if (c == cl + GD) { put('D'); --v; c = cl; }
-                        else if (c == cu + GI) { put('I'); --h; c = cu; }
-                        else { put((c == cg + MISMATCH) ? 'X' : 'M'); --h; --v; c = cg; }
-                    }
-                } else {
-                    enum { L_M, L_I, L_D };
-                    int layer = L_M;
-                    while (h > 0 && v > 0) {
-                        const int at = W * h + v;
-                        // everything any branch of this step compares, fetched together (one round trip, not a chain)
-                        const int R = at / W, C = at - R * W;
-                        int m, cdd, cii, mu, ml, mg;
-                        if (use_tile && C >= 1) {
-                            if (!in_tile(R, C)) refill(R, C);
-                            m = tget(tileM, R, C); cdd = tget(tileD, R, C); cii = tget(tileI, R, C);
-                            mu = tget(tileM, R, C - 1); ml = tget(tileM, R - 1, C); mg = tget(tileM, R - 1, C - 1);
-                        } else {
-                            const size_t a0 = addr(at);
-                            m = TM[a0]; cdd = TD[a0]; cii = TI[a0];
-                            mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
-                        }
-                        if (layer == L_D) {
-                            put('D');
-                            if (cdd == mu + OE) layer = L_M;
-                            --v;
-                        } else if (layer == L_I) {
-                            put('I');
-                            if (cii == ml + OE) layer = L_M;
-                            --h;
-                        } else {
-                            if (m == cdd) layer = L_D;
-                            else if (m == cii) layer = L_I;
-                            else if (m == mg + MATCH) { put('M'); --h; --v; }
-                            else if (m == mg + MISMATCH) { put('X'); --h; --v; }
-                            else { status = AIM_PAIR_SWG_NO_OP; break; }
-                        }
-                    }
-                }
-                if (status == AIM_PAIR_OK) {
-                    for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
-                    if (h > 0) sentinel -= h;
-                    for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
-                    if (v > 0) sentinel -= v;
-                }
-                begin_offset = sentinel + 1;
+    // nw_traceback / swg_traceback over flat indices (first wavefront); canonical slab unless literal
+    auto addr = [&](int f) -> size_t {
+        if (literal) return (size_t)f;
+        const int r = f / W;
+        return (size_t)r * S + 7 + (f - r * W);
+    };
+    int sentinel = end_offset - 1;
+    int h = tlen, v = plen;
+#ifdef AIM_DPW_DIAG_NO_TRACEBACK
+    h = 0; v = 0;      // diagnostic builds only (results are wrong)
+#endif
+    const int cap = 2 * rs;
+    auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
+    // Tiled walk. The walk is wave-uniform and the slab is canonical -- flat index f lives at (R, C) = (f / W,
+    // f % W) -- so whenever C >= 1 the cells a step compares are (R, C), (R, C-1), (R-1, C), (R-1, C-1). The 64
+    // lanes fetch an 8-row x 64-column window ending at (R, C) with ONE 16-B load per lane and plane into LDS
+    // (the row buffers are dead by now) and the walk reads from it until it leaves: a refill every >= 7 steps
+    // instead of an HBM round trip per step (decomposition: the walk was 27 % / 20 % of NW / SWG at l = 1000).
+    // Steps on the boundary column (C == 0) and the literal path keep the per-step reads.
+    int16_t *tileM = tile, *tileI = tile + 512, *tileD = tile + 1024;   // [8 rows][8 units][8 cells]
+    int tR = -1, tC0 = 0;                                                       // rows tR-7..tR, columns tC0..tC0+63
+    auto refill = [&](int R, int C) {                                           // C >= 1
+        const int u0 = ((C - 1) >> 3) - 7;                                      // units of 8 columns: unit u = 8u+1 .. 8u+8
+        tR = R; tC0 = 8 * u0 + 1;
+        const int r = R - (lane >> 3), u = u0 + (lane & 7);
+        if (r >= 0 && u >= -1) {                                                // unit -1: column 0 (and row padding)
+            const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);               // == r*S + 7 + (8u+1), 16-B aligned
+            *reinterpret_cast<uint4 *>(&tileM[lane * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
+            if (SWG) {
+                *reinterpret_cast<uint4 *>(&tileI[lane * 8]) = *reinterpret_cast<const uint4 *>(&TI[e]);
+                *reinterpret_cast<uint4 *>(&tileD[lane * 8]) = *reinterpret_cast<const uint4 *>(&TD[e]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");              // one wavefront: in-order LDS, no barrier
+    };
+    auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - 7 && C - 1 >= tC0 && C <= tC0 + 63; };
+    auto tget = [&](const int16_t *t, int r, int c) {
+        const int cc = c - tC0;
+        return (int)t[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)];
+    };
+    if (!SWG) {
+        // the three neighbours are fetched together (one HBM round trip per step instead of up to three dependent
+        // ones) and the cell moved to becomes the next step's table[at]: same cells, values and comparison order
+        int c = (h > 0 && v > 0) ? (int)TM[addr(W * h + v)] : 0;
+        while (h > 0 && v > 0) {
+            const int at = W * h + v;
+            const int R = at / W, C = at - R * W;
+            int cl, cu, cg;
+            if (use_tile && C >= 1) {
+                if (!in_tile(R, C)) refill(R, C);
+                cl = tget(tileM, R, C - 1); cu = tget(tileM, R - 1, C); cg = tget(tileM, R - 1, C - 1);
+            } else {
+                cl = TM[addr(at - 1)]; cu = TM[addr(at - W)]; cg = TM[addr(at - W - 1)];
+            }
+            if (c == cl + GD) { put('D'); --v; c = cl; }
+            else if (c == cu + GI) { put('I'); --h; c = cu; }
+            else { put((c == cg + MISMATCH) ? 'X' : 'M'); --h; --v; c = cg; }
+        }
+    } else {
+        enum { L_M, L_I, L_D };
+        int layer = L_M;
+        while (h > 0 && v > 0) {
+            const int at = W * h + v;
+            // everything any branch of this step compares, fetched together (one round trip, not a chain)
+            const int R = at / W, C = at - R * W;
+            int m, cdd, cii, mu, ml, mg;
+            if (use_tile && C >= 1) {
+                if (!in_tile(R, C)) refill(R, C);
+                m = tget(tileM, R, C); cdd = tget(tileD, R, C); cii = tget(tileI, R, C);
+                mu = tget(tileM, R, C - 1); ml = tget(tileM, R - 1, C); mg = tget(tileM, R - 1, C - 1);
+            } else {
+                const size_t a0 = addr(at);
+                m = TM[a0]; cdd = TD[a0]; cii = TI[a0];
+                mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
+            }
+            if (layer == L_D) {
+                put('D');
+                if (cdd == mu + OE) layer = L_M;
+                --v;
+            } else if (layer == L_I) {
+                put('I');
+                if (cii == ml + OE) layer = L_M;
+                --h;
+            } else {
+                if (m == cdd) layer = L_D;
+                else if (m == cii) layer = L_I;
+                else if (m == mg + MATCH) { put('M'); --h; --v; }
+                else if (m == mg + MISMATCH) { put('X'); --h; --v; }
+                else { status = AIM_PAIR_SWG_NO_OP; break; }
+            }
+        }
+    }
+    if (status == AIM_PAIR_OK) {
+        for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
+        if (h > 0) sentinel -= h;
+        for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
+        if (v > 0) sentinel -= v;
+    }
+    begin_offset = sentinel + 1;
 }
 
 #ifdef AIM_DPW_STAMPS   // diagnostic builds only: s_memtime per phase, summed by thread 0, dumped into the pair's ops row

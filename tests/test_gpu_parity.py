@@ -1173,7 +1173,7 @@ def test_fused_group_kernel_against_oracle(gpu, l, err, n, cost, bt):
             assert np.array_equal(out["res"]["score"], ores["score"])
 
 
-@pytest.mark.parametrize("env", [dict(AIM_GROUP_WLDS="64"), dict(AIM_SCRATCH_GB="2"), dict(AIM_GROUP_G="64"), dict(AIM_GROUP_G="2")])
+@pytest.mark.parametrize("env", [dict(AIM_GROUP_WLDS="64"), dict(AIM_SCRATCH_GB="4"), dict(AIM_GROUP_G="64"), dict(AIM_GROUP_G="2")])
 def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
     """The side roads of the fused group path: a narrow LDS window that pairs outgrow (they reach the general kernel through the
     to-do list: their packed rows are expanded for it and its ops rows are run-length encoded afterwards), a scratch bound that
@@ -1181,7 +1181,7 @@ def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
     from aim_amd import engine
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    l, err, n = 1000, 0.05, (5000 if "AIM_SCRATCH_GB" in env else 1500)   # 5000 history regions of 228 KB do not fit half of 2 GB
+    l, err, n = 1000, 0.05, (5000 if "AIM_SCRATCH_GB" in env else 1500)   # 5000 history regions of 228 KB do not fit a quarter of 4 GB (one of the two buffers)
     ms, rs = engine.launcher_sizes("wfa", l, err)
     req, pat, txt = engine.gen_pairs(17, 0, n, l, err, rs)
     pat[5, 17] = ord("N")
@@ -1279,3 +1279,26 @@ def test_host_cli_packed_input_file(gpu, sample_bytes, err_bytes, ref_digests, t
     assert r.returncode == 0 and "READ LENGTH less than length of the input reads" in r.stdout and (tmp_path / "p.out").read_bytes() == b""
     r = subprocess.run([host, str(tmp_path / "s.seq"), str(tmp_path / "p.out"), "20000", "--packed-input"] + base, capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode == 1 and "not a packed batch file" in r.stderr
+
+
+@pytest.mark.parametrize("env", [dict(), dict(AIM_GROUP_NO_OVERLAP="1")])
+def test_group_kernel_chunks_overlap_traceback_and_compute(gpu, monkeypatch, env):
+    """A batch larger than two rounds of wfa_group's persistent grid runs as several chunks: the traceback kernel of chunk c on
+    a second stream while chunk c + 1 is computed, two buffers of history regions alternating. Results must not depend on it
+    (AIM_GROUP_NO_OVERLAP=1: one launch, one stream): default ABI and fused I/O against the oracle, 150 000 pairs, three chunks."""
+    from aim_amd import engine
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    l, err, n = 100, 0.05, 150000
+    ms, rs = engine.launcher_sizes("wfa", l, err)
+    req, pat, txt = engine.gen_pairs(2718, 0, n, l, err, rs)
+    for i in range(0, n, 997):
+        pat[i, i % 50] = ord("N")
+    params = engine.make_params("wfa", ms, rs, backtrace=True, reduce=True)
+    ores, want = _oracle_text("wfa", params, req, pat, txt)
+    out, plan = _fused(params, req, pat, txt, runs_cap=n * 24, expect_kernel="wfa_group_kernel")
+    chunk = int(plan.split("chunk=")[1].split()[0])
+    assert (chunk < n) == (not env), plan
+    assert np.array_equal(out["cig"]["score"], ores["score"]) and engine.format_output_runs(out["cig"], out["runs"]) == want
+    res, ops = engine.align(params, req, pat, txt)
+    assert engine.format_output(res, ops, True) == want
