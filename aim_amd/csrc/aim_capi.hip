@@ -105,7 +105,7 @@ aim::Knobs read_knobs()
     k.no_group = env_flag("AIM_NO_GROUP");
     k.no_lane_ext = env_flag("AIM_NO_LANE_EXT");
     k.no_lane_pk = env_flag("AIM_NO_LANE_PK");
-    k.group_no_overlap = env_flag("AIM_GROUP_NO_OVERLAP");
+    k.group_overlap = env_flag("AIM_GROUP_OVERLAP");
     k.wfa_no_ring = env_flag("AIM_WFA_NO_RING");
     k.wfa_slotw = env_int("AIM_WFA_SLOTW", -1);
     k.force_dpwave = env_flag("AIM_FORCE_DPWAVE");
@@ -219,14 +219,17 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         if (group_ok && ghist_pair) {
             // BACKTRACE: every pair of a launch keeps its history region until the traceback kernel has walked it. Launches are
             // chunks of the batch whose regions fit half of the scratch bound (one chunk whenever possible).
-            // Two buffers of regions alternate, so that the traceback kernel of one chunk (second stream) overlaps the compute
-            // kernel of the next; a chunk is two rounds of the persistent grid (so that chunking costs no partial rounds).
+            // One launch when the regions fit. (AIM_GROUP_OVERLAP=1: chunks of two grid rounds, two alternating buffers of regions, the
+            // traceback kernel of chunk c on a second stream while chunk c + 1 is computed. Measured and NOT adopted: cfg3 3.57 ->
+            // 3.79 ms, l = 100 e = 5 % 1.62 -> 1.75 ms -- several shorter compute launches lose more to ramp-up and partial rounds than
+            // the overlapped 10 % traceback gives back. Kept as a tested code path: it is also what a batch does whose regions do
+            // not fit the scratch bound.)
             const uint64_t fit = (budget / 4) / ghist_pair;          // per buffer
             if (fit < 4096 && fit < n_pairs) group_ok = false;   // too few pairs in flight to fill the chip: the general kernel's pools are smaller
             else {
                 const uint64_t two_rounds = 2ull * ggrid * (uint64_t)(64 / gg);
                 uint64_t chunk = std::min<uint64_t>(fit, std::max<uint64_t>(two_rounds, 4096));
-                if (chunk >= n_pairs || kn.group_no_overlap) chunk = std::min<uint64_t>(n_pairs, 2 * fit);   // one launch (or as few as fit)
+                if (chunk >= n_pairs || !kn.group_overlap) chunk = std::min<uint64_t>(n_pairs, 2 * fit);   // one launch (or as few as fit)
                 gchunk = (uint32_t)chunk;
                 if (gchunk < n_pairs) gchunk &= ~63u;
                 const uint32_t nchunks = (n_pairs + gchunk - 1) / gchunk;

@@ -88,7 +88,7 @@ struct Knobs {
     bool no_group = false;        // AIM_NO_GROUP=1      WFA: skip wfa_group_kernel
     bool no_lane_ext = false;     // AIM_NO_LANE_EXT=1   WFA: only the (3,4,1) MAX_SCORE<=5 lane shapes (round-1 behaviour)
     bool no_lane_pk = false;      // AIM_NO_LANE_PK=1    packed batches: always unpack to ASCII rows first (round-2 behaviour)
-    bool group_no_overlap = false;// AIM_GROUP_NO_OVERLAP=1  wfa_group with CIGAR: one launch, traceback kernel on the same stream (no second stream)
+    bool group_overlap = false;   // AIM_GROUP_OVERLAP=1 wfa_group with CIGAR: chunked launches, traceback kernel of chunk c on a second stream under chunk c+1's compute
     bool wfa_no_ring = false;     // AIM_WFA_NO_RING=1   wfa_wave: no LDS offset ring
     int wfa_slotw = -1;           // AIM_WFA_SLOTW       wfa_wave: diagonals per ring slot
     bool force_dpwave = false;    // AIM_FORCE_DPWAVE=1  NW/SWG: row-scan kernel also for short reads
