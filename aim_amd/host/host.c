@@ -16,7 +16,7 @@
  *     --gpus N      physical MI355X devices to shard each batch over
  *     --batch B     pairs per device per launch (default 4194304)
  *     --threads T   host threads for parsing / formatting (default: all cores, max 512; two thirds parse + pack the next
- *                   batch while one third formats + writes the previous one)
+ *                   batch while one third formats the previous one and one more thread writes the one before)
  *     --packed-input  <input> is a packed batch file (written by --pack-only or `python -m aim_amd.gen_dataset --packed`):
  *                   2 bits per base + raw side list, ready for the device; no text is parsed
  * The UPMEM dispatch (dpu_alloc/dpu_load/dpu_push_xfer/dpu_launch) is replaced
@@ -699,7 +699,7 @@ int main(int argc, char *argv[])
     const uint64_t pair_cap = (uint64_t)nb_reads_per_dpu * nr_dpus; /* H3: what the reference would consume */
 
     /* two pools: parse + pack of the next batch || format + write of the previous one */
-    int fmt_threads = threads >= 3 ? threads / 3 : 1, pack_threads = threads >= 3 ? threads - fmt_threads : threads;
+    int fmt_threads = threads >= 3 ? threads / 3 : 1, pack_threads = threads >= 3 ? threads - fmt_threads : threads;   /* 32 + 16 of 48: on one box 3.3-3.5e8 pairs/s against 2.8-3.3e8 for 28 + 20 and 3.1-3.2e8 for 24 + 24 */
     if (pack_threads_arg > 0) pack_threads = pack_threads_arg;
     if (fmt_threads_arg > 0) fmt_threads = fmt_threads_arg;
     pool_init(&g_pack_pool, 0, pack_threads);
@@ -747,7 +747,7 @@ int main(int argc, char *argv[])
         }
         if (sc.malformed) { fprintf(stderr, "malformed input (a line shorter than 2 characters)\n"); exit(1); }
     }
-    double parse_ms = now_ms() - t_index, write_ms = 0, wait_ms = 0;
+    double parse_ms = now_ms() - t_index, write_ms = 0, wait_ms = 0, join_ms = 0, submit_ms = 0, wrwait_ms = 0;
 
     /* batches: enough of them to keep every (device, slot) busy, none larger than --batch */
     const uint32_t ring = gpus * slots;
@@ -903,7 +903,9 @@ int main(int argc, char *argv[])
             const size_t batch_at = out_at;
             for (int t = 0; t < g_fmt_pool.n; ++t) { f.off[t] = out_at; out_at += f.len[t]; }
             if (g_writer.started) {   /* hand the printed batch to the writer; the next one is printed into the other buffer set */
+                const double tw = now_ms();
                 writer_submit(&g_writer, g_fmt_pool.n, f.buf, f.len, f.off);
+                wrwait_ms += now_ms() - tw;
                 if (g_writer.failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", out); return 1; }
                 f.set ^= 1;
                 f.buf = f.bufs[f.set]; f.cap = f.caps[f.set]; f.len = f.lens[f.set]; f.off = f.offs[f.set];
@@ -928,8 +930,10 @@ int main(int argc, char *argv[])
             if (!pairs_first_done) { pairs_first_done = done; t_first_done = now_ms(); }
         }
         if (have_new) {
+            const double tj = now_ms();
             if (packed_input) pool_join(&g_pack_pool);
             else pack_finish(j, batch);
+            join_ms += now_ms() - tj;                      /* what the pack still needed after the format stage was done */
             parse_ms += now_ms() - t_pack;                 /* (overlaps the format + write above) */
             if (it == 0) { printf("Copying data to DPU\n"); printf("Run program on DPU(s)\n"); }
             aim_batch_io_t io;
@@ -946,7 +950,9 @@ int main(int argc, char *argv[])
             else { io.cigars = j->cig; io.runs = j->runs; io.runs_cap = runs_cap; }
             j->io = io;
             j->use_full = 0;
+            const double ts = now_ms();
             if ((rc = aim_set_submit(set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
+            submit_ms += now_ms() - ts;
             j->in_flight = 1;
             sent += j->n;
             if (packed_input && sent < total_pairs && it + 1 == n_jobs) { fprintf(stderr, "'%s': fewer pairs than its header states\n", in); exit(1); }
@@ -971,8 +977,8 @@ int main(int argc, char *argv[])
     /* steady state: from the moment the first batch is on disk to the last one (start-up -- HIP context, pinned buffers, the
        pipeline filling -- excluded) */
     const double steady = (done > pairs_first_done && t_end > t_first_done) ? (double)(done - pairs_first_done) / ((t_end - t_first_done) * 1e-3) : 0.0;
-    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms (line index %.3f ms), wait %.3f ms, format+write %.3f ms, loop %.3f ms, steady %.4g pairs/s; input %s, output %s\n",
-           (unsigned long long)done, (unsigned long long)n_jobs, batch, gpus, slots, parse_ms, index_ms, wait_ms, write_ms, t_end - t_loop, steady,
+    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms (line index %.3f ms), wait %.3f ms, format+write %.3f ms, loop %.3f ms, steady %.4g pairs/s (in the loop: pack join %.3f ms, writer hand-over %.3f ms, submit %.3f ms); input %s, output %s\n",
+           (unsigned long long)done, (unsigned long long)n_jobs, batch, gpus, slots, parse_ms, index_ms, wait_ms, write_ms, t_end - t_loop, steady, join_ms, wrwait_ms, submit_ms,
            packed_input ? "packed batch file" : (no_pack ? "ASCII rows" : "packed 2 bit/base"), !backtrace ? "{idx, score}" : (full_ops ? "ops rows" : "device-side RLE"));
 
     pool_stop(&g_pack_pool);
