@@ -118,6 +118,7 @@ aim::Knobs read_knobs()
     k.group_g = env_int("AIM_GROUP_G", -1);
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
     k.group_wlds = env_int("AIM_GROUP_WLDS", -1);
+    k.group_unit1 = env_int("AIM_GROUP_UNIT1", 0);
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
     k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;
@@ -229,7 +230,8 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             else {
                 const uint64_t two_rounds = 2ull * ggrid * (uint64_t)(64 / gg);
                 uint64_t chunk = std::min<uint64_t>(fit, std::max<uint64_t>(two_rounds, 4096));
-                if (chunk >= n_pairs || !kn.group_overlap) chunk = std::min<uint64_t>(n_pairs, 2 * fit);   // one launch (or as few as fit)
+                if (n_pairs <= 2 * fit && (chunk >= n_pairs || !kn.group_overlap)) chunk = n_pairs;   // one launch, one buffer of regions (half the bound)
+                else if (!kn.group_overlap) chunk = fit;                                                  // as few launches as fit, over the two buffers
                 gchunk = (uint32_t)chunk;
                 if (gchunk < n_pairs) gchunk &= ~63u;
                 const uint32_t nchunks = (n_pairs + gchunk - 1) / gchunk;

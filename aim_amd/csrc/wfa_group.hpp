@@ -59,6 +59,9 @@ struct GroupCfg {
                       // window": homes are (k + kbias) & wmask; a pair whose wavefront outgrows wlds - 2 diagonals is handed
                       // to the general kernel through the to-do list, like a pair with non-ACGT bytes)
     int wmask;        // wlds - 1 in narrow mode, 0xffff otherwise
+    int unit;         // score unit: gcd(x, o+e, e). Only multiples of it have a wavefront (every score is a sum of penalties), so the
+                      // score loop counts in units -- row s of the rings / of the history table is score s * unit -- and never
+                      // visits the null wavefronts in between (x = 4, o = 6, e = 2: every second step of the reference's loop)
 };
 
 enum { GF_PRESENT = 1, GF_MNULL = 2, GF_INULL = 4, GF_DNULL = 8, GF_HASI = 16, GF_HASD = 32 };
@@ -120,7 +123,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
     uint32_t *packed = mine + ((c.ring_m + 2 * c.ring_e) * c.wlds * 2 + c.ring_m * 8 + 3) / 4;   // P then T, np dwords each
     uint32_t *pkP = packed, *pkT = packed + c.np;
 
-    const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
+    const int U = c.unit;                                // scores below are in units of U (GroupCfg::unit)
+    const int X = a.p.mismatch / U, OE = (a.p.gap_o + a.p.gap_e) / U, E = a.p.gap_e / U, MS = a.p.max_score;
     const int kb = c.kbias;
     uint32_t *todo = reinterpret_cast<uint32_t *>(a.scratch);
     // BACKTRACE: every wavefront is also streamed to the pair's history region in HBM (GroupCfg); wfa_group_tb_kernel walks it.
@@ -329,10 +333,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                 // affine_wfa_end_reached, wfa.c:210-230
                 if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[H(ak)] >= tlen) {
                     done = true;
-                    final_score = score;
-                } else if (score + 1 > MS) {   // wfa.c:368-376
+                    final_score = score * U;
+                } else if ((score + 1) * U > MS) {   // wfa.c:368-376: the reference steps through the null wavefronts up to MAX_SCORE and leaves with MAX_SCORE + 1
                     done = true;
-                    final_score = score + 1;
+                    final_score = MS + 1;
                 }
             }
             AIM_GSTAMP(1);   // reduce + descriptors + end test
@@ -583,7 +587,8 @@ __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
     const uint32_t pair = blockIdx.x * kWave + lane;
     const bool in_batch = pair < a.n_pairs;
     const int rs = a.p.read_size;
-    const int X = a.p.mismatch, OE = a.p.gap_o + a.p.gap_e, E = a.p.gap_e, MS = a.p.max_score;
+    const int U = c.unit;                                // the history table is indexed in score units (GroupCfg::unit)
+    const int X = a.p.mismatch / U, OE = (a.p.gap_o + a.p.gap_e) / U, E = a.p.gap_e / U, MS = a.p.max_score;
     char *hreg = a.scratch + a.scratch_per_wave + (size_t)(in_batch ? pair : 0u) * (size_t)c.hist_pair_bytes;
     const TbHead hd = *reinterpret_cast<const TbHead *>(hreg);
     const bool active = in_batch && hd.walk == 1;        // pairs on the to-do list belong to the general kernel
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
     int status = AIM_PAIR_OK;
     if constexpr (RUNS) {
         RunCollector<1> coll(plen + tlen - 1, reinterpret_cast<uint32_t *>(hreg + c.runs_off), c.runs_cap);
-        if (walk) status = group_tb_walk(tab, pool, final_score, plen, tlen, X, OE, E, coll);
+        if (walk) status = group_tb_walk(tab, pool, final_score / U, plen, tlen, X, OE, E, coll);
         coll.flush();
         if (coll.n == 0) {   // nothing inside [0, end): edit_cigar_print still prints operations[begin_offset] = 'M'
             coll.cur_op = (uint32_t)'M'; coll.cur_len = 1u;
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
         sink.cap = 2 * rs;
         sink.pos = plen + tlen - 1;                       // edit_cigar_allocate, wfa.c:57-67
         if (walk) {
-            status = group_tb_walk(tab, pool, final_score, plen, tlen, X, OE, E, sink);
+            status = group_tb_walk(tab, pool, final_score / U, plen, tlen, X, OE, E, sink);
             if (status == AIM_PAIR_OK) ++sink.pos;
         }
         if (active) {
@@ -640,6 +645,11 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     ring_m = R + 1;
     while (ring_e <= p.gap_e) ring_e *= 2;
     if (ring_m > 32 || ring_e > 16) return false;
+    {
+        auto gcd = [](int a_, int b_) { while (b_) { const int t = a_ % b_; a_ = b_; b_ = t; } return a_; };
+        const int u = gcd(gcd(p.mismatch, p.gap_o + p.gap_e), p.gap_e);
+        c->unit = (u > 1 && !kn.group_unit1) ? u : 1;
+    }
     c->kbias = p.max_score + 1;
     c->wcap = 2 * p.max_score + 3;
     c->ring_m = ring_m;
@@ -718,8 +728,8 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     if (gr > need) gr = need < 8u ? 8u : need;
     *grid = gr;
     if (kn.plan_debug)
-        fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u wlds=%d\n", g, ring_m, ring_e,
-                c->wcap, dw * 4, *lds, lds_fit, per_cu, gr, c->wlds);
+        fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u wlds=%d unit=%d\n", g, ring_m, ring_e,
+                c->wcap, dw * 4, *lds, lds_fit, per_cu, gr, c->wlds, c->unit);
     // BACKTRACE: the per-pair history region (GroupCfg). The pool holds, per score, the 3 * width cells the compute kernel
     // stores; a wavefront is at most 2s+1 diagonals wide and at most what the LDS row admits (a pair beyond that leaves for
     // the to-do list before anything of the offending score is stored).

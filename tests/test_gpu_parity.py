@@ -134,7 +134,9 @@ def test_wfa_custom_penalties_and_overflow(gpu, force_wave, monkeypatch):
     from aim_amd import engine
     monkeypatch.setenv("AIM_FORCE_WAVE", force_wave)
     for (x, o, e), err, ms_override in (((4, 6, 2), 0.05, None), ((2, 3, 1), 0.05, None), ((5, 4, 2), 0.03, None),
-                                        ((3, 4, 1), 0.05, 7), ((1, 1, 1), 0.04, None)):
+                                        ((3, 4, 1), 0.05, 7), ((1, 1, 1), 0.04, None),
+                                        # gcd(x, o+e, e) > 1: wfa_group_kernel counts in score units (GroupCfg::unit) -- caps on both sides of a multiple
+                                        ((4, 6, 2), 0.05, 9), ((4, 6, 2), 0.05, 10), ((2, 4, 2), 0.05, None), ((6, 3, 3), 0.04, 14), ((6, 3, 3), 0.04, None)):
         ms, rs = engine.launcher_sizes("wfa", 100, err, mismatch=x, gap_o=o, gap_e=e)
         if ms_override is not None:
             ms = ms_override
@@ -1181,7 +1183,7 @@ def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
     from aim_amd import engine
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    l, err, n = 1000, 0.05, (5000 if "AIM_SCRATCH_GB" in env else 1500)   # 5000 history regions of 228 KB do not fit a quarter of 4 GB (one of the two buffers)
+    l, err, n = 1000, 0.05, (9600 if "AIM_SCRATCH_GB" in env else 1500)   # 9600 history regions of 228 KB do not fit half of a 4 GB bound
     ms, rs = engine.launcher_sizes("wfa", l, err)
     req, pat, txt = engine.gen_pairs(17, 0, n, l, err, rs)
     pat[5, 17] = ord("N")
