@@ -58,7 +58,10 @@ struct GroupCfg {
     int wlds;         // entries per ring row IN LDS: wcap (every diagonal has its own home), or a power of two < wcap ("narrow
                       // window": homes are (k + kbias) & wmask; a pair whose wavefront outgrows wlds - 2 diagonals is handed
                       // to the general kernel through the to-do list, like a pair with non-ACGT bytes)
-    int wmask;        // wlds - 1 in narrow mode, 0xffff otherwise
+    int wmask;        // wlds - 1 in narrow mode, 0xffff otherwise (REDUCE = false kernels: home = (k + kbias) & wmask)
+    int wmagic;       // MODW kernels (G = 16 with the reduction): rows that are no power of two -- home = t - ((t * wmagic) >> 16) * wlds with
+                      // t = k + kbias, i.e. t mod wlds for wmagic = ceil(65536 / wlds). Rows of 96 hold cfg3 at 16 workgroups per CU where 128
+                      // hold 12. 0 = the other kernels (mask).
     int unit;         // score unit: gcd(x, o+e, e). Only multiples of it have a wavefront (every score is a sum of penalties), so the
                       // score loop counts in units -- row s of the rings / of the history table is score s * unit -- and never
                       // visits the null wavefronts in between (x = 4, o = 6, e = 2: every second step of the reference's loop)
@@ -98,7 +101,7 @@ __device__ __forceinline__ int group_min(int v)
 #else
 #define AIM_GSTAMP(i) do { } while (0)
 #endif
-template <int G, bool REDUCE, bool BT>
+template <int G, bool REDUCE, bool BT, bool MODW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MIN_WAVES))) void wfa_group_kernel(KArgs a, GroupCfg c)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -155,7 +158,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
     int score = 0, sm = 0, i_x = 0, i_oe = 0, i_e = 0;
     auto back = [&](int d) { const int i = sm - d; return i < 0 ? i + c.ring_m : i; };   // 0 <= d < ring_m
     const int wmask = c.wmask;
-    auto H = [&](int k) { return (k + kb) & wmask; };                                // home of diagonal k inside a ring row
+    const uint32_t wmagic = (uint32_t)c.wmagic;
+    const int wl = c.wlds;
+    auto H = [&](int k) {                                                            // home of diagonal k inside a ring row
+        const int t = k + kb;                                                        // 0 <= t < wcap
+        if constexpr (MODW) return t - (int)__umul24(__umul24((uint32_t)t, wmagic) >> 16, (uint32_t)wl);   // t mod wlds (GroupCfg::wmagic); 24-bit multiplies are full rate, v_mul_lo_u32 is not
+        else return t & wmask;
+    };
     auto mrow_at = [&](int i) { return Mw + i * c.wlds; };                           // row base: row[H(k)]
     auto meta_at = [&](int i) { return meta + i * 4; };
     auto islot = [&](int s) { return Iw + (s & (c.ring_e - 1)) * c.wlds; };
@@ -635,8 +644,8 @@ __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
 // ---------------------------------------------------------------------------------------------------------------
 // hist_pair_bytes: bytes of ONE pair's history region (BACKTRACE; 0 otherwise) -- the caller sizes launches (chunks of pairs)
 // so that their regions fit its scratch bound. packed: the batch arrives packed (no staging rows in LDS).
-inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, bool packed, GroupCfg *c, int *G, uint32_t *grid, size_t *lds,
-                           size_t *hist_pair_bytes)
+inline bool wfa_group_plan_rows(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, bool packed, int rows, GroupCfg *c, int *G, uint32_t *grid,
+                                size_t *lds, size_t *hist_pair_bytes)   // rows: entries per LDS ring row asked for; < 0 = the default rule
 {
     if (p.algo != AIM_ALGO_WFA) return false;
     if (p.read_size > 2048 || p.max_score > 400) return false;
@@ -662,13 +671,23 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     // this latency-bound kernel lacked. A wavefront that outgrows 126 diagonals sends its pair to the general kernel.
     c->wlds = c->wcap;
     c->wmask = 0xffff;
+    c->wmagic = 0;
     {
         // (same-box probe, tools/group_policy2.py, score-only kernel ms, row of 128 vs one home per diagonal at the better G:
         // l=1000 e=5% 3.76 vs 6.06; l=400 e=10% 1.57 vs 2.29; l=500 e=5% 1.89 vs 2.12; l=250 e=10% 1.87 vs 2.18; l=1000 e=2% 1.63
         // vs 1.63; no pair of these sets outgrew the row. Rows of 64 cost 0.3-47 % of the pairs a detour, rows of 32 most.)
         int narrow = (p.flags & AIM_FLAG_REDUCE) && c->wcap >= 192 ? 128 : 0;   // without the reduction widths grow with the score
-        if (kn.group_wlds >= 0) narrow = kn.group_wlds;
-        if (narrow >= 16 && (narrow & (narrow - 1)) == 0 && narrow < c->wcap) { c->wlds = narrow; c->wmask = narrow - 1; }
+        if (rows >= 0) narrow = rows;
+        const bool pow2 = (narrow & (narrow - 1)) == 0;
+        if (narrow >= 16 && narrow < c->wcap) {
+            if (pow2) { c->wlds = narrow; c->wmask = narrow - 1; }
+            else if (narrow % 8 == 0 && (p.flags & AIM_FLAG_REDUCE)) {   // MODW kernels; the caller checks that the plan comes out at G = 16
+                const int magic = (65536 + narrow - 1) / narrow;
+                bool exact = true;                           // (t * magic) >> 16 == t / narrow for every home index the kernel forms
+                for (int t = 0; t <= c->wcap + 2 && exact; ++t) exact = (int)(((uint32_t)t * (uint32_t)magic) >> 16) == t / narrow;
+                if (exact) { c->wlds = narrow; c->wmask = 0; c->wmagic = magic; }
+            }
+        }
     }
     int dw = ((ring_m + 2 * ring_e) * c->wlds * 2 + ring_m * 8 + 3) / 4 + 2 * c->np;
     dw |= 1;
@@ -747,6 +766,25 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     return true;
 }
 
+// Rows of the LDS rings. One home per diagonal up to MAX_SCORE 94; beyond that, with the reduction, rows of 128 addressed modulo 128 --
+// or of 96 where the launcher's MAX_SCORE says the error rate is 5 % or less (4 * MAX_SCORE <= READ_SIZE): at 16 workgroups per CU instead
+// of 12 the latency-bound score step has a third more wavefronts to hide behind. Same box, kernel ms, rows of 128 -> 96, pairs leaving
+// for the general kernel in brackets: l=1000 e=5 % 3.09 -> 2.82 (0), with CIGAR 3.63 -> 3.41; l=500 e=5 % 1.54 -> 1.41 (0); l=1000 e=2 %
+// 1.21 -> 1.10 (0); but l=400 e=10 % 1.34 -> 1.73 (57 of 32 768) and l=250 e=10 % 1.59 -> 1.82 (38 of 65 536): every pair that outgrows
+// its row costs a whole general-kernel pass, so wide wavefronts keep 128. (Rows of 80: 42 pairs of cfg3 leave, 3.50 ms; tools/group_rows.py.)
+inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, bool packed, GroupCfg *c, int *G, uint32_t *grid, size_t *lds,
+                           size_t *hist_pair_bytes)
+{
+    int rows = kn.group_wlds;
+    if (rows < 0 && (p.flags & AIM_FLAG_REDUCE) && 2 * p.max_score + 3 >= 192 && 4 * p.max_score <= p.read_size) rows = 96;
+    if (rows >= 16 && (rows & (rows - 1)) != 0) {   // no power of two: only the G = 16 kernels address such rows
+        Knobs quiet = kn;
+        quiet.plan_debug = 0;
+        if (!wfa_group_plan_rows(p, n_pairs, quiet, packed, rows, c, G, grid, lds, hist_pair_bytes) || *G != 16 || c->wmagic == 0) rows = -1;
+    }
+    return wfa_group_plan_rows(p, n_pairs, kn, packed, rows, c, G, grid, lds, hist_pair_bytes);
+}
+
 inline void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pairs, const KArgs &ka, hipStream_t s)
 {
     (void)p;
@@ -765,6 +803,11 @@ inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, ui
         else if (bt) hipLaunchKernelGGL((wfa_group_kernel<GG, false, true>), dim3(grid), dim3(kWave), lds, s, ka, c);   \
         else hipLaunchKernelGGL((wfa_group_kernel<GG, false, false>), dim3(grid), dim3(kWave), lds, s, ka, c);          \
     } while (0)
+    if (c.wmagic) {   // rows that are no power of two (the planner admits them at G = 16 with the reduction only)
+        if (bt) hipLaunchKernelGGL((wfa_group_kernel<16, true, true, true>), dim3(grid), dim3(kWave), lds, s, ka, c);
+        else hipLaunchKernelGGL((wfa_group_kernel<16, true, false, true>), dim3(grid), dim3(kWave), lds, s, ka, c);
+        return;
+    }
     switch (G) {
     case 1: AIM_GRP(1); break;
     case 2: AIM_GRP(2); break;

@@ -131,7 +131,9 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
     assert G(100, 0.02, AIM_NO_LANE_EXT="1")[2] == 11          # G = 4: 12.8 KB incl. LDS staging rows
     # round 2: groups of >= 8 lanes pack straight from global memory (no staging rows) and up to 20 workgroups per CU are used
     assert G(250, 0.05)[2] == 14 and G(100, 0.05)[2] == 16 and G(100, 0.10)[2] == 16   # 11.2 KB / 9.4 KB / 8.8 KB workgroups (18 fit: kept a multiple of the 4 SIMDs)
-    assert G(1000, 0.05)[2] == 12                  # score-only, 12.7-KB workgroups of four pairs: 12 fit
+    assert G(1000, 0.05, AIM_GROUP_WLDS="128")[2] == 12    # score-only, 12.7-KB workgroups of four pairs with rows of 128: 12 fit
+    assert G(1000, 0.05)[2] == 16 and G(400, 0.10)[2] == 14  # rows of 96 where 4 * MAX_SCORE <= READ_SIZE (10.1-KB workgroups); 128 for wider wavefronts
+    assert G(1000, 0.05, AIM_GROUP_WLDS="96", AIM_GROUP_G="32")[0] == 32   # (only the G = 16 kernels address rows that are no power of two: back to 128)
     assert G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14              # 10.7 KB
 
 
