@@ -281,6 +281,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
         // Every later wavefront is extended by the lane that computes it (below); score 0 has no compute step.
         int part = 0x7fffffff;                     // min over my diagonals of the distance to the end (for the reduction)
+        int dist0 = 0x7fffffff, dist1 = 0x7fffffff; // that distance on my first and second diagonal of the current row
         // history region of this pair (BACKTRACE): descriptor table + pool; h_off / h_lo / h_hi describe the current score's row
         char *hreg = BT ? hist_base + (size_t)(active ? pair : 0u) * (size_t)c.hist_pair_bytes : nullptr;
         TbRow *htab = reinterpret_cast<TbRow *>(hreg + sizeof(TbHead));
@@ -311,7 +312,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     // bottom_limit -- are min(top_limit, lowest) and max(bottom_limit, highest) over the whole row.
                     const int mind = min(max(plen, tlen), group_min<G>(part));
                     int kfirst = 0x7fffffff, klast = -0x7fffffff;
-                    for (int k = klo + g; k <= khi; k += G) {
+                    // A live row was computed by the previous score step over the same [klo, khi] with the same lanes: the distances of
+                    // my first two diagonals are still in registers (dist0, dist1); only rows wider than 2 G are read back from LDS.
+                    {
+                        const int k0 = klo + g, k1 = k0 + G;
+                        const bool c0 = k0 <= khi && dist0 - mind <= 50, c1 = k1 <= khi && dist1 - mind <= 50;
+                        kfirst = c0 ? k0 : (c1 ? k1 : kfirst);
+                        klast = c1 ? k1 : (c0 ? k0 : klast);
+                    }
+                    for (int k = klo + g + 2 * G; k <= khi; k += G) {
                         const int off = mrow[H(k)];
                         if ((max(plen - (off - k), tlen - off) - mind) <= 50) { kfirst = min(kfirst, k); klast = max(klast, k); }
                     }
@@ -407,7 +416,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     const int16_t *r_ie = islot(s_e < 0 ? 0 : s_e), *r_de = dslot(s_e < 0 ? 0 : s_e);
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
                     part = 0x7fffffff;
-                    for (int k = lo + g; k <= hi_run; k += G) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
+                    int trip = 0;
+                    for (int k = lo + g; k <= hi_run; k += G, ++trip) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
                         // The five source cells are fetched TOGETHER and unconditionally (every row is a valid LDS row of
                         // wcap = 2*MAX_SCORE+3 entries and |k +- 1| <= MAX_SCORE+1, so the addresses are always in bounds);
                         // AFFINE_WAVEFRONT_COND_FETCH's range / null tests then select. Guarded reads compiled to one
@@ -441,7 +451,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         const int ext = extend(k, (int)(int16_t)max(del, max(sub, ins)));
                         om[hk] = (int16_t)ext;
                         if (BT) hrow[k] = make_uint2((uint32_t)(uint16_t)ext | ((uint32_t)(uint16_t)ins << 16), (uint32_t)(uint16_t)del);   // I / D: -10 when absent (never selected)
-                        part = min(part, max(plen - (ext - k), tlen - ext));
+                        const int dist = max(plen - (ext - k), tlen - ext);
+                        part = min(part, dist);
+                        if (REDUCE) { dist0 = trip == 0 ? dist : dist0; dist1 = trip == 1 ? dist : dist1; }
                     }
                 }
                 AIM_GSTAMP(3);   // compute + extend loop
