@@ -119,6 +119,7 @@ aim::Knobs read_knobs()
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
     k.group_wlds = env_int("AIM_GROUP_WLDS", -1);
     k.group_unit1 = env_int("AIM_GROUP_UNIT1", 0);
+    k.ga_long = env_int("AIM_GA_LONG", -1);
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
     k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;
@@ -193,7 +194,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     if (p.algo == AIM_ALGO_GENASM) {
         pl->kid = K_GENASM;
-        aim::genasm_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+        aim::genasm_plan(p, kn, n_pairs, &pl->grid, &pl->block, &pl->lds);
         pl->scratch_per_wg = aim::kGaSlabBytes;
         pl->scratch_total = (size_t)pl->grid * aim::kGaSlabBytes;   // slow-path columns, one slab per wavefront
         return AIM_OK;
@@ -643,7 +644,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         aim::dp_strip_launch(p, pl.strip_k, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_GENASM:
-        aim::genasm_launch(p, pl.grid, pl.lds, ka, stream);
+        aim::genasm_launch(p, kn, pl.grid, pl.lds, ka, stream);
         break;
     }
     HIP_TRY(hipGetLastError());

@@ -147,13 +147,85 @@ __device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t m
     }
     return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
 }
+// LONG variant (long reads: thousands of windows per pair, almost none of them the last). A window that is not the last one commits
+// kGaCommit = 40 characters, so its traceback never reads a column above 41: the sweep still runs over all n columns but keeps only
+// columns 41 .. 0 -- [56 .. -15] with the 15 padding columns either side that the skew needs -- and the pattern masks move to an array
+// of their own: 72 x 16 x 8 B + 96 x 8 B = 9.8 KB instead of 13 KB per wavefront, i.e. 16 wavefronts per CU instead of 12 (4 096 pairs
+// of BASELINE config 5 are resident at once). The first n - 42 steps, while even level 0 is above column 41, store nothing.
+// The pair's LAST window needs every column: it takes the 64-level path (one window in ~2 500).
+constexpr int kGlTop = kGaCommit + 1;                                 // highest column the traceback of a non-final window reads
+constexpr int kGlCols = 15 + kGlTop + 1 + 15;                         // columns 56 .. -15
+constexpr int kGlPm = kGaW + 16 + 16;                                 // pattern masks of columns 79 .. -16
+__device__ __forceinline__ int gl_slot(int col) { return (kGlTop + 15 - col) * 16; }   // descending, like ga_slot
+__device__ __forceinline__ int gl_pm(int col) { return kGlCols * 16 + (kGaW + 15 - col); }
+__device__ __forceinline__ uint64_t ga_dc16_long(int n_, int m_, int lane, uint64_t mypm, uint64_t *Rs)
+{
+    constexpr uint64_t ONES = ~0ull;
+    const int n = __builtin_amdgcn_readfirstlane(n_), m = __builtin_amdgcn_readfirstlane(m_);
+    if (lane < n) Rs[gl_pm(lane)] = mypm;
+    uint64_t hit = 0;
+    if (lane < 16) {
+        Rs[gl_pm(n + lane)] = ONES;
+        uint64_t cur = ONES << lane;                     // R_n[d]
+        if (n <= kGlTop + 15) Rs[gl_slot(n) + lane] = cur;
+        const uint64_t lane0 = lane == 0 ? ONES : 0ull;
+        const uint64_t endbit = 1ull << (m - 1);
+        const int nA = n - 1 > kGlTop ? n - 1 - kGlTop : 0;               // steps before level 0 reaches column 41 (wave-uniform)
+        uint64_t *rp = Rs + gl_slot(n - 1 - nA + lane) + lane;           // my R slot of my column at step nA
+        const uint64_t *pp = Rs + gl_pm(n - 1 + lane);                   // my column's pattern mask at step 0
+        auto shr1 = [](uint64_t v) -> uint64_t {         // lane d-1's value; lane 0 receives 0 (bound_ctrl), OR-ed away below
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x111, 0xf, 0xf, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x111, 0xf, 0xf, true);
+            return ((uint64_t)hi << 32) | lo;
+        };
+        // one step (ga_dc16); `st` false: above column 41, nothing is kept
+        auto step = [&](const uint64_t &nb_prev, uint64_t &nb_cur, const uint64_t &pm_now, uint64_t &pm_next, int k, auto st) {
+            pm_next = pp[k + 1];
+            nb_cur = shr1(cur);
+            const uint64_t t = (((nb_prev & nb_cur) << 1) & nb_prev) | lane0;
+            cur = ((cur << 1) | pm_now) & t;
+            if constexpr (decltype(st)::value) rp[k * 16] = cur;
+        };
+        uint64_t nbA = shr1(cur), nbB, pmA = pp[0], pmB;
+        int u = 0;
+        for (; u + 2 <= nA; u += 2) {
+            step(nbA, nbB, pmA, pmB, 0, std::false_type{});
+            step(nbB, nbA, pmB, pmA, 1, std::false_type{});
+            pp += 2;
+        }
+        if (u < nA) {
+            step(nbA, nbB, pmA, pmB, 0, std::false_type{});
+            nbA = nbB; pmA = pmB;
+            pp += 1;
+        }
+        for (u = nA; u + 2 <= n - 1; u += 2) {           // no level has reached column 0 yet
+            step(nbA, nbB, pmA, pmB, 0, std::true_type{});
+            step(nbB, nbA, pmB, pmA, 1, std::true_type{});
+            rp += 2 * 16;
+            pp += 2;
+        }
+        if (u < n - 1) {
+            step(nbA, nbB, pmA, pmB, 0, std::true_type{});
+            nbA = nbB; pmA = pmB;
+            rp += 16; pp += 1;
+        }
+        for (u = n - 1; u < n + 15; ++u) {               // level u - (n-1) completes column 0 in this step
+            step(nbA, nbB, pmA, pmB, 0, std::true_type{});
+            nbA = nbB; pmA = pmB;
+            rp += 16; pp += 1;
+            hit = __ballot(lane == u - (n - 1) && !(cur & endbit));
+            if (hit) break;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
+}
 #ifdef AIM_GA_STAMPS   // diagnostic builds only: s_memtime per phase of a window, summed per pair, dumped into the pair's ops row
 #define AIM_GASTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); gsum[i] += t_ - glast; glast = t_; } while (0)
 #else
 #define AIM_GASTAMP(i) do { } while (0)
 #endif
-template <bool BT>
+template <bool BT, bool LONG>
 __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,7 +275,9 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             // FAST PATH: levels 0..15 only. Level d of a column depends on levels <= d only, so these are exactly the first 16 of
             // the full computation; if the window aligns within 15 edits (at e = 10 % a 64-character window carries ~6) the
             // traceback never looks further.
-            uint64_t hit = ga_dc16(n, m, lane, mypm, Rs);
+            uint64_t hit = 0;
+            if (!LONG) hit = ga_dc16(n, m, lane, mypm, Rs);
+            else if (!last) hit = ga_dc16_long(n, m, lane, mypm, Rs);   // (the last window's traceback may read every column: 64-level path)
             const bool slow = !hit;            // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
             if (slow) {
@@ -238,11 +312,12 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 // the same tests in the same order as the step-by-step walk (oracle/genasm_oracle.c), without a second fetch.
                 auto walk = [&](auto slow_tag) {
                     constexpr bool SLOW = decltype(slow_tag)::value;
-                    auto Rf = [&](int col, int lvl) -> uint64_t { return SLOW ? Rg[col * 64 + lvl] : Rs[ga_slot(col) + lvl]; };
+                    auto Rf = [&](int col, int lvl) -> uint64_t { return SLOW ? Rg[col * 64 + lvl] : Rs[(LONG ? gl_slot(col) : ga_slot(col)) + lvl]; };
+                    const int amax = (LONG && !SLOW) ? min(n - 1, kGaCommit) : n - 1;   // LONG: columns above 41 were not kept (lanes clamped there are outside the commit range)
                     for (;;) {
                         const int ai = ca + lane, bi = cb + lane;
                         const bool inr = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
-                        const int aic = min(ai, n - 1), bic = min(bi, kGaW - 1);
+                        const int aic = min(ai, amax), bic = min(bi, kGaW - 1);
                         const int dm1 = d > 0 ? d - 1 : 0;
                         const uint64_t rn_d = Rf(aic + 1, d), rn_dm1 = Rf(aic + 1, dm1), rc_dm1 = Rf(aic, dm1);
                         const int pch = __builtin_amdgcn_ds_bpermute(bic << 2, pfwd), tch = __builtin_amdgcn_ds_bpermute(aic << 2, tfwd);
@@ -308,22 +383,33 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 
 constexpr uint64_t kGaSlabBytes = (uint64_t)(kGaW + 1) * 64 * 8;   // one wavefront's slow-path columns in HBM scratch
 
-inline void genasm_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
+inline bool genasm_long(const aim_params_t &p, const Knobs &kn)   // the LONG variant: >= 100 windows per pair (its last window costs a 64-level pass)
 {
-    (void)p;
+    return kn.ga_long >= 0 ? kn.ga_long != 0 : p.read_size >= 4096;
+}
+
+inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
+{
+    const bool lg = genasm_long(p, kn);
     *block = kWave;
-    *lds = (size_t)kGaCols * kGaSlots * 8 + 64;
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
+    *lds = lg ? (size_t)(kGlCols * 16 + kGlPm) * 8 + 64 : (size_t)kGaCols * kGaSlots * 8 + 64;
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(lg ? 16 : 8, lds_workgroups_per_cu(*lds));
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;
 }
 
-inline void genasm_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+inline void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
-    if (p.flags & AIM_FLAG_BACKTRACE) hipLaunchKernelGGL((genasm_wave_kernel<true>), dim3(grid), dim3(kWave), lds, s, ka);
-    else hipLaunchKernelGGL((genasm_wave_kernel<false>), dim3(grid), dim3(kWave), lds, s, ka);
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    if (genasm_long(p, kn)) {
+        if (bt) hipLaunchKernelGGL((genasm_wave_kernel<true, true>), dim3(grid), dim3(kWave), lds, s, ka);
+        else hipLaunchKernelGGL((genasm_wave_kernel<false, true>), dim3(grid), dim3(kWave), lds, s, ka);
+    } else {
+        if (bt) hipLaunchKernelGGL((genasm_wave_kernel<true, false>), dim3(grid), dim3(kWave), lds, s, ka);
+        else hipLaunchKernelGGL((genasm_wave_kernel<false, false>), dim3(grid), dim3(kWave), lds, s, ka);
+    }
 }
 
 }  // namespace aim

@@ -37,7 +37,7 @@ CONFIGS = {
                  name="WFA-adaptive with CIGAR l=1000 e=5%"),
     "cfg4": dict(algo="swg", l=10000, e=0.01, n=256, bt=True, reduce=False, bound="valu", pmc="dp_strip",
                  name="SWG affine-gap with CIGAR l=10000 e=1%"),
-    "cfg5": dict(algo="genasm", l=100000, e=0.10, n=1024, bt=True, reduce=False, bound="issue", pmc="genasm_wave",
+    "cfg5": dict(algo="genasm", l=100000, e=0.10, n=4096, bt=True, reduce=False, bound="issue", pmc="genasm_wave",
                  name="GenASM bit-vector edit distance with CIGAR l=100000 e=10% (parity unpinned)"),
 }
 

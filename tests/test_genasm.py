@@ -170,3 +170,17 @@ def test_genasm_windows_that_need_more_than_15_edits(gpu):
             assert np.array_equal(ops[i, :e], oops[i, :e]), i
         _check_alignment(req, pat, txt, res, ops)
         assert (res["score"] > 16 * (req["pattern_len"] // 40 + 1) // 2).any()   # some windows are far beyond 15 edits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l,err,n", [(30, 0.1, 300), (64, 0.05, 300), (100, 0.1, 1000), (150, 0.3, 400), (300, 0.25, 300), (1000, 0.1, 300), (500, 0.6, 100),
+                                     (5000, 0.02, 64), (3000, 0.15, 64)])
+def test_genasm_long_variant_matches_oracle(gpu, monkeypatch, l, err, n):
+    """The LONG variant (compact column store: columns above 41 are computed but not kept, the pair's last window takes the 64-level
+    path; the default from READ_SIZE 4096 up, 16 wavefronts per CU) forced onto every shape, and the standard variant forced onto long
+    reads: short last windows, windows with m != n, windows beyond 15 edits -- same output as the oracle either way."""
+    monkeypatch.setenv("AIM_GA_LONG", "1")
+    _hip_vs_oracle(l, err, n, 300 + l, True)
+    _hip_vs_oracle(l, err, min(n, 100), 400 + l, False)
+    monkeypatch.setenv("AIM_GA_LONG", "0")
+    _hip_vs_oracle(l, err, min(n, 64), 500 + l, True)

@@ -20,9 +20,9 @@ python3 tools/pmc_summary.py --out $P/wfa_lane_packed_pmc_summary.json --kernel 
 python3 tools/pmc_summary.py --out $P/wfa_group_tb_pmc_summary.json --kernel wfa_group_tb_kernel --pairs 65536 \
    --note "cfg3's traceback kernel (one pair per lane over the compact per-pair history regions)." \
    -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_grouptb.log 2>&1; tail -1 $O/pmc_grouptb.log
-python3 tools/pmc_summary.py --out $P/genasm_wave_pmc_summary.json --kernel genasm_wave_kernel --pairs 1024 \
-   --note "cfg5: GenASM l=100000 e=10% with CIGAR, 1024 pairs (parity unpinned)." \
-   -- python3 tools/bench_configs.py genasm_l100000_e10_cigar > $O/pmc_genasm.log 2>&1; tail -1 $O/pmc_genasm.log
+python3 tools/pmc_summary.py --out $P/genasm_wave_pmc_summary.json --kernel genasm_wave_kernel --pairs 4096 \
+   --note "cfg5: GenASM l=100000 e=10% with CIGAR, 4096 pairs = 16 wavefronts per CU, LONG variant (parity unpinned)." \
+   -- python3 tools/bench_configs.py genasm_l100000_e10_cigar_n4096 > $O/pmc_genasm.log 2>&1; tail -1 $O/pmc_genasm.log
 python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
 python3 -c "
 import sys, json
