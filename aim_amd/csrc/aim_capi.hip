@@ -722,6 +722,23 @@ void free_device_buffers(aim_device_ctx &d)
     d.slots.clear();
 }
 
+// OR of f(i) over i < n != 0, on up to 8 threads for large n (batch-sized host scans sit on the caller's critical path)
+template <typename F>
+bool any_nonzero(size_t n, F f)
+{
+    auto part = [&](size_t lo, size_t hi) { uint32_t acc = 0; for (size_t i = lo; i < hi; ++i) acc |= f(i); return acc; };
+    const unsigned nt = n >= (1u << 19) ? 8u : 1u;
+    if (nt == 1) return part(0, n) != 0;
+    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back([&, t] { acc[t] = part(n * t / nt, n * (t + 1) / nt); });
+    acc[0] = part(0, n / nt);
+    for (auto &x : th) x.join();
+    uint32_t all = 0;
+    for (unsigned t = 0; t < nt; ++t) all |= acc[t];
+    return all != 0;
+}
+
 // Every length of a batch against READ_SIZE (host.c:119-123) before anything is enqueued. A 4 M-pair batch is 32-64 MB of
 // requests: scanned by one thread this was 2.5 ms of every aim_set_submit -- a fifth of the host CLI's loop at 4e8 pairs/s -- so
 // large batches are scanned branch-free by a few threads and only a failing scan is repeated to name the pair.
@@ -788,7 +805,7 @@ int launch_on_slot(aim_set *set, aim_device_ctx &d, aim_slot &s, uint32_t mode =
 {
     const Plan pl = plan_for_batch(set, d, s, s.n_pairs, mode);
     s.plan_last = pl;
-    if (fio && pl.emits_runs) {   // slotted run buffer: pair p owns runs[4p, 4p + 4), the cursor starts behind the slots (wfa_lane_packed.hpp)
+    if (fio && pl.emits_runs) {   // slotted run buffer: pair p owns runs[3p, 3p + 3), the cursor starts behind the slots (wfa_lane_packed.hpp)
         fio->run_slot = (pl.kid == K_WFA_LANE_PK && (uint64_t)s.n_pairs * aim::kRunSlot <= fio->runs_cap) ? aim::kRunSlot : 0u;
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)fio->cursor, (int)(s.n_pairs * fio->run_slot), 1, s.stream));
     }
@@ -1180,7 +1197,7 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
             if (io->cigars) {
                 HIP_TRY(hipMemcpyAsync(s.h_cursor, s.d_cursor, 4, hipMemcpyDeviceToHost, s.stream));
                 HIP_TRY(hipMemcpyAsync(io->cigars, s.d_cig, (size_t)n * sizeof(aim_cigar_t), hipMemcpyDeviceToHost, s.stream));
-                // slotted run buffer (wfa_lane_packed.hpp): the first 4 n runs are the pairs' own slots, known now -- their copy
+                // slotted run buffer (wfa_lane_packed.hpp): the first 3 n runs are the pairs' own slots, known now -- their copy
                 // overlaps the next batch instead of waiting in aim_set_wait for the cursor; only runs behind the slots follow there
                 if (s.runs_sent) HIP_TRY(hipMemcpyAsync(io->runs, s.d_runs, (size_t)s.runs_sent * 4, hipMemcpyDeviceToHost, s.stream));
             }
@@ -1233,15 +1250,21 @@ int aim_set_wait(aim_set_t *set, uint32_t device, uint32_t slot, uint32_t *n_run
     d.kernel_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, s.ev[4], s.ev[5]));
     d.d2h_ms += ms;
+    // Every pair's status (the reference stops at the first DPU fault). 4 M compact CIGARs are 64 MB: one thread scanning them took as
+    // long as the batch's transfers (the e2e rate with CIGAR was bound by THIS loop, not by PCIe), so the scan is an OR over a few
+    // threads and only a batch that holds a fault is walked to name it.
     if (io.cigars) {
-        for (uint32_t i = 0; i < s.n_pairs; ++i) {
-            if (io.cigars[i].status & AIM_CIGAR_OVERFLOW) return fail(AIM_ENOMEM, "run buffer too small (pair idx %u)", io.cigars[i].idx);
-            if (io.cigars[i].status != AIM_PAIR_OK) return status_error(io.cigars[i].idx, io.cigars[i].status);
-        }
+        const aim_cigar_t *cg = io.cigars;
+        if (any_nonzero(s.n_pairs, [cg](size_t i) { return (uint32_t)cg[i].status; }))
+            for (uint32_t i = 0; i < s.n_pairs; ++i) {
+                if (io.cigars[i].status & AIM_CIGAR_OVERFLOW) return fail(AIM_ENOMEM, "run buffer too small (pair idx %u)", io.cigars[i].idx);
+                if (io.cigars[i].status != AIM_PAIR_OK) return status_error(io.cigars[i].idx, io.cigars[i].status);
+            }
     } else if (io.results && !(set->params.flags & AIM_FLAG_RES8)) {
         const aim_result_t *r = static_cast<const aim_result_t *>(io.results);
-        for (uint32_t i = 0; i < s.n_pairs; ++i)
-            if (r[i].status != AIM_PAIR_OK) return status_error(r[i].idx, r[i].status);
+        if (any_nonzero(s.n_pairs, [r](size_t i) { return (uint32_t)r[i].status; }))
+            for (uint32_t i = 0; i < s.n_pairs; ++i)
+                if (r[i].status != AIM_PAIR_OK) return status_error(r[i].idx, r[i].status);
     }
     return AIM_OK;
 }

@@ -334,14 +334,16 @@ struct RunCollector {
 };
 
 constexpr int kLaneRunSpill = 12;   // LDS-spilled runs per lane beyond the four in registers (3 KiB per wavefront)
-constexpr uint32_t kRunSlot = 4;    // runs per pair written at the pair's own fixed place in the run buffer (below)
+constexpr uint32_t kRunSlot = 3;    // runs per pair written at the pair's own fixed place in the run buffer (below)
 
 // Where a pair's runs go. The shared run buffer of the compact-CIGAR format is bump-allocated through one cursor
-// (cigar_rle_kernel: one atomic per wavefront). A one-pair-per-lane kernel whose alignments have <= 4 runs does better: when
-// the buffer holds 4 runs per pair, pair p owns runs[4p, 4p + 4) -- one coalesced 16-B store per lane, no atomic, no
-// dependence on scheduling -- and the cursor starts at 4 n_pairs (aim_capi.hip), so that only the rare pair with more runs
-// allocates behind the slots (one atomic per wavefront that holds such a pair). a.run_slot is 4 in that mode, 0 otherwise
-// (run buffer smaller than 4 n_pairs: everything is bump-allocated).
+// (cigar_rle_kernel: one atomic per wavefront). A one-pair-per-lane kernel whose alignments have <= 3 runs does better: when
+// the buffer holds 3 runs per pair, pair p owns runs[3p, 3p + 3) -- one coalesced 12-B store per lane, no atomic, no
+// dependence on scheduling -- and the cursor starts at 3 n_pairs (aim_capi.hip), so that only the pairs with more runs
+// allocate behind the slots (one atomic per wavefront that holds such a pair). a.run_slot is 3 in that mode, 0 otherwise
+// (run buffer smaller than 3 n_pairs: everything is bump-allocated). Three, not four: a pair without an edit has one run, with one
+// edit three (M X M), with two five -- a fourth slot is filled by almost no pair and is 4 bytes per pair on the PCIe link,
+// which is what bounds the end-to-end rate with CIGAR (e2e 6.1-6.4e8 pairs/s with four).
 template <typename Coll>
 __device__ __forceinline__ void store_cigar(const KArgs &a, uint32_t pair, bool active, uint32_t idx, int score, int status,
                                             Coll &c, uint32_t run_slot, int lane)
@@ -375,10 +377,10 @@ __device__ __forceinline__ void store_cigar(const KArgs &a, uint32_t pair, bool 
     }
     if (ok && !coll_ovf && fits) {
         if (in_slot && run_slot == kRunSlot) {
-            typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-            aim_u32x4 v4;
-            v4.x = c.r0; v4.y = n_runs > 1 ? c.r1 : 0u; v4.z = n_runs > 2 ? c.r2 : 0u; v4.w = n_runs > 3 ? c.r3 : 0u;
-            *reinterpret_cast<aim_u32x4 *>(a.runs + off) = v4;
+            typedef uint32_t aim_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+            aim_u32x3 v3;
+            v3.x = c.r0; v3.y = n_runs > 1 ? c.r1 : 0u; v3.z = n_runs > 2 ? c.r2 : 0u;
+            *reinterpret_cast<aim_u32x3 *>(a.runs + off) = v3;
         } else {
             // (no select chain over r0..r3 here: the compiler turns one into a dynamically indexed stack object)
             uint32_t *dst = a.runs + off;
