@@ -357,7 +357,12 @@ def main():
                 ach = rate * ins[1] / 1e9 if ins else None
                 roofline = {"bound": "issue", "achieved": ach, "peak": ISSUE_PEAK_GINSTR, "unit": "G wavefront-instructions/s",
                             "frac": ach / ISSUE_PEAK_GINSTR if ins else None, "instructions_per_pair": ins[1] if ins else None,
-                            "instruction_source": ins[2] if ins else None, "traffic": None, "hbm_view": hbm}
+                            "instruction_source": ins[2] if ins else None, "traffic": None, "hbm_view": hbm,
+                            # the vector unit alone: a wave64 VALU instruction occupies its SIMD for 4 clocks, so VALU issue saturates
+                            # at a quarter of the all-types rate above -- this is the fraction that says how full the kernel's SIMDs are
+                            "valu_view": {"achieved": rate * ins[0] * 64.0 / 1e12, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                                          "frac": rate * ins[0] * 64.0 / 1e12 / VALU_PEAK_TLANEOPS,
+                                          "valu_instructions_per_pair": ins[0]} if ins else None}
         line = {
             "metric": ("aligned pairs/sec WFA-adaptive l=%d e=%g%%" % (args.length, args.error * 100)) if headline else
                       ("aligned pairs/sec %s" % cfg["name"]),
