@@ -58,7 +58,7 @@ def test_bench_two_ranks_control_flow(built):
 def test_bench_other_baseline_configs_run_through_the_same_harness(built):
     """`bench.py --config cfg3 | cfg4 | cfg5`: the other BASELINE configurations through the same static split / timing / one-line
     contract, each priced against the roof that bounds its kernel; cfg3 also under two ranks."""
-    for cfg, pairs, bound in (("cfg3", "4096", "issue"), ("cfg4", "16", "valu"), ("cfg5", "64", "issue")):
+    for cfg, pairs, bound in (("cfg3", "4096", "valu"), ("cfg4", "16", "valu"), ("cfg5", "64", "valu")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--pairs", pairs, "--steps", "2", "--warmup", "1",
                             "--length", {"cfg3": "1000", "cfg4": "2000", "cfg5": "5000"}[cfg]], capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, (cfg, r.stderr[-2000:])
@@ -71,4 +71,4 @@ def test_bench_other_baseline_configs_run_through_the_same_harness(built):
                         "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["verified_vs_oracle"] is True and d["roofline"]["bound"] == "issue" and d["gather_ms"] is not None
+    assert d["n_gpus"] == 2 and d["verified_vs_oracle"] is True and d["roofline"]["bound"] == "valu" and d["roofline"]["issue_view"]["frac"] > 0 and d["gather_ms"] is not None
