@@ -2,6 +2,7 @@
 (/root/reference/.gitmodules:1-3), so there is nothing of AIM's to compare with.  What is tested: (CPU) the oracle's
 restatement of the published algorithm against the defining properties of an alignment and against the exact edit
 distance on small inputs; (GPU) the HIP kernel against that oracle, bit for bit, up to config 5's read length."""
+import os
 import numpy as np
 import pytest
 
@@ -184,3 +185,53 @@ def test_genasm_long_variant_matches_oracle(gpu, monkeypatch, l, err, n):
     _hip_vs_oracle(l, err, min(n, 100), 400 + l, False)
     monkeypatch.setenv("AIM_GA_LONG", "0")
     _hip_vs_oracle(l, err, min(n, 64), 500 + l, True)
+
+
+@pytest.mark.gpu
+def test_genasm_compact_cigar_beyond_65535_runs_reports_overflow(gpu, tmp_path):
+    """aim_cigar_t.n_runs is 16 bits. A long pair whose alignment alternates M / X has more runs than that: the device-side
+    run-length encoder must flag AIM_CIGAR_OVERFLOW (aim_set_wait: AIM_ENOMEM) instead of storing a truncated count -- and the host CLI
+    then prints that batch from result_t + ops rows like the reference, i.e. the oracle's text."""
+    import subprocess, sys
+    from conftest import ROOT
+    from aim_amd import capi, engine
+    from oracle import oracle
+    l = 110000               # (windows of > 15 edits drift into indels: ~0.64 runs per base)
+    rs = ((l + 8 + 7) // 8) * 8
+    rng = np.random.RandomState(5)
+    req = np.zeros(3, dtype=engine.REQUEST_DTYPE)
+    pat = np.zeros((3, rs), dtype=np.uint8); txt = np.zeros((3, rs), dtype=np.uint8)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(3):
+        p = rng.choice(bases, size=l)
+        t = p.copy()
+        if i == 1:
+            t[1::2] = bases[(np.searchsorted(bases, p[1::2]) + 1) % 4]          # every second base substituted: M X M X ... = ~70 000 runs in all
+        else:
+            t[100 * (i + 1)] = bases[(np.searchsorted(bases, p[100 * (i + 1)]) + 1) % 4]
+        pat[i, :l], txt[i, :l] = p, t
+        req[i]["pattern_len"] = req[i]["text_len"] = l
+        req[i]["idx"] = i
+    params = engine.make_params("genasm", 0, rs, backtrace=True)
+    res, ops = engine.align(params, req, pat, txt)
+    o = ops[1, : int(res["end_offset"][1])]
+    assert 1 + int((o[1:] != o[:-1]).sum()) > 65535                          # the case is what it claims to be
+    with engine.DeviceSet(1) as s:
+        s.configure_slots(params, 3, slots=1, max_raw=0, max_runs=400000)
+        s.submit(0, 0, req, pat=pat, txt=txt, cigar_runs_cap=400000)
+        io, keep, out = s._inflight[(0, 0)]
+        rc = s.lib.aim_set_wait(s.handle, 0, 0, None)
+        s._inflight.pop((0, 0))
+        assert rc == capi.AIM_ENOMEM, rc
+        cig = out["cig"]
+        assert int(cig["status"][1]) & capi.CIGAR_OVERFLOW and int(cig["n_runs"][1]) == 0
+        assert int(cig["status"][0]) == 0 and int(cig["n_runs"][0]) == 3 and int(cig["status"][2]) == 0
+    inp = tmp_path / "in.seq"
+    inp.write_bytes(engine.pairs_to_text(req, pat, txt))
+    out_f = tmp_path / "out"
+    r = subprocess.run([os.path.join(ROOT, "aim_amd", "host", "host"), str(inp), str(out_f), "3", "--algo", "genasm", "--read-size", str(rs), "--backtrace"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ores, oops, _ = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), req["pattern_len"], req["text_len"], pat, txt, nthreads=3)
+    ores["idx"] = req["idx"]
+    assert out_f.read_bytes() == oracle.format_output(ores, oops, True)
