@@ -103,7 +103,10 @@ def main():
                     tl = int(req["text_len"][i]); txt[i, :tl] = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(tl)), dtype=np.uint8)
                 elif r < 0.2:
                     pat[i, rng.randrange(l)] = ord(rng.choice("Nn*"))
-            case = dict(algo="genasm", l=l, e=e, n=n, read_size=rs, backtrace=int(bt), kernel="genasm_wave_kernel")
+            os.environ.pop("AIM_GA_LONG", None)
+            ga = rng.choice(["", "", "0", "1"])               # default rule (LONG from READ_SIZE 4096 up), or either variant forced onto any shape
+            if ga: os.environ["AIM_GA_LONG"] = ga
+            case = dict(algo="genasm", l=l, e=e, n=n, read_size=rs, backtrace=int(bt), kernel="genasm_wave_kernel", ga_long=ga)
             try:
                 if params.flags & capi.FLAG_RES8:
                     res, _ = engine.align(params, req, pat, txt)
@@ -200,6 +203,7 @@ def main():
         if algo != "wfa" and 0.6 <= r < 0.7: env["AIM_DPL_PER_CU"] = rng.choice(["1", "3", "12"])
         if algo == "wfa" and 0.35 <= r < 0.45: env["AIM_GROUP_PER_CU"] = rng.choice(["1", "5", "32"])
         if algo == "wfa" and 0.45 <= r < 0.5: env.update(AIM_FORCE_WAVE="1", AIM_WFA_NO_RING="1")
+        if algo == "wfa" and rng.random() < 0.15: env["AIM_GROUP_WLDS"] = rng.choice(["64", "80", "96", "112"])   # ring rows that pairs outgrow / rows that are no power of two
         if rng.random() < 0.15: env["AIM_SCRATCH_GB"] = rng.choice(["0.25", "0.5", "2"])
         for k in ("AIM_GROUP_G", "AIM_FORCE_WAVE", "AIM_DPW_NW", "AIM_FORCE_DPWAVE", "AIM_DPL_SEQ_LDS", "AIM_DPL_PER_CU", "AIM_GROUP_PER_CU",
                   "AIM_WFA_NO_RING", "AIM_SCRATCH_GB", "AIM_STRIP_K", "AIM_DPW_LEGACY", "AIM_GROUP_WLDS"): os.environ.pop(k, None)
