@@ -429,7 +429,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         {
                             const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
                             const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? raw_ie_m1 : kGrpNull;
-                            const int v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : (int)(int16_t)(max(ins_g, ins_i) + 1);
+                            // (offsets are <= READ_SIZE <= 2048 or kGrpNull: the reference's int16 store of offset + 1 never wraps, so no cast is spelled out)
+                            const int v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : max(ins_g, ins_i) + 1;
                             if (!i_out_null) {
                                 ins = v;
                                 oi[hk] = (int16_t)ins;
@@ -445,10 +446,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                             }
                         }
                         int sub = -10;
-                        if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? (int)(int16_t)(raw_ms + 1) : kGrpNull;
+                        if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? raw_ms + 1 : kGrpNull;
                         // M[s][k] as the reference stores it (int16), then affine_wfa_extend (wfa.c:186-208) on that value: a
                         // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
-                        const int ext = extend(k, (int)(int16_t)max(del, max(sub, ins)));
+                        const int ext = extend(k, max(del, max(sub, ins)));
                         om[hk] = (int16_t)ext;
                         if (BT) hrow[k] = make_uint2((uint32_t)(uint16_t)ext | ((uint32_t)(uint16_t)ins << 16), (uint32_t)(uint16_t)del);   // I / D: -10 when absent (never selected)
                         const int dist = max(plen - (ext - k), tlen - ext);
