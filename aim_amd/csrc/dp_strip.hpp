@@ -87,6 +87,13 @@ __device__ __forceinline__ int strip_wait(lds_msg_p m, int seq)
 // D[v-1] = D[v] - e (I[h-1] = I[h] - e) whenever the "opened here" test D[v] == M[v-1] + o + e fails -- the recurrence itself,
 // exact because no int16 store wraps (dp_strip_exact_ok). Flags: per row and lane one 8-byte word, cell t = 2 j + hi at bits
 // (hi ? 16 : 0) + 2 (j & 7) of word j >> 3 (row h's words at FL[h * FS + lane]); boundary cells (column 0) in BF[row].
+#ifdef AIM_STRIP_STAMPS   // diagnostic builds only (tools/strip_stamps.py): s_memtime per phase of a row, summed per wavefront, dumped into the pair's ops row
+#define AIM_SSTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); ssum[i] += t_ - slast; slast = t_; } while (0)
+#else
+#define AIM_SSTAMP(i) do { } while (0)
+#endif
+
 template <int K>
 __device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, int plen, int tlen, int S, int FS, const int16_t *TM, const uint2 *FL,
                                                          const unsigned char *BF, int16_t *tile, char *ops, int lane, int &begin_offset, int &status)
@@ -216,6 +223,9 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
         const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
         const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
         char *ops = BT ? a.ops + (uint64_t)pair * 2 * rs : nullptr;
+#ifdef AIM_STRIP_STAMPS
+        unsigned long long ssum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, slast = 0;
+#endif
         const int W = tlen + 1;
         int score = 0, status = AIM_PAIR_OK;
         int begin_offset = plen + tlen - 1;
@@ -320,7 +330,11 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 return (t & 1) ? (int)(int16_t)(w >> 16) : (int)(int16_t)(w & 0xffffu);
             };
 
+#ifdef AIM_STRIP_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(slast) :: "memory");
+#endif
             for (int h = 1; h <= tlen; ++h) {
+                AIM_SSTAMP(7);   // loop back-edge
                 const int slot = h & (kStripDepth - 1);
                 const uint32_t tch2 = (uint32_t)ldsT[h - 1] * 0x00010001u;
                 // ---- diagonal input of this lane's first cell: M[h-1][v0 - 1]
@@ -334,6 +348,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         else dfirst = strip_wait(mbD + wv * kStripDepth + slot, h);
                     }
                 }
+                AIM_SSTAMP(0);   // diagonal input (mailbox D)
                 // ---- pre-carry: I, A, G of this lane's K cells, two per instruction (nothing here depends on this row's carry or
                 // boundary cell: in a tailed pair it runs while the previous row's last strip is still finishing)
                 dps2 A[KP], Iv[KP], G[KP];
@@ -360,6 +375,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 };
                 if (wave_full) precarry(std::false_type{});
                 else precarry(std::true_type{});
+                AIM_SSTAMP(1);   // pre-carry
                 int lane_min = min((int)gmin.x, (int)gmin.y);
                 if (lane_min == kInf16) lane_min = kDpInf;
                 int total;
@@ -377,6 +393,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     }
                     strip_post(mbC + wv * kStripDepth + slot, total, h);
                 }
+                AIM_SSTAMP(6);   // wave scan + post C (incl. waiting for the ring slot)
                 // ---- B(h): the boundary cell of this row
                 if (h == 1 || !has_tail) {
                     if (SWG) { BM = O + h * E; BI = BM; BD = MAXS; }
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     while (bs[3] != h) __builtin_amdgcn_s_sleep(1);     // posted by the lane that owns column W - 1 at the end of row h - 1
                     BM = bs[0]; BI = bs[1]; BD = bs[2];
                 }
+                AIM_SSTAMP(2);   // boundary cell B(h)
                 // ---- the prefix minimum over everything left of this strip: G[0] and the totals of the strips on the left
                 int carry_in = SWG ? min(BD, BM + O) : BM;             // G[0]
                 if (wv > 0) {
@@ -394,6 +412,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     carry_in = min(carry_in, wave_min_i32(t_u));
                     if (lane == 0) cons[wv] = h;                        // every message of row h is read
                 }
+                AIM_SSTAMP(3);   // totals of the strips on the left (mailbox C)
                 // ---- post-carry: D / R and M of the K cells; the new row replaces the old one in the registers
                 const int pre = min(carry_in, lane_pre);
                 dps2 c = dps_splat(pre);
@@ -411,6 +430,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 // ---- hand the next row's diagonal cell to the next strip
                 if (wv + 1 < nw && lane == kWave - 1) strip_post(mbD + (wv + 1) * kStripDepth + ((h + 1) & (kStripDepth - 1)), (int)Mp[KP - 1].y, h + 1);
                 BMprev = BM;
+                AIM_SSTAMP(4);   // post-carry + post D
                 // ---- first tail cell (h, W): the boundary cell of row h + 1 (rows before the last; the last row's tail is walked below)
                 if (owner_wave) {
                     const int upM = pick(Mp, tail_t), upD = pick(Do, tail_t);
@@ -436,6 +456,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         }
                     }
                 }
+                AIM_SSTAMP(5);   // tail cell / picks
                 // ---- table (BT): 16-byte stores where the lane's cells are all inside the row (off the critical path: after the posts)
                 if (BT && nvalid > 0) {
                     const size_t trow = (size_t)h * S + 7 + v0;
@@ -454,6 +475,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     }
                 }
             }
+            AIM_SSTAMP(7);       // (the last row's table stores)
             // ---- after the last row: its regular part into LDS (score; the tail walk reads it), then the reference's tail cells
             {
                 if (nvalid > 0) {
@@ -536,6 +558,13 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             if (SWG && !literal) dp_traceback_swg_compact<K>(a.p, plen, tlen, S, FS, TM, FL, BF, rowM, ops, lane, begin_offset, status);
             else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
         }
+#ifdef AIM_STRIP_STAMPS
+        __syncthreads();         // the traceback is done with the ops row: the stamps go there (the CIGAR of a diagnostic build is void)
+        if (BT && lane == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(ops + 64) + wv * 8;
+            for (int i = 0; i < 8; ++i) dbg[i] = ssum[i];
+        }
+#endif
         if (tid == 0) {
             aim_result_t r;
             r.max_operations = plen + tlen;
