@@ -22,9 +22,9 @@ rows = req["text_len"].astype(np.float64)
 for label, sel in (("pairs with a tail (%d)" % tail.sum(), tail), ("pairs without (%d)" % (~tail).sum(), ~tail)):
     if not sel.any():
         continue
-    per_row = st[sel] / rows[sel][:, None, None]          # ticks per row (s_memtime counts at 100 MHz: 1 tick = 24 shader clocks at 2.4 GHz)
+    per_row = st[sel] / rows[sel][:, None, None]          # ticks per row (on this chip a tick of s_memtime is ~0.5 ns: 5 300 ticks per row at 26.8 ms per 10 112 rows)
     used = per_row.sum(axis=2).mean(axis=0) > 0
-    print(label, "-- ticks per row, by wavefront (columns) and phase (rows); 1 tick = 10 ns")
+    print(label, "-- s_memtime ticks per row (~0.5 ns each), by wavefront (columns) and phase (rows)")
     used &= per_row.sum(axis=2).mean(axis=0) < 1e9      # (slots of wavefronts the shape does not have hold CIGAR bytes)
     print("%-36s" % "" + "".join("%8s" % ("w%d" % w) for w in range(nw) if used[w]))
     for i, nm in enumerate(names):
