@@ -842,6 +842,31 @@ def test_compact_cigar_bytes_per_pair_and_overflow(gpu):
         assert e.value.code == capi.AIM_ENOMEM
 
 
+def test_large_batch_host_scans_report_the_offending_pair(gpu):
+    """aim_set_submit's length check and aim_set_wait's status scan run on several host threads from 2^19 pairs up (they sat on the
+    caller's critical path at 4 M pairs per batch): a bad length / a failing pair anywhere in such a batch is still reported, by index."""
+    from aim_amd import capi, engine
+    n, rs, ms = (1 << 19) + 4097, 32, 3
+    req, pat, txt = engine.gen_pairs(5, 0, n, 24, 0.04, rs)
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=True, req8=True)
+    with engine.DeviceSet(1) as s:
+        s.configure_slots(params, n, slots=1, max_raw=0, max_runs=8 * n)
+        bad = req.copy()
+        bad["pattern_len"][n - 5] = rs + 1                      # in the last thread's share
+        with pytest.raises(capi.AimError) as e:
+            s.submit(0, 0, bad, pat, txt, cigar_runs_cap=8 * n)
+        assert e.value.code == capi.AIM_EINVAL and ("pair %d" % (n - 5)) in str(e.value)
+        s._inflight.pop((0, 0), None)
+        s.submit(0, 0, req, pat, txt, cigar_runs_cap=8 * n)     # the same batch with honest lengths goes through
+        out = s.wait(0, 0)
+        base_res, base_ops = engine.align(engine.make_params("wfa", ms, rs, reduce=True, backtrace=True), req[:4096], pat[:4096], txt[:4096])
+        assert np.array_equal(out["cig"]["score"][:4096], base_res["score"])
+        s.submit(0, 0, req, pat, txt, cigar_runs_cap=n)            # one run per pair is not enough: the pairs the buffer has no room for are flagged
+        with pytest.raises(capi.AimError) as e:
+            s.wait(0, 0)
+        assert e.value.code == capi.AIM_ENOMEM
+
+
 def test_two_slots_pipeline_many_batches(gpu):
     """Double buffering: batches alternate between two slots of one device, each slot's results land in its own buffers;
     the concatenation equals one big default launch. Also: a slot refuses a second submit before its wait."""
