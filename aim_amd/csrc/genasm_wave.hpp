@@ -393,7 +393,8 @@ inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs
     const bool lg = genasm_long(p, kn);
     *block = kWave;
     *lds = lg ? (size_t)(kGlCols * 16 + kGlPm) * 8 + 64 : (size_t)kGaCols * kGaSlots * 8 + 64;
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(lg ? 16 : 8, lds_workgroups_per_cu(*lds));
+    uint32_t per_cu = (uint32_t)std::min<size_t>(lg ? 16 : 8, lds_workgroups_per_cu(*lds));
+    if (kn.ga_per_cu > 0) per_cu = (uint32_t)std::min<size_t>((size_t)kn.ga_per_cu, lds_workgroups_per_cu(*lds));   // residency sweeps
     uint32_t g = 256 * per_cu;
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
