@@ -178,7 +178,7 @@ def test_genasm_windows_that_need_more_than_15_edits(gpu):
                                      (5000, 0.02, 64), (3000, 0.15, 64)])
 def test_genasm_long_variant_matches_oracle(gpu, monkeypatch, l, err, n):
     """The LONG variant (compact column store: columns above 41 are computed but not kept, the pair's last window takes the 64-level
-    path; the default from READ_SIZE 4096 up, 16 wavefronts per CU) forced onto every shape, and the standard variant forced onto long
+    path; the default from READ_SIZE 640 up, 16 wavefronts per CU) forced onto every shape, and the standard variant forced onto long
     reads: short last windows, windows with m != n, windows beyond 15 edits -- same output as the oracle either way."""
     monkeypatch.setenv("AIM_GA_LONG", "1")
     _hip_vs_oracle(l, err, n, 300 + l, True)

@@ -104,7 +104,7 @@ def main():
                 elif r < 0.2:
                     pat[i, rng.randrange(l)] = ord(rng.choice("Nn*"))
             os.environ.pop("AIM_GA_LONG", None)
-            ga = rng.choice(["", "", "0", "1"])               # default rule (LONG from READ_SIZE 4096 up), or either variant forced onto any shape
+            ga = rng.choice(["", "", "0", "1"])               # default rule (LONG from READ_SIZE 640 up), or either variant forced onto any shape
             if ga: os.environ["AIM_GA_LONG"] = ga
             case = dict(algo="genasm", l=l, e=e, n=n, read_size=rs, backtrace=int(bt), kernel="genasm_wave_kernel", ga_long=ga)
             try:
