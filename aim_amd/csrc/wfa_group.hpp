@@ -7,8 +7,11 @@
 //   * a pair is owned by G consecutive lanes (G = 1 .. 64, picked by wfa_group_plan from the LDS one pair's window
 //     needs and the residency that leaves); the lanes of a group take the diagonals k = lo+g, lo+g+G, ...
 //   * the live window of wavefronts -- M for the last max(x,o+e)+1 scores, I and D for the last e+1 -- lives in
-//     LDS as int16, indexed [ring slot][k + MAX_SCORE + 1] (or modulo 128 in the narrow-window mode, GroupCfg::wlds),
-//     so the +/-1 neighbours of affine_wfa_compute_offsets (wfa.c:231-266) are plain LDS reads;
+//     LDS as int16, indexed [ring slot][k + MAX_SCORE + 1] (or modulo 128 / 96 in the narrow-window mode, GroupCfg::wlds),
+//     so the +/-1 neighbours of affine_wfa_compute_offsets (wfa.c:231-266) are plain LDS reads; scores are counted in units
+//     of gcd(x, o+e, e) (GroupCfg::unit), so the null wavefronts between reachable scores are never visited;
+//   * with BACKTRACE every computed cell is streamed to the pair's history region in HBM and wfa_group_tb_kernel walks it, one
+//     pair per lane (wfa_backtracing.c:210-351);
 //   * sequences arrive by LDS-DMA as in wfa_lane.hpp (G < 8) or straight from global memory (G >= 8), are validated
 //     (A/C/G/T only) and packed 2 bits per base into LDS; affine_wfa_extend (wfa.c:186-208) compares 32 bases per
 //     trip with funnel shifts;
