@@ -113,6 +113,7 @@ aim::Knobs read_knobs()
     k.strip_k = env_int("AIM_STRIP_K", -1);
     k.dpw_nw = env_int("AIM_DPW_NW", -1);
     k.dpl_seq_lds = env_int("AIM_DPL_SEQ_LDS", -1);
+    k.dpl_no_reg = env_int("AIM_DPL_NO_REG", 0);
     k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
@@ -636,7 +637,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         break;
     }
     case K_DP_LANE:
-        aim::dp_lane_launch(p, pl.grid, pl.lds, pl.seq_lds, ka, stream);
+        aim::dp_lane_launch(p, kn, pl.grid, pl.lds, pl.seq_lds, ka, stream);
         break;
     case K_DP_WAVE:
         aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);

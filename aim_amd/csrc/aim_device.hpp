@@ -95,6 +95,7 @@ struct Knobs {
     bool dpw_legacy = false;      // AIM_DPW_LEGACY=1    NW/SWG long reads: round 2's row-scan dp_wave_kernel instead of the strip pipeline
     int strip_k = -1;             // AIM_STRIP_K         dp_strip: cells per lane (16 or 32)
     int dpw_nw = -1;              // AIM_DPW_NW          dp_wave: wavefronts per pair (implies the row-scan kernel)
+    int dpl_no_reg = 0;           // AIM_DPL_NO_REG      dp_lane: 1 = never keep the pattern row in registers (A/B)
     int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: 0 = pattern from global memory
     int dpl_per_cu = -1;          // AIM_DPL_PER_CU      dp_lane: residency sweep
     int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs

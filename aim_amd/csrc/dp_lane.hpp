@@ -81,7 +81,12 @@ __host__ __device__ inline bool nw_lane_nowrap(const aim_params_t &p)
     return (2L * p.read_size + 4) * g + 2L * p.mismatch < 32000;
 }
 
-template <bool BT, bool SEQ_LDS, bool NOWRAP>
+// SEQ: where the inner loop takes the pattern bytes from -- 1: the transposed LDS image; 0: global memory; 2: REGISTERS (READ_SIZE <= 128:
+// the row is 32 dwords, indexed by the chunk counter, which is wave-uniform -- the compiler addresses the vector with s_set_gpr_idx, no
+// scratch). These kernels scale with residency (NW l = 100: 5 / 6 / 7 workgroups per CU = 5.59 / 4.65 / 4.30 ms) and the image is a third of
+// their LDS; global reads in the cell loop cost more than the residency they free (5.24 ms at 10 per CU), registers do not.
+typedef uint32_t dpl_u32x32 __attribute__((ext_vector_type(32)));
+template <bool BT, int SEQ, bool NOWRAP>
 __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     uint32_t *imgP = reinterpret_cast<uint32_t *>(smem);                             // pattern image [dword][lane]
+    constexpr bool SEQ_LDS = SEQ == 1;
     int16_t *R = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));    // [(rs+1)][64]
     int16_t *tb = BT ? reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
@@ -112,8 +118,14 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         const bool active = pair < a.n_pairs;
         const int n_rows = min((uint32_t)kWave, a.n_pairs - pair0);
         __syncthreads();
-        if (SEQ_LDS) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
+        if (SEQ_LDS || SEQ == 2) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
         __syncthreads();
+        dpl_u32x32 preg = {};
+        if (SEQ == 2) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) preg[j] = j < rsw ? imgP[j * kWave + lane] : 0u;
+            __syncthreads();                          // every lane holds its row before the row area is initialised
+        }
         if (!active) continue;
         const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
@@ -147,8 +159,8 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
             // writes of the chunk only touch lower indices), then the 8 cells run back to back in registers
             for (int v0 = 1; v0 <= plen; v0 += 8) {
                 const int w0 = (v0 - 1) >> 2;
-                const uint32_t pa = SEQ_LDS ? imgP[w0 * kWave + lane] : gP32[w0];
-                const uint32_t pb = (w0 + 1 < rsw) ? (SEQ_LDS ? imgP[(w0 + 1) * kWave + lane] : gP32[w0 + 1]) : 0u;
+                const uint32_t pa = SEQ == 2 ? preg[w0] : SEQ_LDS ? imgP[w0 * kWave + lane] : gP32[w0];
+                const uint32_t pb = SEQ == 2 ? preg[w0 + 1] : (w0 + 1 < rsw) ? (SEQ_LDS ? imgP[(w0 + 1) * kWave + lane] : gP32[w0 + 1]) : 0u;
                 cell_t olds[8];
                 if (__all((v0 + 7 <= plen) && (v0 + 7 < W))) {
                     // whole chunk inside the row and left of the aliasing column for EVERY lane: no guards, no branches
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
 #undef RW
 }
 
-template <typename CELL, bool BT, bool SEQ_LDS>
+template <typename CELL, bool BT, int SEQ>
 __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
     // row buffers hold CELL-typed values (int8 cells are stored wrapped, exactly as the reference's dp_cell_t does), so
     // they are CELL-typed: the int8 configuration (MAX_SCORE < 127, e.g. l=100 e=1 %) needs half the LDS, 7 instead of 4
     // workgroups per CU -- this kernel scales with residency (NW: 4 / 6 / 7 per CU = 6.93 / 5.00 / 4.60 ms)
+    constexpr bool SEQ_LDS = SEQ == 1;
     CELL *RMa = reinterpret_cast<CELL *>(imgP + (SEQ_LDS ? rsw * kWave : 0));        // M row, [(rs+1)][64]
     CELL *RIa = RMa + (rs + 1) * kWave;                                              // I row
     // dp_cell_t {M, I, D} (SWG/DPU-WRAM/common/common.h:112-118): one packed word per cell and lane, [idx][lane]:
@@ -308,8 +321,14 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         const bool active = pair < a.n_pairs;
         const int n_rows = min((uint32_t)kWave, a.n_pairs - pair0);
         __syncthreads();
-        if (SEQ_LDS) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);
+        if (SEQ_LDS || SEQ == 2) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
         __syncthreads();
+        dpl_u32x32 preg = {};
+        if (SEQ == 2) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) preg[j] = j < rsw ? imgP[j * kWave + lane] : 0u;
+            __syncthreads();                          // every lane holds its row before the row area is initialised
+        }
         if (!active) continue;
         const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
@@ -350,8 +369,8 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
             const int row = S * h;
             for (int v0 = 1; v0 <= plen; v0 += 8) {   // chunked as in nw_lane_kernel
                 const int w0 = (v0 - 1) >> 2;
-                const uint32_t pa = SEQ_LDS ? imgP[w0 * kWave + lane] : gP32[w0];
-                const uint32_t pb = (w0 + 1 < rsw) ? (SEQ_LDS ? imgP[(w0 + 1) * kWave + lane] : gP32[w0 + 1]) : 0u;
+                const uint32_t pa = SEQ == 2 ? preg[w0] : SEQ_LDS ? imgP[w0 * kWave + lane] : gP32[w0];
+                const uint32_t pb = SEQ == 2 ? preg[w0 + 1] : (w0 + 1 < rsw) ? (SEQ_LDS ? imgP[(w0 + 1) * kWave + lane] : gP32[w0 + 1]) : 0u;
                 CELL oldMs[8], oldIs[8];
                 if (__all((v0 + 7 <= plen) && (v0 + 7 < W))) {   // guard-free chunk (see nw_lane_kernel)
 #pragma unroll
@@ -505,6 +524,10 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     // pairs, same box: image in LDS, 7 workgroups per CU 7.12 ms; no image, 8 / 10 / 11 per CU 6.66 / 6.28 / 6.30 ms). NW and the
     // CIGAR variants measure the other way (NW score-only 4.32 vs 5.24 ms, SWG CIGAR 12.5 vs 13.6 ms).
     if (p.algo == AIM_ALGO_SWG && !(p.flags & AIM_FLAG_BACKTRACE)) *seq_lds = false;
+    // READ_SIZE <= 124: no image either -- the pattern row lives in REGISTERS (dp_lane_launch, SEQ = 2), the LDS it frees is residency
+    // (10 instead of 7 workgroups per CU). l = 100, 1 M pairs, same box, image in LDS / registers / global memory: NW score-only 4.30 / 3.27 /
+    // 5.25 ms, NW with CIGAR 7.60 / 6.86 / 11.8, SWG score-only - / 5.89 / 6.25, SWG with CIGAR 12.7 / 11.0 / 14.5.
+    if (p.read_size <= 124 && !kn.dpl_no_reg) *seq_lds = false;
     if (kn.dpl_seq_lds >= 0) *seq_lds = *seq_lds && kn.dpl_seq_lds != 0;   // experiments: 0 = pattern from global memory
     *lds = rows + (*seq_lds ? img : 0);
     if (*lds > 160 * 1024) return false;
@@ -524,9 +547,10 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     return true;
 }
 
-inline void dp_lane_launch(const aim_params_t &p, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s)
+inline void dp_lane_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    const int seq = seq_lds ? 1 : (p.read_size <= 124 && !kn.dpl_no_reg) ? 2 : 0;   // no image in LDS: registers when the row fits 31 dwords (preg[w0 + 1] stays inside the vector)
 #define AIM_DP_LAUNCH(KERNEL)                                                                                             \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -535,15 +559,16 @@ inline void dp_lane_launch(const aim_params_t &p, uint32_t grid, size_t lds, boo
     if (p.algo == AIM_ALGO_NW) {
         const bool nowrap = nw_lane_nowrap(p);
 #define AIM_NW_LAUNCH(BTV, SLV) do { if (nowrap) AIM_DP_LAUNCH((nw_lane_kernel<BTV, SLV, true>)); else AIM_DP_LAUNCH((nw_lane_kernel<BTV, SLV, false>)); } while (0)
-        if (bt) { if (seq_lds) AIM_NW_LAUNCH(true, true); else AIM_NW_LAUNCH(true, false); }
-        else    { if (seq_lds) AIM_NW_LAUNCH(false, true); else AIM_NW_LAUNCH(false, false); }
+#define AIM_NW_SEQ(BTV) do { if (seq == 1) AIM_NW_LAUNCH(BTV, 1); else if (seq == 2) AIM_NW_LAUNCH(BTV, 2); else AIM_NW_LAUNCH(BTV, 0); } while (0)
+        if (bt) AIM_NW_SEQ(true); else AIM_NW_SEQ(false);
+#undef AIM_NW_SEQ
 #undef AIM_NW_LAUNCH
-    } else if (swg_cell_bytes(p) == 1) {
-        if (bt) { if (seq_lds) AIM_DP_LAUNCH((swg_lane_kernel<int8_t, true, true>)); else AIM_DP_LAUNCH((swg_lane_kernel<int8_t, true, false>)); }
-        else    { if (seq_lds) AIM_DP_LAUNCH((swg_lane_kernel<int8_t, false, true>)); else AIM_DP_LAUNCH((swg_lane_kernel<int8_t, false, false>)); }
     } else {
-        if (bt) { if (seq_lds) AIM_DP_LAUNCH((swg_lane_kernel<int16_t, true, true>)); else AIM_DP_LAUNCH((swg_lane_kernel<int16_t, true, false>)); }
-        else    { if (seq_lds) AIM_DP_LAUNCH((swg_lane_kernel<int16_t, false, true>)); else AIM_DP_LAUNCH((swg_lane_kernel<int16_t, false, false>)); }
+#define AIM_SWG_SEQ(CELLT, BTV) do { if (seq == 1) AIM_DP_LAUNCH((swg_lane_kernel<CELLT, BTV, 1>)); else if (seq == 2) AIM_DP_LAUNCH((swg_lane_kernel<CELLT, BTV, 2>)); \
+                                     else AIM_DP_LAUNCH((swg_lane_kernel<CELLT, BTV, 0>)); } while (0)
+        if (swg_cell_bytes(p) == 1) { if (bt) AIM_SWG_SEQ(int8_t, true); else AIM_SWG_SEQ(int8_t, false); }
+        else { if (bt) AIM_SWG_SEQ(int16_t, true); else AIM_SWG_SEQ(int16_t, false); }
+#undef AIM_SWG_SEQ
     }
 #undef AIM_DP_LAUNCH
 }

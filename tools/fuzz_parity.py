@@ -200,13 +200,14 @@ def main():
         if algo != "wfa" and 0.7 <= r < 0.75: env["AIM_DPW_LEGACY"] = "1"
         if algo != "wfa" and 0.4 <= r < 0.5: env["AIM_FORCE_DPWAVE"] = "1"
         if algo != "wfa" and 0.5 <= r < 0.6: env["AIM_DPL_SEQ_LDS"] = "0"
+        if algo != "wfa" and rng.random() < 0.3: env["AIM_DPL_NO_REG"] = "1"      # short reads: pattern row from the LDS image / global memory instead of registers
         if algo != "wfa" and 0.6 <= r < 0.7: env["AIM_DPL_PER_CU"] = rng.choice(["1", "3", "12"])
         if algo == "wfa" and 0.35 <= r < 0.45: env["AIM_GROUP_PER_CU"] = rng.choice(["1", "5", "32"])
         if algo == "wfa" and 0.45 <= r < 0.5: env.update(AIM_FORCE_WAVE="1", AIM_WFA_NO_RING="1")
         if algo == "wfa" and rng.random() < 0.15: env["AIM_GROUP_WLDS"] = rng.choice(["64", "80", "96", "112"])   # ring rows that pairs outgrow / rows that are no power of two
         if rng.random() < 0.15: env["AIM_SCRATCH_GB"] = rng.choice(["0.25", "0.5", "2"])
         for k in ("AIM_GROUP_G", "AIM_FORCE_WAVE", "AIM_DPW_NW", "AIM_FORCE_DPWAVE", "AIM_DPL_SEQ_LDS", "AIM_DPL_PER_CU", "AIM_GROUP_PER_CU",
-                  "AIM_WFA_NO_RING", "AIM_SCRATCH_GB", "AIM_STRIP_K", "AIM_DPW_LEGACY", "AIM_GROUP_WLDS"): os.environ.pop(k, None)
+                  "AIM_WFA_NO_RING", "AIM_SCRATCH_GB", "AIM_STRIP_K", "AIM_DPW_LEGACY", "AIM_GROUP_WLDS", "AIM_DPL_NO_REG"): os.environ.pop(k, None)
         os.environ.update(env)
         req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
         if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")   # non-ACGT byte
