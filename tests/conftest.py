@@ -36,9 +36,19 @@ def sample_bytes():
 
 
 @pytest.fixture(scope="session")
-def err_bytes():
-    with gzip.open(os.path.join(GOLDEN, "ERR240727-l100-e1-first2000.gz"), "rb") as f:
-        return f.read()
+def err_full_bytes():
+    """The reference's own real-read set Datasets/ERR240727-l100-e1-30000Pairs (15 000 pairs, contains 'N'), whole file."""
+    with gzip.open(os.path.join(GOLDEN, "ERR240727-l100-e1-30000Pairs.gz"), "rb") as f:
+        data = f.read()
+    digests = json.load(open(os.path.join(GOLDEN, "reference_digests.json")))
+    assert hashlib.md5(data).hexdigest() == digests["err240727_input_md5"]
+    return data
+
+
+@pytest.fixture(scope="session")
+def err_bytes(err_full_bytes):
+    """Its first 2 000 pairs."""
+    return b"\n".join(err_full_bytes.split(b"\n")[:4000]) + b"\n"
 
 
 @pytest.fixture(scope="session")
@@ -51,12 +61,29 @@ def md5(b):
 
 
 def judge_cases():
-    """The wider reference digests the judges recorded: 14 in round 1 (tests/golden/judge_r01_cases.json) and 14 in round 2
-    (judge_r02_cases.json: dynamic-bounds / READ_SIZE-80 lane shapes, l = 150, MAX_SCORE 10, MRAM-variant overflow)."""
+    """The wider reference digests the judges recorded: 14 in round 1 (tests/golden/judge_r01_cases.json), 14 in round 2
+    (judge_r02_cases.json: dynamic-bounds / READ_SIZE-80 lane shapes, l = 150, MAX_SCORE 10, MRAM-variant overflow) and 20 in
+    round 3 (judge_r03_cases.json: score-unit loop 4/6/2 and 6/2/2, READ_SIZE 136 ... 184 with CIGAR, rows of 96, NW / SWG at
+    cfg4's real size). Rows where the reference aborts are in judge_abort_cases()."""
     cases = []
-    for name in ("judge_r01_cases.json", "judge_r02_cases.json"):
-        cases += json.load(open(os.path.join(GOLDEN, name)))["cases"]
+    for name in ("judge_r01_cases.json", "judge_r02_cases.json", "judge_r03_cases.json"):
+        cases += [c for c in json.load(open(os.path.join(GOLDEN, name)))["cases"] if "abort" not in c]
     return cases
+
+
+def judge_abort_cases():
+    """judge r03: inputs on which the reference AND the oracle stop with `SWG backtrace. No backtrace operation found`, exit 1
+    (swg.c:99-104: int8 cells wrapped on store)."""
+    return [c for c in json.load(open(os.path.join(GOLDEN, "judge_r03_cases.json")))["cases"] if "abort" in c]
+
+
+def judge_dataset_cases():
+    """judge r03: reference digests on the reference's own Datasets/ERR240727-l100-e1-30000Pairs, NR_DPUS 4, <n> 15000."""
+    return json.load(open(os.path.join(GOLDEN, "judge_r03_cases.json")))["dataset_cases"]
+
+
+def judge_costs(case):
+    return {k: case[k] for k in ("mismatch", "gap_o", "gap_e", "gap") if k in case}
 
 
 def judge_case_input(case):

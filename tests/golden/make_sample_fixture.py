@@ -3,8 +3,9 @@
 
   sample-l100-e1-40K.gz        <- /root/reference/Datasets/sample-l100-e1-40K (20 000 pairs, whole file,
                                   because the recorded reference digests are whole-file digests)
-  ERR240727-l100-e1-first2000.gz <- first 2 000 pairs of Datasets/ERR240727-l100-e1-30000Pairs (real reads,
-                                  contains 'N'; no reference digest exists for it, used for HIP-vs-oracle parity)
+  ERR240727-l100-e1-30000Pairs.gz <- Datasets/ERR240727-l100-e1-30000Pairs, whole file (15 000 pairs of real reads,
+                                  contains 'N'): the judge-r03 reference digests (judge_r03_cases.json,
+                                  "dataset_cases") are whole-file digests; the tests' `err_bytes` is its first 2 000 pairs
 
 reference_digests.json holds the md5 digests of the REFERENCE's output on the sample file as recorded in
 SURVEY.md section 8a / BASELINE.md section 2 (produced during the survey by running the reference sources).
@@ -16,14 +17,15 @@ src = "/root/reference/Datasets/"
 raw = open(src + "sample-l100-e1-40K", "rb").read()
 with gzip.GzipFile(os.path.join(here, "sample-l100-e1-40K.gz"), "wb", compresslevel=9, mtime=0) as f:
     f.write(raw)
-lines = open(src + "ERR240727-l100-e1-30000Pairs", "rb").read().split(b"\n")[:4000]
-with gzip.GzipFile(os.path.join(here, "ERR240727-l100-e1-first2000.gz"), "wb", compresslevel=9, mtime=0) as f:
-    f.write(b"\n".join(lines) + b"\n")
+err = open(src + "ERR240727-l100-e1-30000Pairs", "rb").read()
+with gzip.GzipFile(os.path.join(here, "ERR240727-l100-e1-30000Pairs.gz"), "wb", compresslevel=9, mtime=0) as f:
+    f.write(err)
 digests = {
     "_provenance": "md5 of the reference host program's output file on Datasets/sample-l100-e1-40K, "
                    "n=20000, NR_DPUS=1, launcher flags for -l 100 -e 0.01 (MAX_SCORE=5 [NW: 4], READ_SIZE=112); "
                    "recorded in SURVEY.md 8a and BASELINE.md 2",
     "input_md5": hashlib.md5(raw).hexdigest(),
+    "err240727_input_md5": hashlib.md5(err).hexdigest(),
     "wfa_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",
     "wfa_reduce_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",
     "swg_w8_backtrace": "63dfdb4ed4be17b9735e0febef6deeb7",

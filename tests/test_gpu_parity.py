@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import judge_case_input, judge_cases, md5, reduce_cases
+from conftest import (ROOT, judge_abort_cases, judge_case_input, judge_cases, judge_costs, judge_dataset_cases, md5,
+                      reduce_cases)
 
 pytestmark = pytest.mark.gpu
 
@@ -83,15 +84,56 @@ def test_sample_file_matches_reference_digest(gpu, sample_bytes, ref_digests, ke
 
 @pytest.mark.parametrize("case", judge_cases(), ids=lambda c: c["name"])
 def test_judge_r01_reference_digests_through_hip(gpu, case):
-    """The 14 wider reference digests of judge_r01_cases.json, through aim_set_* on the GPU."""
+    """The wider reference digests of judge_r01 / r02 / r03_cases.json, through aim_set_* on the GPU."""
     from aim_amd import engine
     data = judge_case_input(case)
     req, pat, txt = engine.parse_pairs(data, case["read_size"])
-    cost = {k: case[k] for k in ("mismatch", "gap_o", "gap_e") if k in case}
     params = engine.make_params(case["algo"], case["max_score"], case["read_size"], backtrace=case["backtrace"],
-                                reduce=case.get("reduce", False), swg_w16=case.get("swg_cell_bytes", 0) == 2, **cost)
+                                reduce=case.get("reduce", False), swg_w16=case.get("swg_cell_bytes", 0) == 2, **judge_costs(case))
     res, ops = engine.align(params, req, pat, txt)
     assert md5(engine.format_output(res, ops, case["backtrace"])) == case["output_md5"]
+
+
+def _host_cli(case, inp, out, cwd, extra=()):
+    import subprocess
+    c = judge_costs(case)
+    cmd = [os.path.join(ROOT, "aim_amd", "host", "host"), str(inp), str(out), str(case.get("n", case.get("gen", {}).get("n"))),
+           "--algo", case["algo"], "--max-score", str(case["max_score"]), "--read-size", str(case["read_size"]),
+           "--nr-dpus", str(case.get("nr_dpus", 1)), "--mismatch", str(c.get("mismatch", 3)), "--gap-o", str(c.get("gap_o", 4)),
+           "--gap-e", str(c.get("gap_e", 1)), "--gap", str(c.get("gap", 4))]
+    cmd += (["--backtrace"] if case["backtrace"] else []) + (["--reduce"] if case.get("reduce") else [])
+    cmd += ["--swg-w16"] if case.get("swg_cell_bytes", 0) == 2 else []
+    return subprocess.run(cmd + list(extra), capture_output=True, text=True, cwd=str(cwd))
+
+
+@pytest.mark.parametrize("case", judge_abort_cases(), ids=lambda c: c["name"])
+def test_judge_r03_abort_cases_through_hip(gpu, case, tmp_path):
+    """judge r03: where the reference stops with `SWG backtrace. No backtrace operation found` + exit(1) (swg.c:99-104) the HIP path
+    reports AIM_PAIR_SWG_NO_OP for exactly the pairs the oracle does, and the CLI prints the message and exits 1 -- on every
+    output path (compact CIGAR, ops rows, ASCII rows)."""
+    from aim_amd import capi, engine
+    data = judge_case_input(case)
+    req, pat, txt = engine.parse_pairs(data, case["read_size"])
+    params = engine.make_params(case["algo"], case["max_score"], case["read_size"], backtrace=True, **judge_costs(case))
+    res, _, ores = _compare(case["algo"], params, req, pat, txt)
+    assert (res["status"] == capi.PAIR_SWG_NO_OP).any() and set(res["status"].tolist()) <= {0, capi.PAIR_SWG_NO_OP}
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.write_bytes(data)
+    for extra in ((), ("--full-ops",), ("--no-pack", "--full-ops")):
+        r = _host_cli(case, inp, out, tmp_path, extra)
+        assert r.returncode == 1 and case["abort"] in r.stdout, (extra, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("case", judge_dataset_cases(), ids=lambda c: c["name"])
+def test_judge_r03_dataset_digests_through_the_host_cli(gpu, case, err_full_bytes, tmp_path):
+    """judge r03: whole-file digests of the reference on its own Datasets/ERR240727-l100-e1-30000Pairs (real reads with 'N':
+    the raw side list), NR_DPUS 4, through the drop-in CLI -- packed + compact output, and the reference's own wire formats."""
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.write_bytes(err_full_bytes)
+    for extra in ((), ("--no-pack", "--full-ops") if case["backtrace"] else ("--no-pack",), ("--batch", "4000", "--threads", "5")):
+        r = _host_cli(case, inp, out, tmp_path, extra)
+        assert r.returncode == 0, (extra, r.stdout, r.stderr)
+        assert md5(out.read_bytes()) == case["output_md5"], extra
 
 
 def test_sample_file_wave_kernel_too(gpu, sample_bytes, ref_digests, monkeypatch):

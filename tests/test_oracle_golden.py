@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, judge_case_input, judge_cases, md5, reduce_cases
+from conftest import (ROOT, judge_abort_cases, judge_case_input, judge_cases, judge_costs, judge_dataset_cases, md5,
+                      reduce_cases)
 
 
 def _run(oracle_mod, engine, data, algo, max_score, backtrace, reduce=False, swg_cell_bytes=0, threads=4):
@@ -85,12 +86,45 @@ def test_oracle_reproduces_judge_r01_reference_digests(built, case):
     from oracle import oracle
     data = judge_case_input(case)
     req, pat, txt = engine.parse_pairs(data, case["read_size"])
-    cost = {k: case[k] for k in ("mismatch", "gap_o", "gap_e") if k in case}
     p = oracle.params(case["algo"], case["max_score"], case["read_size"], backtrace=case["backtrace"],
-                      reduce=case.get("reduce", False), swg_cell_bytes=case.get("swg_cell_bytes", 0), **cost)
+                      reduce=case.get("reduce", False), swg_cell_bytes=case.get("swg_cell_bytes", 0), **judge_costs(case))
     res, ops, worst = oracle.align_batch(p, req["pattern_len"], req["text_len"], pat, txt, nthreads=4)
     assert worst == 0 and len(res) == case["gen"]["n"]
     assert md5(oracle.format_output(res, ops, case["backtrace"])) == case["output_md5"]
+
+
+@pytest.mark.parametrize("case", judge_abort_cases(), ids=lambda c: c["name"])
+def test_oracle_aborts_where_the_reference_aborts(built, case, tmp_path):
+    """judge r03: the reference stops with `SWG backtrace. No backtrace operation found` + exit(1) (swg.c:99-104) on these inputs
+    (int8 cells wrapped on store); so do the oracle and its CLI."""
+    from aim_amd import engine
+    from oracle import oracle
+    data = judge_case_input(case)
+    req, pat, txt = engine.parse_pairs(data, case["read_size"])
+    p = oracle.params(case["algo"], case["max_score"], case["read_size"], backtrace=True,
+                      swg_cell_bytes=case.get("swg_cell_bytes", 0), **judge_costs(case))
+    _, _, worst = oracle.align_batch(p, req["pattern_len"], req["text_len"], pat, txt, nthreads=4)
+    assert worst != 0
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.write_bytes(data)
+    g, c = case["gen"], judge_costs(case)
+    r = subprocess.run([os.path.join(ROOT, "oracle", "oracle_cli"), "swg", "-i", str(inp), "-o", str(out), "-n", str(g["n"]),
+                        "-l", str(g["l"]), "-e", str(g["e"]), "-b", "--max-score", str(case["max_score"]), "--read-size",
+                        str(case["read_size"]), "-x", str(c.get("mismatch", 3)), "-g", str(c.get("gap_o", 4)), "-a",
+                        str(c.get("gap_e", 1))], capture_output=True, text=True)
+    assert r.returncode == 1 and case["abort"] in r.stdout
+
+
+@pytest.mark.parametrize("case", judge_dataset_cases(), ids=lambda c: c["name"])
+def test_oracle_cli_reproduces_judge_r03_dataset_digests(built, case, err_full_bytes, tmp_path):
+    """judge r03: whole-file digests of the reference on its own real-read set, 4 DPUs (oracle_cli restates parser + partition)."""
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.write_bytes(err_full_bytes)
+    flags = (["-b"] if case["backtrace"] else []) + (["-r"] if case.get("reduce") else [])
+    subprocess.check_call([os.path.join(ROOT, "oracle", "oracle_cli"), case["algo"], "-i", str(inp), "-o", str(out), "-n",
+                           str(case["n"]), "-l", "100", "-e", "0.01", "-d", str(case["nr_dpus"]), "-t", "4", "--max-score",
+                           str(case["max_score"]), "--read-size", str(case["read_size"])] + flags)
+    assert md5(out.read_bytes()) == case["output_md5"]
 
 
 def test_oracle_reduction_changes_scores_on_constructed_pairs(built):
