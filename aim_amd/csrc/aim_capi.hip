@@ -125,6 +125,33 @@ aim::Knobs read_knobs()
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
     k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;
+    k.cus = (uint32_t)std::max(0, env_int("AIM_CHIP_CUS", 0));   // 0: ask the device (chip_cus)
+    return k;
+}
+
+// Compute units of the CURRENT device, read once per device (256 on a whole MI355X; a DPX / QPX / CPX partition or a CU-reduced part
+// reports fewer and every persistent grid shrinks with it). Without a device (planning queries on a CPU-only host) the whole chip.
+uint32_t chip_cus()
+{
+    static uint32_t cached[64] = {0};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (!cached[dev]) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        cached[dev] = (uint32_t)n;
+    }
+    return cached[dev];
+}
+// Knobs for a plan on the current device: AIM_CHIP_CUS wins, else the device's own count.
+aim::Knobs with_chip(aim::Knobs k)
+{
+    if (k.cus == 0) k.cus = chip_cus();
     return k;
 }
 
@@ -181,10 +208,10 @@ int validate_params(const aim_params_t &p)
     }
     if ((p.flags & AIM_FLAG_RES8) && (p.flags & AIM_FLAG_BACKTRACE))
         return fail(AIM_EINVAL, "AIM_FLAG_RES8 (idx, score results) cannot be combined with AIM_FLAG_BACKTRACE");
-    if (p.algo == AIM_ALGO_WFA && p.read_size >= 16376)
-        return fail(AIM_EINVAL, "WFA offsets are int16 (common.h:98-100): read_size must be < 16376");
-    if (p.algo != AIM_ALGO_WFA && p.read_size >= 32760)
-        return fail(AIM_EINVAL, "NW/SWG cells are int16: read_size must be < 32760");
+    // the reference's lengths, WFA offsets and NW / SWG cells are int16 (WFA/DPU-WRAM/common/common.h:98-100, 174-175): what it admits
+    // is < 32 767; READ_SIZE is a multiple of 8
+    if (p.read_size >= 32760)
+        return fail(AIM_EINVAL, "%s are int16: read_size must be < 32760", p.algo == AIM_ALGO_WFA ? "WFA offsets (common.h:98-100)" : "NW/SWG cells");
     return AIM_OK;
 }
 
@@ -205,7 +232,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         aim::wfa_lane_packed_supported(p, !kn.no_lane_ext)) {
         // packed rows in; {idx, score}, compact CIGAR or result_t + ops rows out: one kernel per batch, no scratch (wfa_lane_packed.hpp)
         pl->kid = K_WFA_LANE_PK;
-        aim::wfa_lane_packed_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+        aim::wfa_lane_packed_plan(p, n_pairs, kn, &pl->grid, &pl->block, &pl->lds);
         pl->scratch_total = 256;
         pl->pk = true;
         pl->emits_runs = bt && (mode & MODE_RUNS_OUT);
@@ -245,7 +272,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             // one pair per lane, everything in registers; no scratch, no second kernel (pairs with bytes outside A/C/G/T take
             // the kernel's own raw-byte path)
             pl->kid = K_WFA_LANE;
-            aim::wfa_lane_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+            aim::wfa_lane_plan(p, n_pairs, kn, &pl->grid, &pl->block, &pl->lds);
             pl->scratch_total = 256;   // unused; aim_scratch_bytes() keeps 0 for "invalid configuration"
 #if AIM_LANE_STAMPS
             pl->scratch_total += (size_t)pl->grid * 64;   // diagnostic builds park their s_memtime sums behind the first 256 bytes
@@ -267,7 +294,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             pl->fb_grid = fb.grid;
             pl->fb_lds = fb.lds;
             pl->kid = K_WFA_LANE_PK;
-            aim::wfa_lane_packed_plan(p, n_pairs, &pl->grid, &pl->block, &pl->lds);
+            aim::wfa_lane_packed_plan(p, n_pairs, kn, &pl->grid, &pl->block, &pl->lds);
             pl->pack_first = true;
             pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
             const size_t npw = aim::packed_row_dwords(p.read_size);
@@ -330,12 +357,12 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         // persistent single-wave workgroups: exactly what is resident (4 waves/SIMD by VGPRs, 160 KiB LDS per CU);
         // a larger grid runs in uneven rounds
         const uint32_t wg_per_cu = (uint32_t)std::min<size_t>(16, aim::lds_workgroups_per_cu(pl->lds));
-        uint32_t grid = 256 * wg_per_cu;
+        uint32_t grid = aim::resident_grid(kn, wg_per_cu);
         const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
         if (grid > need) grid = std::max(8u, need);
         uint64_t per = (uint64_t)pl->meta_cap * sizeof(aim::WfMeta) + cap * sizeof(int16_t);
         per = (per + 255) & ~255ull;
-        while (grid > 512 && per * grid > budget) grid = ((grid / 2) + 7u) & ~7u;
+        while (grid > 2 * kn.cus && grid > 16 && per * grid > budget) grid = ((grid / 2) + 7u) & ~7u;
         if (per * grid > budget) {
             const uint64_t meta_b = (uint64_t)pl->meta_cap * sizeof(aim::WfMeta);
             if (bt) {
@@ -416,7 +443,7 @@ int make_plan(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uin
     int rc = validate_params(p);
     if (rc) return rc;
     memset(pl, 0, sizeof *pl);
-    rc = make_plan_inner(p, n_pairs, kn, budget, mode, pl);
+    rc = make_plan_inner(p, n_pairs, kn.cus ? kn : with_chip(kn), budget, mode, pl);
     if (rc == AIM_OK && kn.plan_debug) {
         char line[384];
         describe_plan(*pl, p, n_pairs, budget, line, sizeof line);
@@ -438,29 +465,40 @@ void launch_wfa_wave(const Plan &pl, const aim::KArgs &ka, hipStream_t s)
 // wfa_group's traceback kernel of chunk c runs there while chunk c + 1 is computed on the caller's stream (the traceback is a
 // latency-bound walk -- 93 % of its wavefront cycles are waits -- so it costs the compute kernel next to nothing). Events are
 // re-recorded per launch; a hipStreamWaitEvent captures the record that precedes it, so re-use across launches is safe.
+// OWNERSHIP: every slot of a device set has its own (created on first use, destroyed with the slot), so two host threads driving two
+// sets -- or two slots -- on one device never record / wait on each other's events. The stateless aim_align_device has no slot: it
+// uses one per-device instance and holds that device's mutex across its whole chunk loop.
 struct AuxStream {
     hipStream_t stream = nullptr;
     hipEvent_t computed[2] = {nullptr, nullptr};   // compute kernel of the chunk that uses history buffer b has finished
     hipEvent_t walked[2] = {nullptr, nullptr};     // traceback of that chunk has finished (buffer b is free again)
 };
-int aux_stream_for_current_device(AuxStream **out)
+int aux_stream_create(AuxStream &a)
 {
-    static std::mutex mu;
-    static AuxStream table[64];
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return fail(AIM_ENODEV, "device index %d out of range", dev);
-    std::lock_guard<std::mutex> lock(mu);
-    AuxStream &a = table[dev];
-    if (!a.stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&a.computed[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&a.walked[i], hipEventDisableTiming));
-        }
+    if (a.stream) return AIM_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&a.computed[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&a.walked[i], hipEventDisableTiming));
     }
-    *out = &a;
     return AIM_OK;
+}
+void aux_stream_destroy(AuxStream &a)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (a.computed[i]) (void)hipEventDestroy(a.computed[i]);
+        if (a.walked[i]) (void)hipEventDestroy(a.walked[i]);
+    }
+    if (a.stream) (void)hipStreamDestroy(a.stream);
+    a = AuxStream();
+}
+struct SharedAux { std::mutex mu; AuxStream aux; };
+SharedAux *shared_aux_for_current_device()
+{
+    static SharedAux table[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    return &table[dev];
 }
 
 // The fused batch I/O of a launch (Plan::pk / Plan::emits_runs): packed rows in, compact CIGAR out.
@@ -474,7 +512,7 @@ struct FusedIo {
 // Enqueue one alignment launch that follows plan `pl` (made for >= n_pairs pairs under the caller's knobs and budget).
 int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t n_pairs, const void *d_req,
            const char *d_pat, const char *d_txt, void *d_res, char *d_ops, void *d_scratch, size_t scratch_bytes,
-           hipStream_t stream, const FusedIo *fio = nullptr)
+           hipStream_t stream, const FusedIo *fio = nullptr, AuxStream *slot_aux = nullptr)
 {
     if (n_pairs == 0) return AIM_OK;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
@@ -569,9 +607,16 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         const uint32_t nchunks = (n_pairs + chunk - 1) / chunk;
         const bool overlap = bt && nchunks > 1;
         const size_t buf_bytes = overlap ? pl.hist_bytes / 2 : 0;     // two alternating buffers of history regions
-        AuxStream *aux = nullptr;
+        AuxStream *aux = slot_aux;
+        std::unique_lock<std::mutex> shared_lock;   // stateless callers: the device's shared instance, locked until the last wait is enqueued
+        if (overlap && !aux) {
+            SharedAux *sh = shared_aux_for_current_device();
+            if (!sh) return fail(AIM_ENODEV, "no current HIP device");
+            shared_lock = std::unique_lock<std::mutex>(sh->mu);
+            aux = &sh->aux;
+        }
         if (overlap) {
-            int arc = aux_stream_for_current_device(&aux);
+            int arc = aux_stream_create(*aux);
             if (arc) return arc;
         }
         uint32_t ci = 0;
@@ -678,6 +723,7 @@ struct aim_slot {
     uint32_t n_pairs = 0;
     uint32_t runs_sent = 0;  // runs of the batch in flight whose D2H copy aim_set_submit already enqueued (slotted run buffer)
     bool pushed = false, launched = false, submitted = false;
+    AuxStream aux;           // this slot's second stream + events (chunked wfa_group launches with CIGAR); created on first use
     Plan plan_last;          // the plan the last launch followed (the configure-time plan re-made for the pushed pair count)
     aim_batch_io_t io;       // the batch in flight (aim_set_submit .. aim_set_wait)
 };
@@ -713,6 +759,7 @@ void free_slot(aim_slot &s)
     for (auto &e : s.ev)
         if (e) (void)hipEventDestroy(e);
     if (s.stream) (void)hipStreamDestroy(s.stream);
+    aux_stream_destroy(s.aux);
     s = aim_slot();
 }
 
@@ -812,7 +859,7 @@ int launch_on_slot(aim_set *set, aim_device_ctx &d, aim_slot &s, uint32_t mode =
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)fio->cursor, (int)(s.n_pairs * fio->run_slot), 1, s.stream));
     }
     return launch(pl, set->knobs, set->params, s.n_pairs, s.d_req, s.d_pat, s.d_txt, s.d_res, s.d_ops, s.d_scratch,
-                  s.scratch_bytes, s.stream, fio);
+                  s.scratch_bytes, s.stream, fio, &s.aux);
 }
 }  // namespace
 
@@ -894,8 +941,8 @@ int aim_set_configure_slots(aim_set_t *set, const aim_params_t *params, uint32_t
             HIP_TRY(hipMalloc((void **)&s.d_packP, (size_t)max_pairs * rowdw * 4 + 64));
             HIP_TRY(hipMalloc((void **)&s.d_packT, (size_t)max_pairs * rowdw * 4 + 64));
             HIP_TRY(hipMalloc((void **)&s.d_rawidx, (size_t)max_raw * 4));
-            HIP_TRY(hipMalloc((void **)&s.d_rawP, (size_t)max_raw * rs));
-            HIP_TRY(hipMalloc((void **)&s.d_rawT, (size_t)max_raw * rs));
+            HIP_TRY(hipMalloc((void **)&s.d_rawP, (size_t)max_raw * rs + 64));   // (+64 B: the raw side pass hands them to the ASCII kernels as patterns / texts, aim_hip.h tail slack)
+            HIP_TRY(hipMalloc((void **)&s.d_rawT, (size_t)max_raw * rs + 64));
             HIP_TRY(hipMalloc(&s.d_rawreq, (size_t)max_raw * req_size(*params)));
             HIP_TRY(hipMalloc(&s.d_rawres, (size_t)max_raw * res_size(*params)));
             if (params->flags & AIM_FLAG_BACKTRACE) HIP_TRY(hipMalloc((void **)&s.d_rawops, (size_t)max_raw * 2 * rs + 64));
@@ -1171,8 +1218,9 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
                                    s.d_rawidx, nr, rq_dw, (uint32_t *)s.d_rawreq);
                 HIP_TRY(hipGetLastError());
                 const Plan rp = plan_for_batch(set, d, s, nr, 0u);
-                rc = launch(rp, set->knobs, p, nr, s.d_rawreq, s.d_rawP, s.d_rawT, s.d_rawres, s.d_rawops, s.d_scratch, s.scratch_bytes, s.stream);
+                rc = launch(rp, set->knobs, p, nr, s.d_rawreq, s.d_rawP, s.d_rawT, s.d_rawres, s.d_rawops, s.d_scratch, s.scratch_bytes, s.stream, nullptr, &s.aux);
                 if (rc) return rc;
+                // (both outputs may be asked for at once -- aim_cigar_t + runs AND result_t [+ ops rows]: each gets its own scatter)
                 if (io->cigars) {
                     aim::KArgs kr = ka;
                     kr.n_pairs = nr;
@@ -1181,7 +1229,8 @@ int aim_set_submit(aim_set_t *set, uint32_t device, uint32_t slot, const aim_bat
                     hipLaunchKernelGGL(aim::cigar_rle_kernel, dim3((nr + 63) / 64), dim3(64), 0, s.stream, kr, s.d_rawcig, s.d_runs, runs_cap, s.d_cursor);
                     hipLaunchKernelGGL(aim::scatter_elems_kernel, blocks((uint64_t)nr * 4), dim3(256), 0, s.stream, (const uint32_t *)s.d_rawcig,
                                        s.d_rawidx, nr, 4u, (uint32_t *)s.d_cig);
-                } else {
+                }
+                if (!io->cigars || io->results || io->ops) {
                     hipLaunchKernelGGL(aim::scatter_elems_kernel, blocks((uint64_t)nr * rs_dw), dim3(256), 0, s.stream, (const uint32_t *)s.d_rawres,
                                        s.d_rawidx, nr, rs_dw, (uint32_t *)s.d_res);
                     if (bt) {   // default output (result_t + ops rows): the side list's ops rows go home too

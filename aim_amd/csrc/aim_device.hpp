@@ -1,6 +1,7 @@
 // aim_device.hpp -- shared device-side definitions for the gfx950 alignment kernels.
 // CDNA4 only: 64-lane wavefronts are assumed everywhere.
 #pragma once
+#include <algorithm>
 #include <cstddef>
 
 #include <hip/hip_runtime.h>
@@ -96,7 +97,7 @@ struct Knobs {
     int strip_k = -1;             // AIM_STRIP_K         dp_strip: cells per lane (16 or 32)
     int dpw_nw = -1;              // AIM_DPW_NW          dp_wave: wavefronts per pair (implies the row-scan kernel)
     int dpl_no_reg = 0;           // AIM_DPL_NO_REG      dp_lane: 1 = never keep the pattern row in registers (A/B)
-    int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: 0 = pattern from global memory
+    int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: where the pattern row lives -- 0 global memory, 1 LDS image, 2 registers (READ_SIZE <= 124); unset: the measured default
     int dpl_per_cu = -1;          // AIM_DPL_PER_CU      dp_lane: residency sweep
     int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs
     int group_g = -1;             // AIM_GROUP_G         wfa_group: lanes per pair
@@ -108,12 +109,27 @@ struct Knobs {
     int poison_scratch = -1;      // AIM_DEBUG_POISON_SCRATCH  fill scratch with this byte at configure
     int poison_lds = -1;          // AIM_DEBUG_POISON_LDS      fill dynamic LDS with this byte at kernel entry
     bool plan_debug = false;      // AIM_PLAN_DEBUG=1    print the chosen plan to stderr
+    // Not a knob but the one fact about the chip every plan needs: compute units of the device the plan is made for
+    // (hipDeviceAttributeMultiprocessorCount, read once per device by chip_cus() in aim_capi.hip: 256 on a whole MI355X, 128 / 64 / 32
+    // in DPX / QPX / CPX partitions). AIM_CHIP_CUS overrides it (CPU tests plan for devices this host does not have).
+    uint32_t cus = 256;
 };
+
+// Persistent grid = what is resident: `per_cu` workgroups on each of the device's compute units, rounded up to the multiple of 8
+// xcd_unit() needs.
+inline uint32_t resident_grid(const Knobs &kn, uint32_t per_cu)
+{
+    const uint64_t g = (uint64_t)(kn.cus ? kn.cus : 256u) * per_cu;
+    return (uint32_t)std::min<uint64_t>((g + 7u) & ~7ull, 1u << 20);
+}
 
 // XCD-aware work distribution: workgroups are dealt round-robin over the 8 XCDs
 // (blockIdx % 8 labels the XCD group), so give each group one contiguous slice
 // of the batch: neighbouring pairs share 128-B lines and then share an L2.
 // Requires gridDim.x % 8 == 0.  Returns false when this (block, iteration) has no work.
+// The 8 is the slice count, not an assumption about the device: on a partition with X = 4 / 2 / 1 XCDs workgroup b runs on
+// XCD b % X, and since X divides 8 the slices b % 8 == c and c + X, ... land on the same XCD -- every XCD still owns whole
+// contiguous slices. What DOES depend on the device is the resident grid size: resident_grid() above.
 __device__ __forceinline__ bool xcd_unit(uint32_t n_units, uint32_t it, uint32_t *unit)
 {
     const uint32_t xcd = blockIdx.x & 7u;

@@ -509,7 +509,7 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     per = (per + 255) & ~255ull;
     if (!(p.flags & AIM_FLAG_BACKTRACE)) per = 256;   // score-only: no table at all
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
-    uint32_t g = 256 * 12;   // capped below by what LDS admits
+    uint32_t g = resident_grid(kn, 12);   // capped below by what LDS admits
     const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     while (g > 8 && per * g > budget) g -= 8;
@@ -527,19 +527,22 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     // READ_SIZE <= 124: no image either -- the pattern row lives in REGISTERS (dp_lane_launch, SEQ = 2), the LDS it frees is residency
     // (10 instead of 7 workgroups per CU). l = 100, 1 M pairs, same box, image in LDS / registers / global memory: NW score-only 4.30 / 3.27 /
     // 5.25 ms, NW with CIGAR 7.60 / 6.86 / 11.8, SWG score-only - / 5.89 / 6.25, SWG with CIGAR 12.7 / 11.0 / 14.5.
-    if (p.read_size <= 124 && !kn.dpl_no_reg) *seq_lds = false;
-    if (kn.dpl_seq_lds >= 0) *seq_lds = *seq_lds && kn.dpl_seq_lds != 0;   // experiments: 0 = pattern from global memory
+    if (p.read_size <= 124 && !kn.dpl_no_reg && kn.dpl_seq_lds < 0) *seq_lds = false;
+    // experiments (AIM_DPL_SEQ_LDS): 0 = pattern from global memory, 1 = image in LDS (where it fits), 2 = registers (READ_SIZE <= 124);
+    // an explicit value overrides the defaults above
+    if (kn.dpl_seq_lds == 0 || (kn.dpl_seq_lds == 2 && p.read_size <= 124)) *seq_lds = false;
+    else if (kn.dpl_seq_lds == 1) *seq_lds = img + rows <= 150 * 1024;
     *lds = rows + (*seq_lds ? img : 0);
     if (*lds > 160 * 1024) return false;
     uint32_t per_cu = (uint32_t)std::min<size_t>(12, lds_workgroups_per_cu(*lds));
     if (kn.dpl_per_cu >= 0) {   // experiments: residency sweep (also lifts the 8-per-CU start value)
         per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.dpl_per_cu), lds_workgroups_per_cu(*lds));
-        g = std::min<uint32_t>(256 * per_cu, need < 8u ? 8u : need);
+        g = std::min<uint32_t>(resident_grid(kn, per_cu), need < 8u ? 8u : need);
         while (g > 8 && per * g > budget) g -= 8;
         *grid = g;
     }
-    if (g > 256 * per_cu) {
-        g = 256 * per_cu;
+    if (g > resident_grid(kn, per_cu)) {
+        g = resident_grid(kn, per_cu);
         *grid = g;
     }
     *scratch_per_wg = per;
@@ -550,7 +553,7 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
 inline void dp_lane_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-    const int seq = seq_lds ? 1 : (p.read_size <= 124 && !kn.dpl_no_reg) ? 2 : 0;   // no image in LDS: registers when the row fits 31 dwords (preg[w0 + 1] stays inside the vector)
+    const int seq = seq_lds ? 1 : (p.read_size <= 124 && !kn.dpl_no_reg && kn.dpl_seq_lds != 0) ? 2 : 0;   // no image in LDS: registers when the row fits 31 dwords (preg[w0 + 1] stays inside the vector)
 #define AIM_DP_LAUNCH(KERNEL)                                                                                             \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

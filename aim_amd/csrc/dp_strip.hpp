@@ -594,7 +594,7 @@ inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *s
         const int nw = (rs + kWave * k - 1) / (kWave * k);
         if (nw > (k == 16 ? 12 : 8)) continue;
         // few pairs (about one per CU, config 4): the busiest SIMD's wavefronts set the time; many pairs: the total work does
-        const long cost = (n_pairs > 1024 ? (long)nw : (long)((nw + 3) / 4)) * (110 + 10L * k);
+        const long cost = (n_pairs > 4u * kn.cus ? (long)nw : (long)((nw + 3) / 4)) * (110 + 10L * k);
         if (!best_k || cost < best_cost) { best_k = k; best_nw = nw; best_cost = cost; }
     }
     if (!best_k) return false;
@@ -632,7 +632,7 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     const bool heavy = swg && (p.flags & AIM_FLAG_BACKTRACE);
     const uint32_t waves_per_cu = sh.k >= 24 ? 8u : (heavy ? 12u : 16u);
     const uint32_t per_cu = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves_per_cu / (uint32_t)nw, (uint64_t)lds_workgroups_per_cu(*lds)));
-    uint32_t g = 256 * per_cu;
+    uint32_t g = resident_grid(kn, per_cu);
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     while (g > 8 && per * g > budget) g -= 8;

@@ -611,7 +611,7 @@ inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn)
     // 2.49 / 2.09 / 2.38; READ_SIZE 2048, 2048 pairs NW 9.66 / 9.46 / 11.2, SWG 17.2 / 15.9 / 17.1; READ_SIZE 3072, 2048 pairs
     // NW 19.1 / 18.8 / 24.0, SWG 38.9 / 34.3 / 37.6 (8 wavefronts 32.8 / 45.6).
     if (nblocks <= 8) {
-        const uint32_t target = n_pairs ? (4096u + n_pairs - 1) / n_pairs : 4u;
+        const uint32_t target = n_pairs ? (16u * kn.cus + n_pairs - 1) / n_pairs : 4u;   // (4 096 wavefronts on 256 CUs)
         const int cap = (int)std::min<uint32_t>(target, (uint32_t)nblocks);
         return cap >= 4 ? 4 : (cap >= 2 ? 2 : 1);
     }
@@ -641,7 +641,7 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     *lds = ((rs + 31) & ~15ull) + (size_t)((swg ? 4 : 2) * rowcap + 64) * 2 + 256;
     if (*lds > 160 * 1024) return false;
     const uint32_t per_cu = (uint32_t)std::min<uint64_t>(32 / nw, (uint64_t)lds_workgroups_per_cu(*lds));
-    uint32_t g = 256 * per_cu;
+    uint32_t g = resident_grid(kn, per_cu);
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     while (g > 8 && per * g > budget) g -= 8;

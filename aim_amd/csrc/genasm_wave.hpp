@@ -398,7 +398,7 @@ inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs
     *lds = lg ? (size_t)(kGlCols * 16 + kGlPm) * 8 + 64 : (size_t)kGaCols * kGaSlots * 8 + 64;
     uint32_t per_cu = (uint32_t)std::min<size_t>(16, lds_workgroups_per_cu(*lds));   // (the standard variant's 13 KB: 11; capped at 8 until round 3)
     if (kn.ga_per_cu > 0) per_cu = (uint32_t)std::min<size_t>((size_t)kn.ga_per_cu, lds_workgroups_per_cu(*lds));   // residency sweeps
-    uint32_t g = 256 * per_cu;
+    uint32_t g = resident_grid(kn, per_cu);
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;

@@ -758,7 +758,7 @@ inline bool wfa_group_plan_rows(const aim_params_t &p, uint32_t n_pairs, const K
     if (per_cu > 16) per_cu &= ~3u;
     if (kn.group_per_cu >= 0) per_cu = (uint32_t)std::min<size_t>((size_t)std::max(1, kn.group_per_cu), lds_fit);   // residency sweeps
     const uint32_t n_units = (n_pairs + (kWave / g) - 1) / (kWave / g);
-    uint32_t gr = 256 * per_cu;
+    uint32_t gr = resident_grid(kn, per_cu);
     const uint32_t need = ((n_units + 7u) / 8u) * 8u;
     if (gr > need) gr = need < 8u ? 8u : need;
     *grid = gr;

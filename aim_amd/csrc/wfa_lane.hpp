@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64, DYN ? 2 : AIM_LANE_MIN_WAVES) void wfa_lane_ker
 // ---------------------------------------------------------------------------------------------------
 // host-side planning / dispatch
 // ---------------------------------------------------------------------------------------------------
-constexpr uint32_t kLaneGrid = 256 * AIM_LANE_WGS_PER_CU;   // single-wave workgroups, LDS 2 x 64 rows x 112 B = 14 KiB each
+// persistent grid: AIM_LANE_WGS_PER_CU single-wave workgroups per CU, LDS 2 x 64 rows x 112 B = 14 KiB each
 
 constexpr int kLaneDynMaxScore = 10;   // the dynamic-bounds instantiation: MAX_SCORE 6..10 (l = 100: e up to 2 %), score-only
 
@@ -905,10 +905,10 @@ inline bool wfa_lane_supported(const aim_params_t &p, bool allow_dynamic = true)
 
 inline size_t wfa_lane_todo_bytes(uint32_t n_pairs) { return ((size_t)(LANE_TODO_LIST + n_pairs) * 4 + 255) & ~(size_t)255; }
 
-inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
+inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, uint32_t *block, size_t *lds)
 {
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
-    uint32_t g = kLaneGrid;
+    uint32_t g = resident_grid(kn, AIM_LANE_WGS_PER_CU);
     const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;

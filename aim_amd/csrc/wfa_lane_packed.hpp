@@ -584,7 +584,7 @@ inline bool wfa_lane_packed_supported(const aim_params_t &p, bool allow_dynamic 
     return allow_dynamic && p.max_score <= kLaneDynMaxScore;
 }
 
-inline void wfa_lane_packed_plan(const aim_params_t &p, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
+inline void wfa_lane_packed_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, uint32_t *block, size_t *lds)
 {
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE, dyn = p.max_score > 5;
@@ -596,7 +596,7 @@ inline void wfa_lane_packed_plan(const aim_params_t &p, uint32_t n_pairs, uint32
     const int np = (p.read_size + 15) / 16;
     uint32_t per_cu = !dyn ? AIM_LANEPK_WGS_PER_CU : ((np <= 7 && !bt) ? 16u : (np <= 9 ? 12u : (np <= 10 && !bt ? 12u : AIM_LANEPK_DYN_WGS_PER_CU)));
     if (*lds) per_cu = (uint32_t)std::min<size_t>(per_cu, lds_workgroups_per_cu(*lds));
-    uint32_t g = 256u * per_cu;
+    uint32_t g = resident_grid(kn, per_cu);
     const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
     if (g > need) g = need < 8u ? 8u : need;
     *grid = g;

@@ -455,6 +455,7 @@ typedef struct {
     size_t caps[2][MAX_THREADS], lens[2][MAX_THREADS], offs[2][MAX_THREADS];
     char **buf;                        /* = bufs[set] etc. */
     size_t *cap, *len, *off;
+    int seq;                           /* output is no regular file: sequential write() by one thread, in thread order */
     char *map;                         /* MAP_SHARED window of the output file for this batch (NULL: pwrite) */
     size_t map_base;                   /* file offset of map[0] */
     int failed;
@@ -526,7 +527,7 @@ typedef struct {
     pthread_mutex_t mu;
     pthread_cond_t cv;
     int started, busy, stop, failed;
-    int fd, n;
+    int fd, n, seq;                      /* seq: the output is no regular file (pipe, FIFO, /dev/stdout piped): write() in order, no offsets */
     char **buf;
     size_t *len, *off;
 } writer_t;
@@ -543,7 +544,7 @@ static void *writer_main(void *arg)
             const char *q = w->buf[t];
             size_t left = w->len[t], off = w->off[t];
             while (left) {
-                const ssize_t k = pwrite(w->fd, q, left, (off_t)off);
+                const ssize_t k = w->seq ? write(w->fd, q, left) : pwrite(w->fd, q, left, (off_t)off);
                 if (k <= 0) { w->failed = 1; break; }
                 q += k; off += (size_t)k; left -= (size_t)k;
             }
@@ -583,7 +584,7 @@ static void write_range(int tid, int nt, void *arg)
     const char *q = f->buf[tid];
     size_t left = f->len[tid], off = f->off[tid];
     while (left) {
-        const ssize_t w = pwrite(f->fd, q, left, (off_t)off);
+        const ssize_t w = f->seq ? write(f->fd, q, left) : pwrite(f->fd, q, left, (off_t)off);
         if (w <= 0) { __atomic_store_n(&f->failed, 1, __ATOMIC_RELAXED); return; }
         q += w; off += (size_t)w; left -= (size_t)w;
     }
@@ -837,14 +838,18 @@ int main(int argc, char *argv[])
     pthread_cond_init(&g_writer.cv, NULL);
     g_writer.fd = out_fd;
     const char *out_mode = getenv("AIM_HOST_OUT");
-    const int out_async = !out_mode || !strcmp(out_mode, "async");
-    if (out_async) g_writer.started = pthread_create(&g_writer.th, NULL, writer_main, &g_writer) == 0;
-    int out_mmap = out_mode && !strcmp(out_mode, "mmap");   /* A/B switch; see the loop */
+    /* A pipe / FIFO / character device cannot be written at offsets (pwrite: ESPIPE): like the reference's fopen(out, "w") the
+       text then goes out sequentially -- one writer, batches and per-thread buffers in order. */
+    int out_seq = 0;
     {
         struct stat os;
-        if (fstat(out_fd, &os) || !S_ISREG(os.st_mode)) out_mmap = 0;
+        if (fstat(out_fd, &os) || !S_ISREG(os.st_mode)) out_seq = 1;
     }
-    const int out_serial = getenv("AIM_HOST_OUT") && !strcmp(getenv("AIM_HOST_OUT"), "serial");   /* one thread writes */
+    g_writer.seq = f.seq = out_seq;
+    const int out_async = out_seq || !out_mode || !strcmp(out_mode, "async");
+    if (out_async) g_writer.started = pthread_create(&g_writer.th, NULL, writer_main, &g_writer) == 0;
+    int out_mmap = !out_seq && out_mode && !strcmp(out_mode, "mmap");   /* A/B switch; see the loop */
+    const int out_serial = out_seq || (out_mode && !strcmp(out_mode, "serial"));   /* one thread writes (also the fallback when no writer thread could be created) */
     if (out_serial) out_mmap = 0;
     const double t_loop = now_ms();
     double t_first_done = 0;
@@ -912,7 +917,7 @@ int main(int argc, char *argv[])
             } else {
             /* Writes to one file serialise on its inode lock (measured: 2.5 GB/s however many threads call pwrite, and the output
                is 14-22 bytes per pair); a shared mapping of the batch's window lets all threads fill the page cache at once.
-               Falls back to pwrite where the file cannot be extended / mapped (pipes, /dev/null). */
+               Falls back to pwrite where the file cannot be extended / mapped; no regular file at all (pipes): out_seq above. */
             f.map = NULL;
             if (out_mmap && out_at > batch_at && ftruncate(out_fd, (off_t)out_at) == 0) {
                 const size_t pg = (size_t)sysconf(_SC_PAGESIZE);

@@ -160,3 +160,34 @@ def test_scratch_bound_default_and_override(built):
     assert c2_default == c2_16 == c2_100                     # need-capped plan
     assert c4_16 <= 16 << 30 and c4_16 // per_pair in range(20, 28)     # 5 rounds of 128 pairs
     assert c4_100 // per_pair == 128                         # one round
+
+
+def test_plans_follow_the_device_compute_unit_count(built):
+    """Every persistent grid is `workgroups per CU x the device's CU count` (aim::resident_grid), not a literal 256: plans made for a
+    64-CU (QPX partition), 128-CU (DPX) and 304-CU device scale with it, stay multiples of 8 (xcd_unit), and keep the per-CU residency."""
+    from aim_amd import engine
+    cases = [("wfa", 100, 0.01, {}, 1 << 22), ("wfa", 100, 0.05, {}, 1 << 22), ("wfa", 1000, 0.05, dict(reduce=True, backtrace=True), 1 << 16),
+             ("wfa", 10000, 0.01, dict(reduce=True), 1 << 16), ("nw", 100, 0.01, dict(backtrace=True), 1 << 22), ("swg", 100, 0.01, {}, 1 << 22),
+             ("swg", 1000, 0.05, {}, 1 << 16), ("genasm", 1000, 0.1, {}, 1 << 16)]
+    lines = ["import ctypes as C, sys; sys.path.insert(0, %r); from aim_amd import capi, engine; lib = capi.load(); buf = C.create_string_buffer(512)" % ROOT]
+    for algo, l, e, kw, n in cases:
+        ms, rs = engine.launcher_sizes("wfa" if algo == "genasm" else algo, l, e)
+        lines.append("p = engine.make_params(%r, %d, %d, **%r); assert lib.aim_plan_describe(C.byref(p), %d, buf, 512) == 0; print(buf.value.decode())"
+                     % (algo, ms, rs, kw, n))
+    def grids(cus):
+        e = {k: v for k, v in os.environ.items() if k != "AIM_CHIP_CUS"}
+        if cus:
+            e["AIM_CHIP_CUS"] = str(cus)
+        r = subprocess.run([os.sys.executable, "-c", "\n".join(lines)], env=e, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        out = [(l.split()[0], int(re.search(r"grid=(\d+)", l).group(1))) for l in r.stdout.splitlines()]
+        assert len(out) == len(cases)
+        return out
+    whole = grids(256)
+    assert grids(None) == whole                       # no device here: the whole chip
+    assert dict(whole)["wfa_lane_kernel"] == 2048     # the headline plan is unchanged
+    for cus in (64, 128, 304):
+        for (k0, g0), (k1, g1) in zip(whole, grids(cus)):
+            assert k0 == k1 and g1 % 8 == 0
+            exp = g0 * cus // 256
+            assert g1 == exp or (k0.startswith("dp_") and exp - 64 <= g1 <= exp), (k0, cus, g0, g1)   # (table slabs: the 16-GB planning bound may trim a few workgroups)

@@ -57,6 +57,13 @@ def test_generator_is_deterministic_and_shardable(built):
     assert (np.abs(r3["text_len"] - 1000) <= 50).all() and (t3[np.arange(500), r3["text_len"] - 1] != 0).all()
 
 
+def test_host_cli_output_to_a_pipe_is_sequential(built):
+    """the writer must not pwrite() into a pipe (ESPIPE). Only the code path can be checked without a GPU: host.c stats
+    the output and switches writer + fallback loop to in-order write() when it is no regular file."""
+    src = open(os.path.join(ROOT, "aim_amd", "host", "host.c")).read()
+    assert "S_ISREG" in src and "w->seq ? write(" in src and "f->seq ? write(" in src
+
+
 def test_host_cli_argument_errors(built, tmp_path):
     host = os.path.join(ROOT, "aim_amd", "host", "host")
     r = subprocess.run([host], capture_output=True, text=True)
