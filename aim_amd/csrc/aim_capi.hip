@@ -452,13 +452,9 @@ int make_plan(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &kn, uin
     return rc;
 }
 
-template <bool BT, bool RED>
-void launch_wfa_wave(const Plan &pl, const aim::KArgs &ka, hipStream_t s)
+void launch_wfa_wave(bool bt, bool red, const Plan &pl, const aim::KArgs &ka, hipStream_t s)
 {
-    if (pl.seq_lds)
-        hipLaunchKernelGGL((aim::wfa_wave_kernel<BT, RED, true>), dim3(pl.grid), dim3(64), pl.lds, s, ka);
-    else
-        hipLaunchKernelGGL((aim::wfa_wave_kernel<BT, RED, false>), dim3(pl.grid), dim3(64), pl.lds, s, ka);
+    aim::wfa_wave_launch(bt, red, pl.seq_lds, pl.grid, pl.lds, ka, s);
 }
 
 // A second stream per device for work that only has to be ordered against ONE kernel of a launch, not against the whole stream:
@@ -551,10 +547,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     ka.pair_base = 0;
     switch (pl.kid) {
     case K_WFA_WAVE:
-        if (bt && red) launch_wfa_wave<true, true>(pl, ka, stream);
-        else if (bt) launch_wfa_wave<true, false>(pl, ka, stream);
-        else if (red) launch_wfa_wave<false, true>(pl, ka, stream);
-        else launch_wfa_wave<false, false>(pl, ka, stream);
+        launch_wfa_wave(bt, red, pl, ka, stream);
         break;
     case K_WFA_LANE:
         ka.scratch_per_wave = 256;
@@ -587,10 +580,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
             fb.grid = pl.fb_grid;
             fb.lds = pl.fb_lds;
             kb.dbg_lds_bytes = (uint32_t)fb.lds;
-            if (bt && red) launch_wfa_wave<true, true>(fb, kb, stream);
-            else if (bt) launch_wfa_wave<true, false>(fb, kb, stream);
-            else if (red) launch_wfa_wave<false, true>(fb, kb, stream);
-            else launch_wfa_wave<false, false>(fb, kb, stream);
+            launch_wfa_wave(bt, red, fb, kb, stream);
             break;
         }
         aim::wfa_lane_packed_launch(p, pl.grid, pl.lds, ka, fio->run_slot, stream);
@@ -671,10 +661,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         fb.grid = pl.fb_grid;
         fb.lds = pl.fb_lds;
         kb.dbg_lds_bytes = (uint32_t)fb.lds;
-        if (bt && red) launch_wfa_wave<true, true>(fb, kb, stream);
-        else if (bt) launch_wfa_wave<true, false>(fb, kb, stream);
-        else if (red) launch_wfa_wave<false, true>(fb, kb, stream);
-        else launch_wfa_wave<false, false>(fb, kb, stream);
+        launch_wfa_wave(bt, red, fb, kb, stream);
         if (pl.emits_runs) {   // the general kernel wrote result_t + ops rows for the to-do pairs: their compact CIGAR
             hipLaunchKernelGGL(aim::cigar_rle_todo_kernel, dim3(256), dim3(64), 0, stream, kb, kb.todo, ka.cig, ka.runs, ka.runs_cap, ka.cursor);
             HIP_TRY(hipGetLastError());

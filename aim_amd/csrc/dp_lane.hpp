@@ -550,7 +550,9 @@ inline bool dp_lane_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     return true;
 }
 
-inline void dp_lane_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_DP_LANE); every other includer sees the declaration only.
+#ifdef AIM_TU_DP_LANE
+void dp_lane_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const int seq = seq_lds ? 1 : (p.read_size <= 124 && !kn.dpl_no_reg && kn.dpl_seq_lds != 0) ? 2 : 0;   // no image in LDS: registers when the row fits 31 dwords (preg[w0 + 1] stays inside the vector)
@@ -575,5 +577,8 @@ inline void dp_lane_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid
     }
 #undef AIM_DP_LAUNCH
 }
+#else
+void dp_lane_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, bool seq_lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

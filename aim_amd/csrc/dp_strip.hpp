@@ -644,7 +644,9 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
 }
 
 // k: the plan's cells per lane (dp_strip_plan); the workgroup size gives the wavefront count
-inline void dp_strip_launch(const aim_params_t &p, int k, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_DP_STRIP); every other includer sees the declaration only.
+#ifdef AIM_TU_DP_STRIP
+void dp_strip_launch(const aim_params_t &p, int k, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     StripShape sh;
@@ -668,5 +670,8 @@ inline void dp_strip_launch(const aim_params_t &p, int k, uint32_t grid, uint32_
 #undef AIM_STRIP_K
 #undef AIM_STRIP
 }
+#else
+void dp_strip_launch(const aim_params_t &p, int k, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

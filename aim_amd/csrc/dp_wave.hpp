@@ -652,7 +652,9 @@ inline bool dp_wave_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budge
     return true;
 }
 
-inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_DP_WAVE); every other includer sees the declaration only.
+#ifdef AIM_TU_DP_WAVE
+void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const int nw = (int)(block / kWave);   // the plan's choice (it depends on the number of pairs)
@@ -680,5 +682,8 @@ inline void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, uin
 #undef AIM_DPW_NW
 #undef AIM_DPW
 }
+#else
+void dp_wave_launch(const aim_params_t &p, bool cell8, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

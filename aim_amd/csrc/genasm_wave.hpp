@@ -404,7 +404,9 @@ inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs
     *grid = g;
 }
 
-inline void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_GENASM); every other includer sees the declaration only.
+#ifdef AIM_TU_GENASM
+void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     if (genasm_long(p, kn)) {
@@ -415,5 +417,8 @@ inline void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid,
         else hipLaunchKernelGGL((genasm_wave_kernel<false, false>), dim3(grid), dim3(kWave), lds, s, ka);
     }
 }
+#else
+void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

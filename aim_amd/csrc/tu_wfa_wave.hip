@@ -1,0 +1,4 @@
+// tu_wfa_wave.hip -- the translation unit that instantiates the kernels of wfa_wave.hpp (aim_amd/build.py compiles the tu_*.hip files in
+// parallel and links them with aim_capi.hip into libaim_hip.so).
+#define AIM_TU_WFA_WAVE 1
+#include "wfa_wave.hpp"

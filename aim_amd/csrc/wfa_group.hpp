@@ -801,15 +801,22 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     return wfa_group_plan_rows(p, n_pairs, kn, packed, rows, c, G, grid, lds, hist_pair_bytes);
 }
 
-inline void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pairs, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_WFA_GROUP); every other includer sees the declaration only.
+#ifdef AIM_TU_WFA_GROUP
+void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pairs, const KArgs &ka, hipStream_t s)
 {
     (void)p;
     const uint32_t grid = (n_pairs + kWave - 1) / kWave;
     if (ka.cig) hipLaunchKernelGGL((wfa_group_tb_kernel<true>), dim3(grid), dim3(kWave), 0, s, ka, c);
     else hipLaunchKernelGGL((wfa_group_tb_kernel<false>), dim3(grid), dim3(kWave), 0, s, ka, c);
 }
+#else
+void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pairs, const KArgs &ka, hipStream_t s);
+#endif
 
-inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_WFA_GROUP); every other includer sees the declaration only.
+#ifdef AIM_TU_WFA_GROUP
+void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool red = p.flags & AIM_FLAG_REDUCE, bt = p.flags & AIM_FLAG_BACKTRACE;
 #define AIM_GRP(GG)                                                                                                     \
@@ -836,5 +843,8 @@ inline void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, ui
     }
 #undef AIM_GRP
 }
+#else
+void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

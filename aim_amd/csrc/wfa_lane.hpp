@@ -916,7 +916,9 @@ inline void wfa_lane_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &
     *lds = (size_t)2 * kWave * p.read_size + kWave * 16 + ((p.flags & AIM_FLAG_BACKTRACE) ? kWave * sizeof(aim_result_t) : 0);
 }
 
-inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_WFA_LANE); every other includer sees the declaration only.
+#ifdef AIM_TU_WFA_LANE
+void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s)
 {
     (void)block;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
@@ -937,5 +939,8 @@ inline void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block
     }
 #undef AIM_LANE_LAUNCH
 }
+#else
+void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

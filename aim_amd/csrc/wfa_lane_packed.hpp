@@ -604,7 +604,9 @@ inline void wfa_lane_packed_plan(const aim_params_t &p, uint32_t n_pairs, const 
 }
 
 // Output follows the buffers given: compact CIGAR when ka.cig is set, else (BACKTRACE) result_t + ops rows, else scores.
-inline void wfa_lane_packed_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, uint32_t run_slot, hipStream_t s)
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_WFA_LANE_PACKED); every other includer sees the declaration only.
+#ifdef AIM_TU_WFA_LANE_PACKED
+void wfa_lane_packed_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, uint32_t run_slot, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const int np = (p.read_size + 15) / 16;
@@ -627,5 +629,8 @@ inline void wfa_lane_packed_launch(const aim_params_t &p, uint32_t grid, size_t 
 #undef AIM_LANEPK_LAUNCH
 #undef AIM_LANEPK_ONE
 }
+#else
+void wfa_lane_packed_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, uint32_t run_slot, hipStream_t s);
+#endif
 
 }  // namespace aim

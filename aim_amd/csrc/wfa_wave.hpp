@@ -457,4 +457,23 @@ __global__ __launch_bounds__(64) void wfa_wave_kernel(KArgs a)
     }
 }
 
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_WFA_WAVE); every other includer sees the declaration only.
+#ifdef AIM_TU_WFA_WAVE
+void wfa_wave_launch(bool bt, bool red, bool seq_lds, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+#define AIM_WFW(BTV, REDV)                                                                                              \
+    do {                                                                                                                \
+        if (seq_lds) hipLaunchKernelGGL((wfa_wave_kernel<BTV, REDV, true>), dim3(grid), dim3(kWave), lds, s, ka);       \
+        else hipLaunchKernelGGL((wfa_wave_kernel<BTV, REDV, false>), dim3(grid), dim3(kWave), lds, s, ka);              \
+    } while (0)
+    if (bt && red) AIM_WFW(true, true);
+    else if (bt) AIM_WFW(true, false);
+    else if (red) AIM_WFW(false, true);
+    else AIM_WFW(false, false);
+#undef AIM_WFW
+}
+#else
+void wfa_wave_launch(bool bt, bool red, bool seq_lds, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
+
 }  // namespace aim

@@ -1385,7 +1385,7 @@ def test_group_kernel_chunks_overlap_traceback_and_compute(gpu, monkeypatch, env
 
 
 # ------------------------------------------------------------------ round 4
-@pytest.mark.parametrize("l,err,n,kw", [(16000, 0.01, 6, dict(reduce=True, backtrace=True)), (20000, 0.005, 6, dict(reduce=True)),
+@pytest.mark.parametrize("l,err,n,kw", [(16300, 0.01, 6, dict(reduce=True, backtrace=True)), (20000, 0.005, 6, dict(reduce=True)),
                                         (32000, 0.002, 4, dict(reduce=True, backtrace=True)), (32000, 0.002, 4, dict())])
 def test_wfa_reads_up_to_the_int16_length_limit(gpu, l, err, n, kw):
     """The reference's lengths and WFA offsets are int16 (WFA/DPU-WRAM/common/common.h:98-100, 174-175): READ_SIZE < 32 760 is admitted
