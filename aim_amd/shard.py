@@ -17,10 +17,11 @@ def weak_first_index(pairs_per_rank, rank):
     return rank * pairs_per_rank
 
 
-def gather_scores(local_scores, dist=None):
-    """All-gather equally sized per-rank score tensors into one tensor in rank (= input) order."""
+def gather_scores(local_scores, dist=None, force=False):
+    """All-gather equally sized per-rank score tensors into one tensor in rank (= input) order. `force`: run the collective
+    even in a group of one rank (bench.py's AIM_BENCH_FORCE_DIST: the RCCL branch on a single-GPU box)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return local_scores.clone()
     world = dist.get_world_size()
     out = torch.empty(world * local_scores.numel(), dtype=local_scores.dtype, device=local_scores.device)
@@ -31,3 +32,40 @@ def gather_scores(local_scores, dist=None):
     else:
         dist.all_gather_into_tensor(out, local_scores)
     return out
+
+
+def gather_cigars(cig, runs, dist=None, force=False):
+    """The CIGAR half of the path's final gather (the reference gathers results + ops rows, host.c:316-327): every rank holds its pairs'
+    compact CIGAR -- `cig` int32 [n, 4] = aim_cigar_t {idx, score, run_offset, n_runs | status << 16} and `runs` int32 [r_rank], r_rank
+    differing per rank -- and receives all ranks' in rank (= input) order: run counts first (one all-gather of a word), then the
+    headers (equal sizes) and the run buffers padded to the longest one (all_gather_into_tensor wants equal sizes; the padding is
+    dropped again), with every rank's run_offset rebased onto the concatenated run buffer.
+    Returns (cig_all [world * n, 4], runs_all [sum r], runs_per_rank list)."""
+    import torch
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return cig.clone(), runs.clone(), [int(runs.numel())]
+    world = dist.get_world_size()
+    gloo = dist.get_backend() == "gloo"
+
+    def all_gather(t):
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if gloo:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            torch.stack(parts, out=out)
+        else:
+            dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1))
+        return out
+
+    counts = all_gather(torch.tensor([runs.numel()], dtype=torch.int64, device=runs.device)).view(-1).tolist()
+    longest = max(max(counts), 1)
+    padded = torch.zeros(longest, dtype=runs.dtype, device=runs.device)
+    padded[: runs.numel()] = runs
+    runs_by_rank = all_gather(padded)
+    cig_by_rank = all_gather(cig)
+    base = 0
+    for r in range(world):
+        cig_by_rank[r, :, 2] += base          # run_offset (values stay below 2^31: a run buffer is at most 2^28 runs per rank)
+        base += counts[r]
+    runs_all = torch.cat([runs_by_rank[r, : counts[r]] for r in range(world)])
+    return cig_by_rank.view(-1, cig.shape[1]), runs_all, counts

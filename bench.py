@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--no-default-io", action="store_true", help="skip the extra default-layout timing (profiling runs: one kernel shape only)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg (reported as `e2e`, never as `value`)")
     ap.add_argument("--verify-pairs", type=int, default=1 << 20, help="pairs re-checked against the CPU oracle after timing")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (RCCL) and run the final gather even at world size 1 (also AIM_BENCH_FORCE_DIST=1): "
+                         "exercises the N > 1 exchange path on a single-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -185,12 +188,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = args.force_dist or os.environ.get("AIM_BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:   # not under torch.distributed.run: a group of this one process
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
         if share:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     from aim_amd import capi, engine, shard
     lib = capi.load()
@@ -237,7 +245,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -251,7 +259,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -280,17 +288,46 @@ def main():
                       "note": "same kernel, default 16-B request / 24-B result structs; not `value`"}
         del d_req2, d_res2
 
-    # final (idx, score) gather to every rank over RCCL/xGMI -- outside the timed region, reported separately
-    gather_ms = None
+    # final score / CIGAR gather to every rank over RCCL/xGMI (host.c:316-327) -- outside the timed region, reported separately
+    gather_ms, gather = None, None
     res_host = np.frombuffer(d_res[: n * res_dtype.itemsize].cpu().numpy().tobytes(), dtype=res_dtype)
-    if world > 1:
+    ops_host = d_ops[: n * 2 * rs].cpu().numpy().reshape(n, 2 * rs) if args.backtrace else None
+    if dist_on:
         scores = torch.from_numpy(np.ascontiguousarray(res_host["score"])).to(dev)
         torch.cuda.synchronize(dev)
         g0 = time.perf_counter()
-        out = shard.gather_scores(scores, dist)
+        out = shard.gather_scores(scores, dist, force=True)
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert bool((out[rank * n:(rank + 1) * n] == scores).all())
+        gather = {"backend": dist.get_backend(), "world": world, "scores_ms": gather_ms, "scores_bytes": int(out.numel() * out.element_size())}
+        if args.backtrace:
+            # with CIGAR the exchange carries the compact form: 16-B aim_cigar_t per pair + its runs, made by the drop-in path
+            # (aim_set_submit with a run buffer) from the rank's own batch; run counts differ per rank (shard.gather_cigars)
+            del d_scratch
+            torch.cuda.empty_cache()
+            runs_cap = min(n * max(8, rs // 4 + 2), 1 << 28)
+            try:
+                with engine.DeviceSet(1, [local_rank]) as s:
+                    s.configure_slots(params, n, slots=1, max_raw=0, max_runs=runs_cap)
+                    s.submit(0, 0, req, pat, txt, cigar_runs_cap=runs_cap)
+                    cg = s.wait(0, 0)
+                cig_d = torch.from_numpy(cg["cig"].view(np.int32).reshape(n, 4).copy()).to(dev)
+                runs_d = torch.from_numpy(cg["runs"].view(np.int32).copy()).to(dev)
+                torch.cuda.synchronize(dev)
+                g0 = time.perf_counter()
+                cig_all, runs_all, counts = shard.gather_cigars(cig_d, runs_d, dist, force=True)
+                torch.cuda.synchronize(dev)
+                cigar_ms = (time.perf_counter() - g0) * 1e3
+                # this rank's slice of what every rank now holds prints like its own ops rows (edit_cigar_print, host.c:69-89)
+                nchk = min(n, 4096)
+                mine = cig_all[rank * n: rank * n + nchk].cpu().numpy().view(np.uint32).reshape(-1).view(capi.CIGAR_DTYPE)
+                same = engine.format_output_runs(mine, runs_all.cpu().numpy().view(np.uint32)) == engine.format_output(res_host[:nchk], ops_host[:nchk], True)
+                gather.update({"cigar_ms": cigar_ms, "cigar_bytes": int(cig_all.numel() * 4 + runs_all.numel() * 4), "runs_per_rank": counts,
+                               "cigar_matches_ops_rows": bool(same)})
+                assert same
+            except capi.AimError as e:   # (a run buffer too small for this configuration's CIGARs: reported, scores were still gathered)
+                gather["cigar_skipped"] = str(e)
 
     # correctness of what was timed: re-check a bounded prefix against the CPU oracle (checker only)
     from oracle import oracle
@@ -300,7 +337,7 @@ def main():
                                         nthreads=os.cpu_count() or 1)
     verified = bool(worst == 0 and np.array_equal(ores["score"], res_host["score"][:nv])
                     and np.array_equal(res_host["idx"], req["idx"]))
-    if world > 1:
+    if dist_on:
         v = torch.tensor([1 if verified else 0], device=dev)
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(int(v[0]))
@@ -384,10 +421,11 @@ def main():
             "default_io": default_io,
             "e2e": e2e,
             "gather_ms": gather_ms,
+            "gather": gather,
             "verified_vs_oracle": verified,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if not verified:

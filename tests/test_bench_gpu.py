@@ -72,3 +72,31 @@ def test_bench_other_baseline_configs_run_through_the_same_harness(built):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["verified_vs_oracle"] is True and d["roofline"]["bound"] == "valu" and d["roofline"]["issue_view"]["frac"] > 0 and d["gather_ms"] is not None
+
+
+def test_bench_rccl_branch_at_world_size_one(built):
+    """the `nccl` (= RCCL) branch of bench.py -- init_process_group(backend="nccl", device_id=...), barrier, the
+    max-over-ranks all_reduce, all_gather_into_tensor of the scores and, with --backtrace, of the compact CIGAR (run counts, headers,
+    padded run buffers: shard.gather_cigars) -- executed on the box's one GPU in a group of one rank under torch.distributed.run."""
+    env = dict(os.environ, AIM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AIM_BENCH_SHARE_GPU", None)
+    for extra, port in ((["--backtrace"], "29741"), ([], "29742")):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pairs", "262144", "--steps", "3",
+                            "--warmup", "1", "--verify-pairs", "32768", "--no-cpu-baseline", "--no-e2e"] + extra,
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        d = _last_json(r.stdout)
+        assert d["n_gpus"] == 1 and d["verified_vs_oracle"] is True and d["gather_ms"] is not None and d["gather_ms"] > 0
+        assert d["gather"]["backend"] == "nccl" and d["gather"]["scores_bytes"] == 4 * 262144
+        if extra:
+            assert d["gather"]["cigar_matches_ops_rows"] is True and d["gather"]["cigar_ms"] > 0
+            assert d["gather"]["cigar_bytes"] >= 16 * 262144 + 4 * d["gather"]["runs_per_rank"][0] > 16 * 262144
+    # cfg3 (wfa_group + traceback kernel, compact CIGAR from the RLE kernel) through the same exchange, two ranks sharing the GPU over gloo
+    env = dict(os.environ, AIM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29743", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3", "--pairs", "2048", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["gather"]["backend"] == "gloo" and d["gather"]["cigar_matches_ops_rows"] is True and len(d["gather"]["runs_per_rank"]) == 2
