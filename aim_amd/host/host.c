@@ -32,6 +32,7 @@
 #define _GNU_SOURCE
 #include <fcntl.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,24 +65,27 @@ static void die_aim(const char *what, int rc)
  * exist so that the parse + pack of batch k+1 and the format + write of batch k-1 run at the same time (the reference's
  * loop is strictly serial, host.c:246-352). A worker that could not be created has its share run inside pool_join. */
 typedef void (*range_fn)(int tid, int nthreads, void *arg);
+struct pool;
+typedef struct { struct pool *p; int tid; } worker_t;
 typedef struct pool {
     pthread_t th[MAX_THREADS];
     int created[MAX_THREADS];
+    worker_t workers[MAX_THREADS];
     int n, pending, stop;
     unsigned long gen;
     range_fn fn;
     void *arg;
+    const cpu_set_t *cpus;   /* workers run on these CPUs (a lane's share of the machine), or NULL */
     pthread_mutex_t mu;
     pthread_cond_t go, idle;
 } pool_t;
-typedef struct { pool_t *p; int tid; } worker_t;
-static worker_t g_workers[2][MAX_THREADS];
 
 static void *pool_worker(void *a)
 {
     worker_t *w = a;
     pool_t *p = w->p;
     unsigned long seen = 0;
+    if (p->cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), p->cpus);
     for (;;) {
         pthread_mutex_lock(&p->mu);
         while (p->gen == seen && !p->stop) pthread_cond_wait(&p->go, &p->mu);
@@ -97,18 +101,19 @@ static void *pool_worker(void *a)
         pthread_mutex_unlock(&p->mu);
     }
 }
-static void pool_init(pool_t *p, int which, int n)
+static void pool_init(pool_t *p, int n, const cpu_set_t *cpus)
 {
     memset(p, 0, sizeof *p);
     if (n < 1) n = 1;
     if (n > MAX_THREADS) n = MAX_THREADS;
     p->n = n;
+    p->cpus = cpus;
     pthread_mutex_init(&p->mu, NULL);
     pthread_cond_init(&p->go, NULL);
     pthread_cond_init(&p->idle, NULL);
     for (int t = 0; t < n; ++t) {
-        g_workers[which][t] = (worker_t){p, t};
-        p->created[t] = pthread_create(&p->th[t], NULL, pool_worker, &g_workers[which][t]) == 0;
+        p->workers[t] = (worker_t){p, t};
+        p->created[t] = pthread_create(&p->th[t], NULL, pool_worker, &p->workers[t]) == 0;
     }
 }
 static void pool_start(pool_t *p, range_fn fn, void *arg)
@@ -139,7 +144,6 @@ static void pool_stop(pool_t *p)
     for (int t = 0; t < p->n; ++t)
         if (p->created[t]) pthread_join(p->th[t], NULL);
 }
-static pool_t g_pack_pool, g_fmt_pool;
 
 /* ---- input: mapped file + line index --------------------------------------------------------------- */
 typedef struct {
@@ -332,21 +336,19 @@ static void pack_range(int tid, int nt, void *arg)
  * on the pack pool and returns (the caller formats the previous batch meanwhile); pack_finish joins it and assembles the raw
  * side list (or falls back to ASCII rows for an unusually dirty batch). */
 static void *(*g_big_alloc)(size_t);
-static pack_t g_pk;
-static void pack_begin(const input_t *inp, job_t2 *j, int read_size, uint32_t max_raw, int no_pack)
+static void pack_begin(pool_t *pool, pack_t *pk, const input_t *inp, job_t2 *j, int read_size, uint32_t max_raw, int no_pack)
 {
-    memset(&g_pk, 0, sizeof g_pk);
-    g_pk.in = inp; g_pk.job = j; g_pk.read_size = read_size; g_pk.max_raw = max_raw; g_pk.pass = 0;
+    memset(pk, 0, sizeof *pk);
+    pk->in = inp; pk->job = j; pk->read_size = read_size; pk->max_raw = max_raw; pk->pass = 0;
     j->ascii = no_pack;
     j->n_raw = 0;
-    pool_start(&g_pack_pool, pack_range, &g_pk);
+    pool_start(pool, pack_range, pk);
 }
-static void pack_finish(job_t2 *j, uint32_t batch)
+static void pack_finish(pool_t *pool, pack_t *pk, job_t2 *j, uint32_t batch)
 {
-    pack_t *pk = &g_pk;
-    const int threads = g_pack_pool.n;
+    const int threads = pool->n;
     const size_t rs = (size_t)pk->read_size;
-    pool_join(&g_pack_pool);
+    pool_join(pool);
     if (j->ascii) return;
     uint32_t total_raw = 0;
     for (int t = 0; t < threads; ++t) { const uint32_t c = pk->raw_count[t + 1]; pk->raw_count[t] = total_raw; total_raw += c; }
@@ -356,11 +358,11 @@ static void pack_finish(job_t2 *j, uint32_t batch)
         if (!j->pat) { j->pat = g_big_alloc((size_t)batch * rs); j->txt = g_big_alloc((size_t)batch * rs); }
         j->ascii = 1;
         pk->pass = 0;
-        pool_run(&g_pack_pool, pack_range, pk);
+        pool_run(pool, pack_range, pk);
         return;
     }
     pk->pass = 1;
-    pool_run(&g_pack_pool, pack_range, pk);
+    pool_run(pool, pack_range, pk);
     j->n_raw = total_raw;
 }
 
@@ -388,10 +390,23 @@ static void copy_range(int tid, int nt, void *arg)
         if (hi > lo) memcpy(cs->it[i].dst + lo, cs->it[i].src + lo, hi - lo);
     }
 }
-static copy_set_t g_cs;
+/* Size of the batch that starts at `at` (0: malformed) -- the walk that finds a packed file's batch boundaries. */
+static size_t packed_batch_bytes(const char *at, size_t left, int req8, int read_size, uint32_t *n_out)
+{
+    if (left < 16) return 0;
+    uint32_t hdr[4];
+    memcpy(hdr, at, 16);
+    const uint32_t n = hdr[0], ascii = hdr[1], n_raw = hdr[2];
+    const size_t rs = (size_t)read_size, dw = (size_t)(read_size + 15) / 16, rq = req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t);
+    if (hdr[3] != (uint32_t)read_size || n_raw > n) return 0;
+    const size_t need = 16 + n * rq + (ascii ? 2 * n * rs : 2 * n * dw * 4 + (size_t)n_raw * (4 + 2 * rs));
+    if (left < need) return 0;
+    *n_out = n;
+    return need;
+}
 /* One batch of a packed file into the job's (pinned) buffers; returns the bytes consumed, 0 on a malformed batch. `take` <= n
  * pairs of it are used (the reference's partition rule may end inside a batch). */
-static size_t packed_begin(const char *at, size_t left, job_t2 *j, int read_size, uint32_t batch, uint32_t max_raw, uint32_t take)
+static size_t packed_begin(pool_t *pool, copy_set_t *cs, const char *at, size_t left, job_t2 *j, int read_size, uint32_t batch, uint32_t max_raw, uint32_t take)
 {
     if (left < 16) return 0;
     uint32_t hdr[4];
@@ -402,7 +417,6 @@ static size_t packed_begin(const char *at, size_t left, job_t2 *j, int read_size
     const size_t need = 16 + n * rq + (ascii ? 2 * n * rs : 2 * n * dw * 4 + (size_t)n_raw * (4 + 2 * rs));
     if (left < need) return 0;
     const char *q = at + 16;
-    copy_set_t *cs = &g_cs;
     cs->n = 0;
     cs->it[cs->n++] = (copy_item_t){q, (char *)j->req, take * rq}; q += n * rq;
     j->ascii = (int)ascii;
@@ -421,7 +435,7 @@ static size_t packed_begin(const char *at, size_t left, job_t2 *j, int read_size
         cs->it[cs->n++] = (copy_item_t){q, j->rawT, (size_t)keep * rs};
         j->n_raw = keep;
     }
-    pool_start(&g_pack_pool, copy_range, cs);
+    pool_start(pool, copy_range, cs);
     return need;
 }
 
@@ -531,7 +545,6 @@ typedef struct {
     char **buf;
     size_t *len, *off;
 } writer_t;
-static writer_t g_writer;
 static void *writer_main(void *arg)
 {
     writer_t *w = arg;
@@ -605,6 +618,260 @@ static void *pinned(size_t bytes)
     return p;
 }
 
+/* ---- lanes ------------------------------------------------------------------------------------------
+ * A LANE is the whole host pipeline -- pack pool, the (device, slot) job ring on its own device set, format pool, one writer,
+ * one output file -- over one contiguous range of the input's pairs. The default is one lane writing <output>: the reference's
+ * contract. `--out-shards K` runs K lanes side by side, lane k writing <output>.00k; `cat <output>.0*` is byte-identical to the
+ * single file. That is what feeds several GPUs: one output file takes ~4-5 GB/s whoever writes it (its inode lock), i.e. ~3e8 pairs/s
+ * score-only, and one lane's stages are sized for one device. Lanes share nothing but the read-only mapped input and its line
+ * index; devices are dealt to lanes round-robin (more lanes than devices: several lanes -- each with its own set -- per device). */
+typedef struct {
+    aim_params_t p;
+    int backtrace, use_req8, no_pack, full_ops, packed_input;
+    uint32_t batch, slots, max_raw, runs_cap;
+    const input_t *inp;
+    const char *in_name, *out_name;
+} cfg_t;
+
+typedef struct lane {
+    int id;
+    const cfg_t *c;
+    /* its share of the input: text = pairs [first_pair, first_pair + n_pairs); packed file = whole batches from byte pk_at */
+    uint64_t first_pair, n_pairs;
+    size_t pk_at;
+    uint64_t n_jobs;
+    /* its devices */
+    int dev_ids[64];
+    uint32_t gpus;
+    aim_set_t *set;
+    /* its threads */
+    int pack_threads, fmt_threads;
+    cpu_set_t cpus;
+    int have_cpus;
+    pool_t pack_pool, fmt_pool;
+    pack_t pk;
+    copy_set_t cs;
+    writer_t writer;
+    fmt_t f;
+    int out_fd;
+    char out_path[4096];
+    pthread_t th;
+    /* what it did */
+    uint64_t done, pairs_first_done;
+    double t_first_done, t_end, t_loop;
+    double parse_ms, write_ms, wait_ms, join_ms, submit_ms, wrwait_ms;
+    float h2d, kern, d2h;
+} lane_t;
+
+static pthread_mutex_t g_say_mu = PTHREAD_MUTEX_INITIALIZER;
+static int g_said_copy, g_said_retrieve;
+static void say_once(int *flag, const char *text)   /* the reference's progress lines, once per run whatever the lane count */
+{
+    pthread_mutex_lock(&g_say_mu);
+    if (!*flag) { fputs(text, stdout); *flag = 1; }
+    pthread_mutex_unlock(&g_say_mu);
+}
+
+static void *lane_main(void *arg)
+{
+    lane_t *L = arg;
+    const cfg_t *c = L->c;
+    const aim_params_t *p = &c->p;
+    const size_t rs = (size_t)p->read_size;
+    const uint32_t dw = (uint32_t)(p->read_size + 15) / 16u;
+    const uint32_t batch = c->batch, slots = c->slots, gpus = L->gpus;
+    const int backtrace = c->backtrace, full_ops = c->full_ops, use_req8 = c->use_req8;
+    int rc;
+    if (L->have_cpus) (void)pthread_setaffinity_np(pthread_self(), sizeof L->cpus, &L->cpus);   /* pinned buffers are first touched here */
+    pool_init(&L->pack_pool, L->pack_threads, L->have_cpus ? &L->cpus : NULL);
+    pool_init(&L->fmt_pool, L->fmt_threads, L->have_cpus ? &L->cpus : NULL);
+    if ((rc = aim_set_alloc(gpus, L->dev_ids, &L->set))) die_aim("aim_set_alloc", rc);
+    rc = aim_set_configure_slots(L->set, p, batch, slots, c->no_pack ? 0 : c->max_raw, c->runs_cap);
+    if (rc) {
+        if (rc == AIM_EINVAL) { printf("%s\n", aim_last_error()); exit(1); }
+        die_aim("aim_set_configure_slots", rc);
+    }
+    const uint32_t ring = gpus * slots;
+    job_t2 *jobs = calloc(ring, sizeof *jobs);
+    for (uint32_t k = 0; k < ring; ++k) {
+        job_t2 *j = &jobs[k];
+        j->device = k % gpus; j->slot = k / gpus;
+        j->req8 = use_req8;
+        j->req = pinned((size_t)batch * (use_req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t)));
+        j->is_raw = plain(batch);
+        if (c->no_pack) { j->pat = pinned((size_t)batch * rs); j->txt = pinned((size_t)batch * rs); }
+        else {
+            j->pkP = pinned((size_t)batch * dw * 4); j->pkT = pinned((size_t)batch * dw * 4);
+            j->raw_idx = pinned((size_t)c->max_raw * 4); j->rawP = pinned((size_t)c->max_raw * rs); j->rawT = pinned((size_t)c->max_raw * rs);
+        }
+        if (!backtrace) j->res8 = pinned((size_t)batch * sizeof(aim_result8_t));
+        else if (full_ops) { j->res = pinned((size_t)batch * sizeof(aim_result_t)); j->ops = pinned((size_t)batch * 2 * rs); }
+        else { j->cig = pinned((size_t)batch * sizeof(aim_cigar_t)); j->runs = pinned((size_t)c->runs_cap * 4); }
+    }
+
+    const uint64_t n_jobs = L->n_jobs;
+    uint64_t sent = 0;
+    size_t out_at = 0, pk_at = L->pk_at;
+    fmt_t *f = &L->f;   /* host.c:331-352; per-thread text buffers live across batches */
+    memset(f, 0, sizeof *f);
+    f->backtrace = backtrace; f->read_size = p->read_size; f->full_ops = full_ops; f->fd = L->out_fd;
+    f->buf = f->bufs[0]; f->cap = f->caps[0]; f->len = f->lens[0]; f->off = f->offs[0];
+    writer_t *W = &L->writer;
+    memset(W, 0, sizeof *W);
+    pthread_mutex_init(&W->mu, NULL);
+    pthread_cond_init(&W->cv, NULL);
+    W->fd = L->out_fd;
+    const char *out_mode = getenv("AIM_HOST_OUT");
+    /* A pipe / FIFO / character device cannot be written at offsets (pwrite: ESPIPE): like the reference's fopen(out, "w") the
+       text then goes out sequentially -- one writer, batches and per-thread buffers in order (ADVICE r03). */
+    int out_seq = 0;
+    {
+        struct stat os;
+        if (fstat(L->out_fd, &os) || !S_ISREG(os.st_mode)) out_seq = 1;
+    }
+    W->seq = f->seq = out_seq;
+    const int out_async = out_seq || !out_mode || !strcmp(out_mode, "async");
+    if (out_async) W->started = pthread_create(&W->th, NULL, writer_main, W) == 0;
+    int out_mmap = !out_seq && out_mode && !strcmp(out_mode, "mmap");   /* A/B switch; see the loop */
+    const int out_serial = out_seq || (out_mode && !strcmp(out_mode, "serial"));   /* one thread writes (also the fallback when no writer thread could be created) */
+    if (out_serial) out_mmap = 0;
+    L->t_loop = now_ms();
+    for (uint64_t it = 0; it < n_jobs + ring; ++it) {
+        job_t2 *j = &jobs[it % ring];
+        const int have_old = j->in_flight;
+        if (have_old) {   /* job it - ring: results are needed now (and its buffers next) */
+            double t0 = now_ms();
+            say_once(&g_said_retrieve, "Retrieve results\n");
+            rc = aim_set_wait(L->set, j->device, j->slot, &j->n_runs);
+            if (rc == AIM_ENOMEM && j->cig && !j->use_full) {
+                /* more runs than READ_SIZE/4 + 2 per pair on average (e.g. SWG with MAX_SCORE as +infinity on dissimilar reads):
+                   run this batch again and gather result_t + ops rows like the reference (host.c:316-326); the inputs are
+                   still in the job's buffers */
+                if (!j->res) { j->res = pinned((size_t)batch * sizeof(aim_result_t)); j->ops = pinned((size_t)batch * 2 * rs); }
+                j->io.cigars = NULL; j->io.runs = NULL; j->io.runs_cap = 0;
+                j->io.results = j->res; j->io.ops = j->ops;
+                j->use_full = 1;
+                if ((rc = aim_set_submit(L->set, j->device, j->slot, &j->io))) die_aim("aim_set_submit", rc);
+                rc = aim_set_wait(L->set, j->device, j->slot, NULL);
+            }
+            if (rc == AIM_EALIGN) { /* the reference prints from the DPU and exits 1 */
+                const char *msg = strstr(aim_last_error(), "(");
+                pthread_mutex_lock(&g_say_mu);   /* (held: one lane prints, the process ends) */
+                printf("%s\n", msg ? msg + 1 : aim_last_error());
+                exit(1);
+            }
+            if (rc) die_aim("aim_set_wait", rc);
+            L->wait_ms += now_ms() - t0;
+            f->job = j; f->n = j->n; f->use_full = j->use_full;
+            j->in_flight = 0;
+        }
+        /* the device is done with this job's input buffers: the next batch's parse + pack starts on the pack pool ... */
+        const int have_new = it < n_jobs;
+        double t_pack = now_ms();
+        if (have_new) {
+            const uint64_t left = L->n_pairs - sent;
+            j->n = left < batch ? (uint32_t)left : batch;
+            j->first_pair = (size_t)(L->first_pair + sent);
+            if (c->packed_input) {
+                uint32_t in_file = 0;
+                if (c->inp->size - pk_at >= 16) memcpy(&in_file, c->inp->data + pk_at, 4);
+                if (j->n > in_file) j->n = in_file;          /* batches are taken as the file holds them */
+                const size_t used = packed_begin(&L->pack_pool, &L->cs, c->inp->data + pk_at, c->inp->size - pk_at, j, p->read_size, batch, c->max_raw, j->n);
+                if (!used || j->n == 0) { fprintf(stderr, "'%s': malformed packed batch at byte %zu\n", c->in_name, pk_at); exit(1); }
+                pk_at += used;
+            } else {
+                pack_begin(&L->pack_pool, &L->pk, c->inp, j, p->read_size, c->max_raw, c->no_pack);
+            }
+        }
+        /* ... while the format pool prints the previous batch of this job (host.c:331-352) and writes it */
+        if (have_old) {
+            double t0 = now_ms();
+            pool_run(&L->fmt_pool, format_range, f);
+            const size_t batch_at = out_at;
+            for (int t = 0; t < L->fmt_pool.n; ++t) { f->off[t] = out_at; out_at += f->len[t]; }
+            if (W->started) {   /* hand the printed batch to the writer; the next one is printed into the other buffer set */
+                const double tw = now_ms();
+                writer_submit(W, L->fmt_pool.n, f->buf, f->len, f->off);
+                L->wrwait_ms += now_ms() - tw;
+                if (W->failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", L->out_path); exit(1); }
+                f->set ^= 1;
+                f->buf = f->bufs[f->set]; f->cap = f->caps[f->set]; f->len = f->lens[f->set]; f->off = f->offs[f->set];
+            } else {
+            /* Writes to one file serialise on its inode lock (measured: 2.5 GB/s however many threads call pwrite, and the output
+               is 14-22 bytes per pair); a shared mapping of the batch's window lets all threads fill the page cache at once.
+               Falls back to pwrite where the file cannot be extended / mapped; no regular file at all (pipes): out_seq above. */
+            f->map = NULL;
+            if (out_mmap && out_at > batch_at && ftruncate(L->out_fd, (off_t)out_at) == 0) {
+                const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+                f->map_base = batch_at / pg * pg;
+                void *m = mmap(NULL, out_at - f->map_base, PROT_READ | PROT_WRITE, MAP_SHARED, L->out_fd, (off_t)f->map_base);
+                if (m != MAP_FAILED) f->map = m; else out_mmap = 0;
+            } else if (out_mmap && out_at > batch_at) out_mmap = 0;
+            if (out_serial) { for (int t = 0; t < L->fmt_pool.n; ++t) write_range(t, L->fmt_pool.n, f); }
+            else pool_run(&L->fmt_pool, write_range, f);
+            if (f->map) { munmap(f->map, out_at - f->map_base); f->map = NULL; }
+            }
+            if (f->failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", L->out_path); exit(1); }
+            L->write_ms += now_ms() - t0;
+            L->done += f->n;
+            if (!L->pairs_first_done) { L->pairs_first_done = L->done; L->t_first_done = now_ms(); }
+        }
+        if (have_new) {
+            const double tj = now_ms();
+            if (c->packed_input) pool_join(&L->pack_pool);
+            else pack_finish(&L->pack_pool, &L->pk, j, batch);
+            L->join_ms += now_ms() - tj;                   /* what the pack still needed after the format stage was done */
+            L->parse_ms += now_ms() - t_pack;              /* (overlaps the format + write above) */
+            say_once(&g_said_copy, "Copying data to DPU\nRun program on DPU(s)\n");
+            aim_batch_io_t io;
+            memset(&io, 0, sizeof io);
+            io.n_pairs = j->n;
+            io.requests = j->req;
+            if (j->ascii) { io.patterns = j->pat; io.texts = j->txt; }
+            else {
+                io.packed_patterns = j->pkP; io.packed_texts = j->pkT;
+                io.n_raw = j->n_raw; io.raw_pairs = j->raw_idx; io.raw_patterns = j->rawP; io.raw_texts = j->rawT;
+            }
+            if (!backtrace) io.results = j->res8;
+            else if (full_ops) { io.results = j->res; io.ops = j->ops; }
+            else { io.cigars = j->cig; io.runs = j->runs; io.runs_cap = c->runs_cap; }
+            j->io = io;
+            j->use_full = 0;
+            const double ts = now_ms();
+            if ((rc = aim_set_submit(L->set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
+            L->submit_ms += now_ms() - ts;
+            j->in_flight = 1;
+            sent += j->n;
+            if (c->packed_input && sent < L->n_pairs && it + 1 == n_jobs) { fprintf(stderr, "'%s': fewer pairs than its header states\n", c->in_name); exit(1); }
+        }
+    }
+    if (W->started) {
+        writer_wait_idle(W);
+        pthread_mutex_lock(&W->mu);
+        W->stop = 1;
+        pthread_cond_broadcast(&W->cv);
+        pthread_mutex_unlock(&W->mu);
+        pthread_join(W->th, NULL);
+        if (W->failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", L->out_path); exit(1); }
+    }
+    L->t_end = now_ms();
+    aim_set_timers(L->set, &L->h2d, &L->kern, &L->d2h);
+    pool_stop(&L->pack_pool);
+    pool_stop(&L->fmt_pool);
+    for (int t = 0; t < MAX_THREADS; ++t) { free(f->bufs[0][t]); free(f->bufs[1][t]); }
+    for (uint32_t k = 0; k < ring; ++k) {
+        job_t2 *j = &jobs[k];
+        void *bufs[] = {j->req, j->pkP, j->pkT, j->raw_idx, j->rawP, j->rawT, j->pat, j->txt, j->res8, j->cig, j->runs, j->res, j->ops};
+        for (size_t b = 0; b < sizeof bufs / sizeof bufs[0]; ++b)
+            if (bufs[b]) aim_host_free(bufs[b]);
+        free(j->is_raw);
+    }
+    free(jobs);
+    aim_set_free(L->set);
+    if (close(L->out_fd)) { fprintf(stderr, "Output file '%s' couldn't be written\n", L->out_path); exit(1); }
+    return NULL;
+}
+
 int main(int argc, char *argv[])
 {
     if (argc < 4) {
@@ -615,17 +882,18 @@ int main(int argc, char *argv[])
     const long n_arg = atol(argv[3]);            /* signed: a negative count is "Invalid nb of reads", not 4 billion */
 
     /* defaults = the reference's common.h defaults for WFA (common.h:63-89), READ_SIZE rounded to 8 */
+    static cfg_t cfg;
     aim_params_t p;
     memset(&p, 0, sizeof p);
     p.algo = AIM_ALGO_WFA;
     p.match = 0; p.mismatch = 3; p.gap_o = 4; p.gap_e = 1; p.gap_i = 4; p.gap_d = 4;
     p.max_score = 250; p.read_size = 112;
-    uint32_t nr_dpus = 1, gpus = 1, batch = 4u << 20, slots = 2;
-    int no_pack = 0, full_ops = 0, packed_input = 0;
+    uint32_t nr_dpus = 1, gpus = 1, batch = 4u << 20, slots = 2, shards = 0;
+    int no_pack = 0, full_ops = 0, packed_input = 0, pin = -1;
     const char *pack_only = NULL;   /* write the packed batches to this file and exit (no GPU is touched) */
     int dev_ids[64], n_dev_ids = 0; /* --device-ids a,b,c: physical device of every set member (tests put one GPU in twice) */
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    int threads = (int)(ncpu < 1 ? 1 : (ncpu > 48 ? 48 : ncpu));   /* measured on a 256-thread host (13.7 GB of text): 32 + 16 beats 64, 128 (1.8x slower) and 256 (3x) */
+    int threads = 0;
     int pack_threads_arg = 0, fmt_threads_arg = 0;
     for (int i = 4; i < argc; ++i) {
         const char *f = argv[i];
@@ -636,6 +904,8 @@ int main(int argc, char *argv[])
         else if (!strcmp(f, "--no-pack")) no_pack = 1;       /* ship ASCII rows like the reference (host.c:258-268) */
         else if (!strcmp(f, "--full-ops")) full_ops = 1;     /* gather result_t + ops rows like the reference (host.c:316-326) */
         else if (!strcmp(f, "--packed-input")) packed_input = 1;
+        else if (!strcmp(f, "--pin")) pin = 1;               /* every lane's threads on its own contiguous share of the CPUs */
+        else if (!strcmp(f, "--no-pin")) pin = 0;
         else if (!v) { printf("wrong number of arguments\n"); exit(1); }
         else if (!strcmp(f, "--pack-only")) { pack_only = v; ++i; }
         else if (!strcmp(f, "--device-ids")) {
@@ -665,7 +935,18 @@ int main(int argc, char *argv[])
         else if (!strcmp(f, "--threads")) { threads = atoi(v); ++i; }
         else if (!strcmp(f, "--pack-threads")) { pack_threads_arg = atoi(v); ++i; }
         else if (!strcmp(f, "--format-threads")) { fmt_threads_arg = atoi(v); ++i; }
+        else if (!strcmp(f, "--out-shards")) { shards = (uint32_t)atoi(v); ++i; }
         else { fprintf(stderr, "unknown flag %s\n", f); exit(1); }
+    }
+    if (shards > 64) { fprintf(stderr, "--out-shards 1..64\n"); exit(1); }
+    const uint32_t n_lanes = shards ? shards : 1;
+    /* threads: per lane 48 at most (measured on a 256-thread host, 13.7 GB of text: 32 + 16 beats 64, 128 and 256 within ONE lane),
+       all lanes together no more than the machine has */
+    if (threads <= 0) {
+        long per = ncpu < 1 ? 1 : ncpu / (long)n_lanes;
+        if (per > 48) per = 48;
+        if (per < 3) per = 3;
+        threads = (int)(per * n_lanes);
     }
     if (threads < 1) threads = 1;
     if (threads > MAX_THREADS) threads = MAX_THREADS;
@@ -679,18 +960,27 @@ int main(int argc, char *argv[])
 #endif
 
     int fd = open(in, O_RDONLY);
-    int out_fd = open(out, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    /* one output file, or with --out-shards K the K files <output>.000 ... (cat in that order = the single file) */
+    static lane_t *lanes;
+    lanes = calloc(n_lanes, sizeof *lanes);
+    if (!lanes) { fprintf(stderr, "out of host memory\n"); exit(1); }
+    int out_bad = 0;
+    for (uint32_t k = 0; k < n_lanes; ++k) {
+        lane_t *L = &lanes[k];
+        L->id = (int)k; L->c = &cfg;
+        if (shards) snprintf(L->out_path, sizeof L->out_path, "%s.%03u", out, k);
+        else snprintf(L->out_path, sizeof L->out_path, "%s", out);
+        L->out_fd = open(L->out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (L->out_fd < 0) out_bad = 1;
+    }
     FILE *dpu_file = fopen("dpu-out", "w"); /* host.c:162: kept (empty) for scripts that expect it */
     if (fd < 0) { fprintf(stderr, "Input file '%s' couldn't be opened\n", in); exit(1); }
-    if (out_fd < 0) { fprintf(stderr, "Output file '%s' couldn't be opened\n", out); exit(1); }
+    if (out_bad) { fprintf(stderr, "Output file '%s' couldn't be opened\n", out); exit(1); }
     if (n_arg <= 0 || n_arg > 0x7fffffffL) { fprintf(stderr, "Invalid nb of reads\n"); exit(1); }
     const uint32_t total_nb_reads = (uint32_t)n_arg;
     if (nr_dpus == 0 || total_nb_reads <= nr_dpus) { printf("Allocated DPUs more than needed\n"); exit(1); }
-    if (gpus == 0 || batch == 0 || slots == 0 || slots > 4) { fprintf(stderr, "--gpus, --batch must be positive, --slots 1..4\n"); exit(1); }
+    if (gpus == 0 || gpus > 64 || batch == 0 || slots == 0 || slots > 4) { fprintf(stderr, "--gpus 1..64, --batch must be positive, --slots 1..4\n"); exit(1); }
 
-    aim_set_t *set = NULL;
-    int rc = pack_only ? 0 : aim_set_alloc(gpus, n_dev_ids ? dev_ids : NULL, &set);
-    if (rc) die_aim("aim_set_alloc", rc);
     g_big_alloc = pack_only ? plain : pinned;
     printf("Allocated %d DPU(s)\n", (int)nr_dpus);
     printf("AIM-HIP: %u MI355X device(s), kernel %s, %d host thread(s)\n", gpus, aim_kernel_name(&p), threads);
@@ -699,16 +989,20 @@ int main(int argc, char *argv[])
     printf("NumReads per dpu = %u\n", nb_reads_per_dpu);
     const uint64_t pair_cap = (uint64_t)nb_reads_per_dpu * nr_dpus; /* H3: what the reference would consume */
 
-    /* two pools: parse + pack of the next batch || format + write of the previous one */
-    int fmt_threads = threads >= 3 ? threads / 3 : 1, pack_threads = threads >= 3 ? threads - fmt_threads : threads;   /* 32 + 16 of 48: on one box 3.3-3.5e8 pairs/s against 2.8-3.3e8 for 28 + 20 and 3.1-3.2e8 for 24 + 24 */
+    /* per lane, two pools: parse + pack of the next batch || format + write of the previous one. The index pool (all threads) maps
+       and indexes the input once for all lanes. */
+    const int lane_threads = threads / (int)n_lanes > 0 ? threads / (int)n_lanes : 1;
+    int fmt_threads = lane_threads >= 3 ? lane_threads / 3 : 1, pack_threads = lane_threads >= 3 ? lane_threads - fmt_threads : lane_threads;   /* 32 + 16 of 48: on one box 3.3-3.5e8 pairs/s against 2.8-3.3e8 for 28 + 20 and 3.1-3.2e8 for 24 + 24 */
     if (pack_threads_arg > 0) pack_threads = pack_threads_arg;
     if (fmt_threads_arg > 0) fmt_threads = fmt_threads_arg;
-    pool_init(&g_pack_pool, 0, pack_threads);
-    pool_init(&g_fmt_pool, 1, fmt_threads);
+    static pool_t idx_pool;
+    int idx_threads = pack_threads * (int)n_lanes;
+    if (idx_threads > MAX_THREADS) idx_threads = MAX_THREADS;
+    pool_init(&idx_pool, idx_threads, NULL);
 
     /* map the input; text: index its lines (replaces the getline loop) and validate; packed file: read the header */
     double t_index = now_ms();
-    input_t inp;
+    static input_t inp;
     memset(&inp, 0, sizeof inp);
     struct stat st;
     if (fstat(fd, &st)) { fprintf(stderr, "Input file '%s' couldn't be opened\n", in); exit(1); }
@@ -735,25 +1029,25 @@ int main(int argc, char *argv[])
         pk_at = sizeof fh;
     } else {
         inp.populate = !(getenv("AIM_HOST_POPULATE") && !strcmp(getenv("AIM_HOST_POPULATE"), "0"));
-        index_lines(&inp, &g_pack_pool);
+        index_lines(&inp, &idx_pool);
         index_ms = now_ms() - t_index;
         uint64_t pairs_in_file = inp.n_lines / 2;   /* a trailing unpaired line ends the reference's loop as well */
         total_pairs = pairs_in_file < pair_cap ? pairs_in_file : pair_cap;
         /* validate every pair the run will touch before the first launch */
         scan_t sc = {&inp, (size_t)total_pairs, p.read_size, 0, 0};
-        pool_run(&g_pack_pool, scan_range, &sc);
+        pool_run(&idx_pool, scan_range, &sc);
         if (sc.too_long) { /* host.c:119-123 */
             printf("READ LENGTH less than length of the input reads");
             exit(0);
         }
         if (sc.malformed) { fprintf(stderr, "malformed input (a line shorter than 2 characters)\n"); exit(1); }
     }
-    double parse_ms = now_ms() - t_index, write_ms = 0, wait_ms = 0, join_ms = 0, submit_ms = 0, wrwait_ms = 0;
+    const double setup_ms = now_ms() - t_index;
 
-    /* batches: enough of them to keep every (device, slot) busy, none larger than --batch */
-    const uint32_t ring = gpus * slots;
+    /* batches: enough of them to keep every (device, slot) of every lane busy, none larger than --batch */
+    const uint32_t ring_all = (gpus > n_lanes ? gpus : n_lanes) * slots;
     if (!packed_input) {
-        uint64_t want = (total_pairs + 2 * ring - 1) / (2 * ring);
+        uint64_t want = (total_pairs + 2 * ring_all - 1) / (2 * ring_all);
         if (want < 65536) want = 65536;
         if (want < batch) batch = (uint32_t)want;
         if ((uint64_t)batch > total_pairs) batch = (uint32_t)(total_pairs ? total_pairs : 1);
@@ -773,29 +1067,18 @@ int main(int argc, char *argv[])
     }
     const uint32_t runs_cap = (backtrace && !full_ops) ? (uint32_t)((uint64_t)batch * rpp > 0xffffffffull ? 0xffffffffu : batch * rpp) : 0;
     const uint32_t max_raw = no_pack ? 0 : (batch / 16 < 1024 ? (batch < 1024 ? batch : 1024) : batch / 16);
-    rc = pack_only ? 0 : aim_set_configure_slots(set, &p, batch, slots, no_pack ? 0 : max_raw, runs_cap);
-    if (rc) {
-        if (rc == AIM_EINVAL) { printf("%s\n", aim_last_error()); exit(1); }
-        die_aim("aim_set_configure_slots", rc);
-    }
-    job_t2 *jobs = calloc(ring, sizeof *jobs);
-    for (uint32_t k = 0; k < ring; ++k) {
-        job_t2 *j = &jobs[k];
-        j->device = k % gpus; j->slot = k / gpus;
-        j->req8 = use_req8;
-        j->req = g_big_alloc((size_t)batch * (use_req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t)));
-        j->is_raw = plain(batch);
-        if (no_pack) { j->pat = g_big_alloc((size_t)batch * rs); j->txt = g_big_alloc((size_t)batch * rs); }
-        else {
-            j->pkP = g_big_alloc((size_t)batch * dw * 4); j->pkT = g_big_alloc((size_t)batch * dw * 4);
-            j->raw_idx = g_big_alloc((size_t)max_raw * 4); j->rawP = g_big_alloc((size_t)max_raw * rs); j->rawT = g_big_alloc((size_t)max_raw * rs);
-        }
-        if (pack_only) continue;
-        if (!backtrace) j->res8 = pinned((size_t)batch * sizeof(aim_result8_t));
-        else if (full_ops) { j->res = pinned((size_t)batch * sizeof(aim_result_t)); j->ops = pinned((size_t)batch * 2 * rs); }
-        else { j->cig = pinned((size_t)batch * sizeof(aim_cigar_t)); j->runs = pinned((size_t)runs_cap * 4); }
-    }
     if (pack_only) {   /* a packed batch file: header, then per batch {n, ascii, n_raw, read_size} + the arrays the device would receive */
+        job_t2 job, *j = &job;
+        memset(j, 0, sizeof *j);
+        j->req8 = use_req8;
+        j->req = plain((size_t)batch * (use_req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t)));
+        j->is_raw = plain(batch);
+        if (no_pack) { j->pat = plain((size_t)batch * rs); j->txt = plain((size_t)batch * rs); }
+        else {
+            j->pkP = plain((size_t)batch * dw * 4); j->pkT = plain((size_t)batch * dw * 4);
+            j->raw_idx = plain((size_t)max_raw * 4); j->rawP = plain((size_t)max_raw * rs); j->rawT = plain((size_t)max_raw * rs);
+        }
+        static pack_t pk;
         FILE *df = fopen(pack_only, "wb");
         if (!df) { fprintf(stderr, "cannot write %s\n", pack_only); exit(1); }
         pkfile_hdr_t fh;
@@ -804,12 +1087,11 @@ int main(int argc, char *argv[])
         fh.version = 1; fh.read_size = (uint32_t)p.read_size; fh.req_bytes = use_req8 ? 8u : 16u; fh.batch_pairs = batch; fh.total_pairs = total_pairs;
         fwrite(&fh, sizeof fh, 1, df);
         uint64_t at = 0;
-        job_t2 *j = &jobs[0];
         while (at < total_pairs) {
             j->n = total_pairs - at < batch ? (uint32_t)(total_pairs - at) : batch;
             j->first_pair = (size_t)at;
-            pack_begin(&inp, j, p.read_size, max_raw, no_pack);
-            pack_finish(j, batch);
+            pack_begin(&idx_pool, &pk, &inp, j, p.read_size, max_raw, no_pack);
+            pack_finish(&idx_pool, &pk, j, batch);
             uint32_t hdr[4] = {j->n, (uint32_t)j->ascii, j->n_raw, (uint32_t)p.read_size};
             fwrite(hdr, 4, 4, df);
             fwrite(j->req, j->req8 ? sizeof(aim_request8_t) : sizeof(aim_request_t), j->n, df);
@@ -824,183 +1106,116 @@ int main(int argc, char *argv[])
         printf("AIM-HIP: packed %llu pairs, batch %u, max_raw %u\n", (unsigned long long)total_pairs, batch, max_raw);
         return 0;
     }
+    pool_stop(&idx_pool);   /* the lanes bring their own threads */
 
+    cfg.p = p; cfg.backtrace = backtrace; cfg.use_req8 = use_req8; cfg.no_pack = no_pack; cfg.full_ops = full_ops; cfg.packed_input = packed_input;
+    cfg.batch = batch; cfg.slots = slots; cfg.max_raw = max_raw; cfg.runs_cap = runs_cap; cfg.inp = &inp; cfg.in_name = in; cfg.out_name = out;
+
+    /* deal the input and the devices to the lanes: lane k takes the k-th contiguous run of whole batches */
     const uint64_t n_jobs = (total_pairs + batch - 1) / batch;
-    uint64_t sent = 0, done = 0;
-    size_t out_at = 0;
-    int first = 1;
-    static fmt_t f;   /* host.c:331-352; per-thread text buffers live across batches */
-    memset(&f, 0, sizeof f);
-    f.backtrace = backtrace; f.read_size = p.read_size; f.full_ops = full_ops; f.fd = out_fd;
-    f.buf = f.bufs[0]; f.cap = f.caps[0]; f.len = f.lens[0]; f.off = f.offs[0];
-    memset(&g_writer, 0, sizeof g_writer);
-    pthread_mutex_init(&g_writer.mu, NULL);
-    pthread_cond_init(&g_writer.cv, NULL);
-    g_writer.fd = out_fd;
-    const char *out_mode = getenv("AIM_HOST_OUT");
-    /* A pipe / FIFO / character device cannot be written at offsets (pwrite: ESPIPE): like the reference's fopen(out, "w") the
-       text then goes out sequentially -- one writer, batches and per-thread buffers in order (ADVICE r03). */
-    int out_seq = 0;
     {
-        struct stat os;
-        if (fstat(out_fd, &os) || !S_ISREG(os.st_mode)) out_seq = 1;
+        size_t at = pk_at;
+        uint64_t pairs_at = 0;
+        for (uint32_t k = 0; k < n_lanes; ++k) {
+            lane_t *L = &lanes[k];
+            const uint64_t j0 = n_jobs * k / n_lanes, j1 = n_jobs * (k + 1) / n_lanes;
+            L->n_jobs = j1 - j0;
+            L->first_pair = pairs_at;
+            L->pk_at = at;
+            if (packed_input) {   /* batches are taken as the file holds them: walk this lane's headers */
+                uint64_t got = 0;
+                for (uint64_t b = j0; b < j1; ++b) {
+                    uint32_t nb = 0;
+                    const size_t used = packed_batch_bytes(inp.data + at, inp.size - at, use_req8, p.read_size, &nb);
+                    if (!used || nb == 0 || nb > batch) { fprintf(stderr, "'%s': malformed packed batch at byte %zu\n", in, at); exit(1); }
+                    at += used;
+                    got += nb;
+                }
+                if (pairs_at + got > total_pairs) got = total_pairs - pairs_at;   /* the partition rule may end inside the last batch */
+                L->n_pairs = got;
+            } else {
+                const uint64_t lo = j0 * batch, hi = j1 * batch < total_pairs ? j1 * batch : total_pairs;
+                L->n_pairs = hi > lo ? hi - lo : 0;
+            }
+            pairs_at += L->n_pairs;
+            /* devices: round-robin over the lanes; more lanes than devices: lane k shares device k % gpus (a set of its own) */
+            L->gpus = 0;
+            if (n_lanes <= gpus) {
+                for (uint32_t g = k; g < gpus; g += n_lanes) L->dev_ids[L->gpus++] = n_dev_ids ? dev_ids[g] : (int)g;
+            } else {
+                L->gpus = 1;
+                L->dev_ids[0] = n_dev_ids ? dev_ids[k % gpus] : (int)(k % gpus);
+            }
+            L->pack_threads = pack_threads; L->fmt_threads = fmt_threads;
+        }
+        if (packed_input && pairs_at < total_pairs) { fprintf(stderr, "'%s': fewer pairs than its header states\n", in); exit(1); }
     }
-    g_writer.seq = f.seq = out_seq;
-    const int out_async = out_seq || !out_mode || !strcmp(out_mode, "async");
-    if (out_async) g_writer.started = pthread_create(&g_writer.th, NULL, writer_main, &g_writer) == 0;
-    int out_mmap = !out_seq && out_mode && !strcmp(out_mode, "mmap");   /* A/B switch; see the loop */
-    const int out_serial = out_seq || (out_mode && !strcmp(out_mode, "serial"));   /* one thread writes (also the fallback when no writer thread could be created) */
-    if (out_serial) out_mmap = 0;
+    /* CPU placement (--pin; default on with several lanes): lane k's threads stay on the k-th contiguous share of the CPUs this
+       process may use, so a lane's pinned buffers, its text buffers and the threads that fill them share a socket / NUMA node */
+    if (pin < 0) pin = n_lanes > 1;
+    if (pin) {
+        cpu_set_t all;
+        CPU_ZERO(&all);
+        if (sched_getaffinity(0, sizeof all, &all) == 0) {
+            int ids[CPU_SETSIZE], n = 0;
+            for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu) if (CPU_ISSET(cpu, &all)) ids[n++] = cpu;
+            if (n >= (int)n_lanes)
+                for (uint32_t k = 0; k < n_lanes; ++k) {
+                    lane_t *L = &lanes[k];
+                    CPU_ZERO(&L->cpus);
+                    for (int q = (int)((long)n * k / n_lanes); q < (int)((long)n * (k + 1) / n_lanes); ++q) CPU_SET(ids[q], &L->cpus);
+                    L->have_cpus = 1;
+                }
+        }
+    }
     const double t_loop = now_ms();
-    double t_first_done = 0;
-    uint64_t pairs_first_done = 0;
-    for (uint64_t it = 0; it < n_jobs + ring; ++it) {
-        job_t2 *j = &jobs[it % ring];
-        const int have_old = j->in_flight;
-        if (have_old) {   /* job it - ring: results are needed now (and its buffers next) */
-            double t0 = now_ms();
-            if (first) printf("Retrieve results\n");
-            first = 0;
-            rc = aim_set_wait(set, j->device, j->slot, &j->n_runs);
-            if (rc == AIM_ENOMEM && j->cig && !j->use_full) {
-                /* more runs than READ_SIZE/4 + 2 per pair on average (e.g. SWG with MAX_SCORE as +infinity on dissimilar reads):
-                   run this batch again and gather result_t + ops rows like the reference (host.c:316-326); the inputs are
-                   still in the job's buffers */
-                if (!j->res) { j->res = pinned((size_t)batch * sizeof(aim_result_t)); j->ops = pinned((size_t)batch * 2 * rs); }
-                j->io.cigars = NULL; j->io.runs = NULL; j->io.runs_cap = 0;
-                j->io.results = j->res; j->io.ops = j->ops;
-                j->use_full = 1;
-                if ((rc = aim_set_submit(set, j->device, j->slot, &j->io))) die_aim("aim_set_submit", rc);
-                rc = aim_set_wait(set, j->device, j->slot, NULL);
-            }
-            if (rc == AIM_EALIGN) { /* the reference prints from the DPU and exits 1 */
-                const char *msg = strstr(aim_last_error(), "(");
-                printf("%s\n", msg ? msg + 1 : aim_last_error());
-                exit(1);
-            }
-            if (rc) die_aim("aim_set_wait", rc);
-            wait_ms += now_ms() - t0;
-            f.job = j; f.n = j->n; f.use_full = j->use_full;
-            j->in_flight = 0;
-        }
-        /* the device is done with this job's input buffers: the next batch's parse + pack starts on the pack pool ... */
-        const int have_new = it < n_jobs;
-        double t_pack = now_ms();
-        if (have_new) {
-            const uint64_t left = total_pairs - sent;
-            j->n = left < batch ? (uint32_t)left : batch;
-            j->first_pair = (size_t)sent;
-            if (packed_input) {
-                uint32_t in_file = 0;
-                if (inp.size - pk_at >= 16) memcpy(&in_file, inp.data + pk_at, 4);
-                if (j->n > in_file) j->n = in_file;          /* batches are taken as the file holds them */
-                const size_t used = packed_begin(inp.data + pk_at, inp.size - pk_at, j, p.read_size, batch, max_raw, j->n);
-                if (!used || j->n == 0) { fprintf(stderr, "'%s': malformed packed batch at byte %zu\n", in, pk_at); exit(1); }
-                pk_at += used;
-            } else {
-                pack_begin(&inp, j, p.read_size, max_raw, no_pack);
-            }
-        }
-        /* ... while the format pool prints the previous batch of this job (host.c:331-352) and writes it */
-        if (have_old) {
-            double t0 = now_ms();
-            pool_run(&g_fmt_pool, format_range, &f);
-            const size_t batch_at = out_at;
-            for (int t = 0; t < g_fmt_pool.n; ++t) { f.off[t] = out_at; out_at += f.len[t]; }
-            if (g_writer.started) {   /* hand the printed batch to the writer; the next one is printed into the other buffer set */
-                const double tw = now_ms();
-                writer_submit(&g_writer, g_fmt_pool.n, f.buf, f.len, f.off);
-                wrwait_ms += now_ms() - tw;
-                if (g_writer.failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", out); return 1; }
-                f.set ^= 1;
-                f.buf = f.bufs[f.set]; f.cap = f.caps[f.set]; f.len = f.lens[f.set]; f.off = f.offs[f.set];
-            } else {
-            /* Writes to one file serialise on its inode lock (measured: 2.5 GB/s however many threads call pwrite, and the output
-               is 14-22 bytes per pair); a shared mapping of the batch's window lets all threads fill the page cache at once.
-               Falls back to pwrite where the file cannot be extended / mapped; no regular file at all (pipes): out_seq above. */
-            f.map = NULL;
-            if (out_mmap && out_at > batch_at && ftruncate(out_fd, (off_t)out_at) == 0) {
-                const size_t pg = (size_t)sysconf(_SC_PAGESIZE);
-                f.map_base = batch_at / pg * pg;
-                void *m = mmap(NULL, out_at - f.map_base, PROT_READ | PROT_WRITE, MAP_SHARED, out_fd, (off_t)f.map_base);
-                if (m != MAP_FAILED) f.map = m; else out_mmap = 0;
-            } else if (out_mmap && out_at > batch_at) out_mmap = 0;
-            if (out_serial) { for (int t = 0; t < g_fmt_pool.n; ++t) write_range(t, g_fmt_pool.n, &f); }
-            else pool_run(&g_fmt_pool, write_range, &f);
-            if (f.map) { munmap(f.map, out_at - f.map_base); f.map = NULL; }
-            }
-            if (f.failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", out); return 1; }
-            write_ms += now_ms() - t0;
-            done += f.n;
-            if (!pairs_first_done) { pairs_first_done = done; t_first_done = now_ms(); }
-        }
-        if (have_new) {
-            const double tj = now_ms();
-            if (packed_input) pool_join(&g_pack_pool);
-            else pack_finish(j, batch);
-            join_ms += now_ms() - tj;                      /* what the pack still needed after the format stage was done */
-            parse_ms += now_ms() - t_pack;                 /* (overlaps the format + write above) */
-            if (it == 0) { printf("Copying data to DPU\n"); printf("Run program on DPU(s)\n"); }
-            aim_batch_io_t io;
-            memset(&io, 0, sizeof io);
-            io.n_pairs = j->n;
-            io.requests = j->req;
-            if (j->ascii) { io.patterns = j->pat; io.texts = j->txt; }
-            else {
-                io.packed_patterns = j->pkP; io.packed_texts = j->pkT;
-                io.n_raw = j->n_raw; io.raw_pairs = j->raw_idx; io.raw_patterns = j->rawP; io.raw_texts = j->rawT;
-            }
-            if (!backtrace) io.results = j->res8;
-            else if (full_ops) { io.results = j->res; io.ops = j->ops; }
-            else { io.cigars = j->cig; io.runs = j->runs; io.runs_cap = runs_cap; }
-            j->io = io;
-            j->use_full = 0;
-            const double ts = now_ms();
-            if ((rc = aim_set_submit(set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
-            submit_ms += now_ms() - ts;
-            j->in_flight = 1;
-            sent += j->n;
-            if (packed_input && sent < total_pairs && it + 1 == n_jobs) { fprintf(stderr, "'%s': fewer pairs than its header states\n", in); exit(1); }
-        }
+    uint32_t started = 0;
+    for (uint32_t k = 0; k < n_lanes; ++k) {
+        lane_t *L = &lanes[k];
+        if (L->n_jobs == 0) { close(L->out_fd); continue; }   /* (an empty shard file) */
+        if (n_lanes == 1) lane_main(L);
+        else if (pthread_create(&L->th, NULL, lane_main, L)) { fprintf(stderr, "cannot start lane %u\n", k); exit(1); }
+        ++started;
     }
-    if (g_writer.started) {
-        writer_wait_idle(&g_writer);
-        pthread_mutex_lock(&g_writer.mu);
-        g_writer.stop = 1;
-        pthread_cond_broadcast(&g_writer.cv);
-        pthread_mutex_unlock(&g_writer.mu);
-        pthread_join(g_writer.th, NULL);
-        if (g_writer.failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", out); return 1; }
-    }
+    if (n_lanes > 1)
+        for (uint32_t k = 0; k < n_lanes; ++k)
+            if (lanes[k].n_jobs) pthread_join(lanes[k].th, NULL);
     const double t_end = now_ms();
+    if (!started) { aim_set_t *set = NULL; int rc = aim_set_alloc(1, n_dev_ids ? dev_ids : NULL, &set); if (rc) die_aim("aim_set_alloc", rc); aim_set_free(set); }   /* nothing to align: a run without a device still fails like the reference */
+    /* device phases: lanes (sets) run side by side -- the slowest one; host phases: likewise the slowest lane's */
     float h2d = 0, kern = 0, d2h = 0;
-    aim_set_timers(set, &h2d, &kern, &d2h);
+    double parse_ms = setup_ms, write_ms = 0, wait_ms = 0, join_ms = 0, submit_ms = 0, wrwait_ms = 0, t_first = 0;
+    uint64_t done = 0, first_done = 0;
+    for (uint32_t k = 0; k < n_lanes; ++k) {
+        const lane_t *L = &lanes[k];
+        if (!L->n_jobs) continue;
+        if (L->h2d > h2d) h2d = L->h2d;
+        if (L->kern > kern) kern = L->kern;
+        if (L->d2h > d2h) d2h = L->d2h;
+        if (setup_ms + L->parse_ms > parse_ms) parse_ms = setup_ms + L->parse_ms;
+        if (L->write_ms > write_ms) write_ms = L->write_ms;
+        if (L->wait_ms > wait_ms) wait_ms = L->wait_ms;
+        if (L->join_ms > join_ms) join_ms = L->join_ms;
+        if (L->submit_ms > submit_ms) submit_ms = L->submit_ms;
+        if (L->wrwait_ms > wrwait_ms) wrwait_ms = L->wrwait_ms;
+        done += L->done; first_done += L->pairs_first_done;
+        if (L->t_first_done > 0 && (t_first == 0 || L->t_first_done < t_first)) t_first = L->t_first_done;
+    }
     if (n_jobs == 0) { printf("Copying data to DPU\n"); printf("Run program on DPU(s)\n"); printf("Retrieve results\n"); }
     printf("CPU-DPU: %f ms\n", h2d);
     printf("DPU Kernel: %f ms\n", kern);
     printf("DPU-CPU: %f ms\n", d2h);
     /* steady state: from the moment the first batch is on disk to the last one (start-up -- HIP context, pinned buffers, the
-       pipeline filling -- excluded) */
-    const double steady = (done > pairs_first_done && t_end > t_first_done) ? (double)(done - pairs_first_done) / ((t_end - t_first_done) * 1e-3) : 0.0;
-    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms (line index %.3f ms), wait %.3f ms, format+write %.3f ms, loop %.3f ms, steady %.4g pairs/s (in the loop: pack join %.3f ms, writer hand-over %.3f ms, submit %.3f ms); input %s, output %s\n",
+       pipeline filling -- excluded); with several lanes: from the first lane's first batch, every lane's first batch not counted */
+    const double steady = (done > first_done && t_first > 0 && t_end > t_first) ? (double)(done - first_done) / ((t_end - t_first) * 1e-3) : 0.0;
+    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms (line index %.3f ms), wait %.3f ms, format+write %.3f ms, loop %.3f ms, steady %.4g pairs/s (in the loop: pack join %.3f ms, writer hand-over %.3f ms, submit %.3f ms); input %s, output %s; %u lane(s) x (%d + %d) threads%s\n",
            (unsigned long long)done, (unsigned long long)n_jobs, batch, gpus, slots, parse_ms, index_ms, wait_ms, write_ms, t_end - t_loop, steady, join_ms, wrwait_ms, submit_ms,
-           packed_input ? "packed batch file" : (no_pack ? "ASCII rows" : "packed 2 bit/base"), !backtrace ? "{idx, score}" : (full_ops ? "ops rows" : "device-side RLE"));
+           packed_input ? "packed batch file" : (no_pack ? "ASCII rows" : "packed 2 bit/base"), !backtrace ? "{idx, score}" : (full_ops ? "ops rows" : "device-side RLE"),
+           n_lanes, pack_threads, fmt_threads, pin ? ", pinned" : "");
 
-    pool_stop(&g_pack_pool);
-    pool_stop(&g_fmt_pool);
-    for (int t = 0; t < MAX_THREADS; ++t) { free(f.bufs[0][t]); free(f.bufs[1][t]); }
-    for (uint32_t k = 0; k < ring; ++k) {
-        job_t2 *j = &jobs[k];
-        void *bufs[] = {j->req, j->pkP, j->pkT, j->raw_idx, j->rawP, j->rawT, j->pat, j->txt, j->res8, j->cig, j->runs, j->res, j->ops};
-        for (size_t b = 0; b < sizeof bufs / sizeof bufs[0]; ++b)
-            if (bufs[b]) aim_host_free(bufs[b]);
-        free(j->is_raw);
-    }
-    free(jobs); free(inp.line_start);
+    free(lanes); free(inp.line_start);
     if (inp.size) munmap((void *)inp.data, inp.size);
     close(fd);
-    aim_set_free(set);
     if (dpu_file) fclose(dpu_file);
-    if (close(out_fd)) { fprintf(stderr, "Output file '%s' couldn't be written\n", out); return 1; }
     return 0;
 }

@@ -1451,3 +1451,39 @@ def test_two_host_threads_drive_chunked_group_launches_on_one_device(gpu, monkey
     for x in th:
         x.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("shards,extra", [(3, ["--batch", "3000"]), (2, ["--batch", "2500", "--device-ids", "0,0,0,0"]), (8, ["--batch", "4000", "--threads", "16"]),
+                                          (4, ["--batch", "3000", "--no-pin", "--slots", "1"])])
+def test_host_cli_out_shards_concatenate_to_the_single_file(gpu, sample_bytes, err_full_bytes, ref_digests, tmp_path, shards, extra):
+    """`--out-shards K` runs K lanes (pack pool, device set, format pool, writer, output file each) over K contiguous
+    runs of batches; `cat <out>.0*` is byte-identical to the single file -- text and packed input, score-only and CIGAR, more lanes than
+    devices and more devices than lanes, a lane count that leaves some shards empty, real reads with 'N' (raw side list)."""
+    import glob
+    import subprocess
+    host = os.path.join(ROOT, "aim_amd", "host", "host")
+    inp = tmp_path / "sample"
+    inp.write_bytes(sample_bytes)
+    pk = tmp_path / "sample.aimpk"
+    r = subprocess.run([host, str(inp), "/dev/null", "20000", "--read-size", "112", "--batch", "3000", "--pack-only", str(pk)], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    def run(src, n, flags, packed=False):
+        for f in glob.glob(str(tmp_path / "out*")):
+            os.unlink(f)
+        cmd = [host, str(src), str(tmp_path / "out"), str(n), "--algo", "wfa", "--max-score", "5", "--read-size", "112", "--out-shards", str(shards)] + flags
+        cmd += (["--packed-input"] if packed else []) + extra          # (a packed file's batches are taken as the file holds them)
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = sorted(glob.glob(str(tmp_path / "out.*")))
+        assert len(files) == shards and not os.path.exists(tmp_path / "out")
+        assert ("%d lane(s)" % shards) in r.stdout and r.stdout.count("Retrieve results") == 1 and r.stdout.count("Copying data to DPU") == 1
+        return b"".join(open(f, "rb").read() for f in files)
+    assert md5(run(inp, 20000, ["--backtrace", "--reduce"])) == ref_digests["wfa_reduce_backtrace"]
+    assert md5(run(inp, 20000, ["--reduce"])) == ref_digests["wfa_score_only"]
+    assert md5(run(pk, 20000, ["--backtrace", "--reduce"], packed=True)) == ref_digests["wfa_reduce_backtrace"]
+    assert md5(run(pk, 20000, ["--reduce"], packed=True)) == ref_digests["wfa_score_only"]
+    err = tmp_path / "err"
+    err.write_bytes(err_full_bytes)
+    want = {c["name"]: c["output_md5"] for c in judge_dataset_cases()}
+    assert md5(run(err, 15000, ["--backtrace", "--reduce", "--nr-dpus", "4"])) == want["err240727_wfa_mram_bt_red"]
+    assert md5(run(err, 15000, ["--reduce", "--nr-dpus", "4"])) == want["err240727_wfa_sc_red"]
