@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1267,6 +1268,11 @@ int aim_set_wait(aim_set_t *set, uint32_t device, uint32_t slot, uint32_t *n_run
     aim_slot &s = d.slots[slot];
     if (!s.submitted) return fail(AIM_ESTATE, "slot %u of device %d holds no batch", slot, d.dev);
     HIP_TRY(hipSetDevice(d.dev));
+    if (getenv("AIM_WAIT_POLL")) {   // A/B (host lanes sharing a device): poll the stream instead of blocking inside the runtime
+        hipError_t q;
+        while ((q = hipStreamQuery(s.stream)) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (q != hipSuccess) return fail(AIM_ENODEV, "hipStreamQuery failed: %s", hipGetErrorString(q));
+    } else
     HIP_TRY(hipStreamSynchronize(s.stream));
     s.submitted = false;
     const aim_batch_io_t &io = s.io;

@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -225,6 +226,7 @@ typedef struct {
     aim_batch_io_t io;               /* what was submitted (kept for a re-submission) */
     uint32_t device, slot;
     int in_flight;
+    int dry_filled;                  /* AIM_HOST_DRY: the stand-in results were written into this job's buffers */
 } job_t2;
 
 typedef struct {
@@ -663,6 +665,7 @@ typedef struct lane {
     float h2d, kern, d2h;
 } lane_t;
 
+static pthread_barrier_t g_lanes_ready;   /* every lane has its device set and pinned buffers: the loops start together */
 static pthread_mutex_t g_say_mu = PTHREAD_MUTEX_INITIALIZER;
 static int g_said_copy, g_said_retrieve;
 static void say_once(int *flag, const char *text)   /* the reference's progress lines, once per run whatever the lane count */
@@ -735,14 +738,20 @@ static void *lane_main(void *arg)
     int out_mmap = !out_seq && out_mode && !strcmp(out_mode, "mmap");   /* A/B switch; see the loop */
     const int out_serial = out_seq || (out_mode && !strcmp(out_mode, "serial"));   /* one thread writes (also the fallback when no writer thread could be created) */
     if (out_serial) out_mmap = 0;
+    pthread_barrier_wait(&g_lanes_ready);
+    /* measurement aids, not product paths: AIM_HOST_TRACE=1 prints every iteration's stage times to stderr; AIM_HOST_DRY=1 skips the
+       device (no submit / wait: the result buffers keep {idx, 0}) -- the HOST-side rate of parse + pack + format + write alone */
+    const int trace = getenv("AIM_HOST_TRACE") != NULL, dry = getenv("AIM_HOST_DRY") != NULL;
     L->t_loop = now_ms();
     for (uint64_t it = 0; it < n_jobs + ring; ++it) {
         job_t2 *j = &jobs[it % ring];
         const int have_old = j->in_flight;
+        const double t_it = now_ms();
+        double d_wait = 0, d_fmt = 0, d_wr = 0, d_join = 0, d_sub = 0;
         if (have_old) {   /* job it - ring: results are needed now (and its buffers next) */
             double t0 = now_ms();
             say_once(&g_said_retrieve, "Retrieve results\n");
-            rc = aim_set_wait(L->set, j->device, j->slot, &j->n_runs);
+            rc = dry ? 0 : aim_set_wait(L->set, j->device, j->slot, &j->n_runs);
             if (rc == AIM_ENOMEM && j->cig && !j->use_full) {
                 /* more runs than READ_SIZE/4 + 2 per pair on average (e.g. SWG with MAX_SCORE as +infinity on dissimilar reads):
                    run this batch again and gather result_t + ops rows like the reference (host.c:316-326); the inputs are
@@ -761,7 +770,7 @@ static void *lane_main(void *arg)
                 exit(1);
             }
             if (rc) die_aim("aim_set_wait", rc);
-            L->wait_ms += now_ms() - t0;
+            L->wait_ms += (d_wait = now_ms() - t0);
             f->job = j; f->n = j->n; f->use_full = j->use_full;
             j->in_flight = 0;
         }
@@ -787,12 +796,13 @@ static void *lane_main(void *arg)
         if (have_old) {
             double t0 = now_ms();
             pool_run(&L->fmt_pool, format_range, f);
+            d_fmt = now_ms() - t0;
             const size_t batch_at = out_at;
             for (int t = 0; t < L->fmt_pool.n; ++t) { f->off[t] = out_at; out_at += f->len[t]; }
             if (W->started) {   /* hand the printed batch to the writer; the next one is printed into the other buffer set */
                 const double tw = now_ms();
                 writer_submit(W, L->fmt_pool.n, f->buf, f->len, f->off);
-                L->wrwait_ms += now_ms() - tw;
+                L->wrwait_ms += (d_wr = now_ms() - tw);
                 if (W->failed) { fprintf(stderr, "Output file '%s' couldn't be written\n", L->out_path); exit(1); }
                 f->set ^= 1;
                 f->buf = f->bufs[f->set]; f->cap = f->caps[f->set]; f->len = f->lens[f->set]; f->off = f->offs[f->set];
@@ -820,7 +830,7 @@ static void *lane_main(void *arg)
             const double tj = now_ms();
             if (c->packed_input) pool_join(&L->pack_pool);
             else pack_finish(&L->pack_pool, &L->pk, j, batch);
-            L->join_ms += now_ms() - tj;                   /* what the pack still needed after the format stage was done */
+            L->join_ms += (d_join = now_ms() - tj);        /* what the pack still needed after the format stage was done */
             L->parse_ms += now_ms() - t_pack;              /* (overlaps the format + write above) */
             say_once(&g_said_copy, "Copying data to DPU\nRun program on DPU(s)\n");
             aim_batch_io_t io;
@@ -838,12 +848,22 @@ static void *lane_main(void *arg)
             j->io = io;
             j->use_full = 0;
             const double ts = now_ms();
-            if ((rc = aim_set_submit(L->set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
-            L->submit_ms += now_ms() - ts;
+            if (dry && j->dry_filled) { }
+            else if (dry) {   /* (what the device would have returned, as far as the formatter's work goes: the right idx, score 0, "<n>M") */
+                for (uint32_t q = 0; q < j->n && !backtrace; ++q) { j->res8[q].idx = (uint32_t)(j->first_pair + q); j->res8[q].score = 0; }
+                for (uint32_t q = 0; q < j->n && backtrace && !full_ops; ++q) {
+                    j->cig[q].idx = (uint32_t)(j->first_pair + q); j->cig[q].score = 0; j->cig[q].run_offset = q; j->cig[q].n_runs = 1; j->cig[q].status = 0;
+                    j->runs[q] = (100u << 8) | 'M';
+                }
+                j->dry_filled = 1;
+            } else if ((rc = aim_set_submit(L->set, j->device, j->slot, &io))) die_aim("aim_set_submit", rc);
+            L->submit_ms += (d_sub = now_ms() - ts);
             j->in_flight = 1;
             sent += j->n;
             if (c->packed_input && sent < L->n_pairs && it + 1 == n_jobs) { fprintf(stderr, "'%s': fewer pairs than its header states\n", c->in_name); exit(1); }
         }
+        if (trace) fprintf(stderr, "[lane %d it %llu] t %.3f total %.3f: wait %.3f format %.3f writer %.3f join %.3f submit %.3f\n", L->id, (unsigned long long)it, t_it - L->t_loop,
+                           now_ms() - t_it, d_wait, d_fmt, d_wr, d_join, d_sub);
     }
     if (W->started) {
         writer_wait_idle(W);
@@ -943,7 +963,8 @@ int main(int argc, char *argv[])
     /* threads: per lane 48 at most (measured on a 256-thread host, 13.7 GB of text: 32 + 16 beats 64, 128 and 256 within ONE lane),
        all lanes together no more than the machine has */
     if (threads <= 0) {
-        long per = ncpu < 1 ? 1 : ncpu / (long)n_lanes;
+        long per = ncpu < 1 ? 1 : (n_lanes > 1 ? ncpu / 2 : ncpu) / (long)n_lanes;   /* several lanes: one thread per physical core of an SMT-2 host in total
+                                                                                     (4 lanes x (16 + 8) measured 1.5x faster than 4 x (32 + 16) on a loaded 256-thread box) */
         if (per > 48) per = 48;
         if (per < 3) per = 3;
         threads = (int)(per * n_lanes);
@@ -1048,6 +1069,11 @@ int main(int argc, char *argv[])
     const uint32_t ring_all = (gpus > n_lanes ? gpus : n_lanes) * slots;
     if (!packed_input) {
         uint64_t want = (total_pairs + 2 * ring_all - 1) / (2 * ring_all);
+        if (n_lanes > 1) {   /* a lane's pipeline fills and drains over `slots` batches: give it at least 8 (and less pinned memory to set up) */
+            const uint64_t w8 = (total_pairs + 8 * n_lanes - 1) / (8 * n_lanes);
+            if (w8 < want) want = w8;
+            if (want < 262144) want = 262144;
+        }
         if (want < 65536) want = 65536;
         if (want < batch) batch = (uint32_t)want;
         if ((uint64_t)batch > total_pairs) batch = (uint32_t)(total_pairs ? total_pairs : 1);
@@ -1169,7 +1195,9 @@ int main(int argc, char *argv[])
         }
     }
     const double t_loop = now_ms();
-    uint32_t started = 0;
+    uint32_t started = 0, busy = 0;
+    for (uint32_t k = 0; k < n_lanes; ++k) busy += lanes[k].n_jobs != 0;
+    pthread_barrier_init(&g_lanes_ready, NULL, busy ? busy : 1);
     for (uint32_t k = 0; k < n_lanes; ++k) {
         lane_t *L = &lanes[k];
         if (L->n_jobs == 0) { close(L->out_fd); continue; }   /* (an empty shard file) */
@@ -1184,7 +1212,7 @@ int main(int argc, char *argv[])
     if (!started) { aim_set_t *set = NULL; int rc = aim_set_alloc(1, n_dev_ids ? dev_ids : NULL, &set); if (rc) die_aim("aim_set_alloc", rc); aim_set_free(set); }   /* nothing to align: a run without a device still fails like the reference */
     /* device phases: lanes (sets) run side by side -- the slowest one; host phases: likewise the slowest lane's */
     float h2d = 0, kern = 0, d2h = 0;
-    double parse_ms = setup_ms, write_ms = 0, wait_ms = 0, join_ms = 0, submit_ms = 0, wrwait_ms = 0, t_first = 0;
+    double parse_ms = setup_ms, write_ms = 0, wait_ms = 0, join_ms = 0, submit_ms = 0, wrwait_ms = 0, t_first = 0, loop_ms = 0, lane_setup_ms = 0, t_last = 0;
     uint64_t done = 0, first_done = 0;
     for (uint32_t k = 0; k < n_lanes; ++k) {
         const lane_t *L = &lanes[k];
@@ -1198,6 +1226,9 @@ int main(int argc, char *argv[])
         if (L->join_ms > join_ms) join_ms = L->join_ms;
         if (L->submit_ms > submit_ms) submit_ms = L->submit_ms;
         if (L->wrwait_ms > wrwait_ms) wrwait_ms = L->wrwait_ms;
+        if (L->t_end - L->t_loop > loop_ms) loop_ms = L->t_end - L->t_loop;
+        if (L->t_loop - t_loop > lane_setup_ms) lane_setup_ms = L->t_loop - t_loop;
+        if (L->t_end > t_last) t_last = L->t_end;
         done += L->done; first_done += L->pairs_first_done;
         if (L->t_first_done > 0 && (t_first == 0 || L->t_first_done < t_first)) t_first = L->t_first_done;
     }
@@ -1207,11 +1238,19 @@ int main(int argc, char *argv[])
     printf("DPU-CPU: %f ms\n", d2h);
     /* steady state: from the moment the first batch is on disk to the last one (start-up -- HIP context, pinned buffers, the
        pipeline filling -- excluded); with several lanes: from the first lane's first batch, every lane's first batch not counted */
-    const double steady = (done > first_done && t_first > 0 && t_end > t_first) ? (double)(done - first_done) / ((t_end - t_first) * 1e-3) : 0.0;
-    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms (line index %.3f ms), wait %.3f ms, format+write %.3f ms, loop %.3f ms, steady %.4g pairs/s (in the loop: pack join %.3f ms, writer hand-over %.3f ms, submit %.3f ms); input %s, output %s; %u lane(s) x (%d + %d) threads%s\n",
-           (unsigned long long)done, (unsigned long long)n_jobs, batch, gpus, slots, parse_ms, index_ms, wait_ms, write_ms, t_end - t_loop, steady, join_ms, wrwait_ms, submit_ms,
+    const double steady = (done > first_done && t_first > 0 && t_last > t_first) ? (double)(done - first_done) / ((t_last - t_first) * 1e-3) : 0.0;
+    printf("AIM-HIP: %llu pairs in %llu batch(es) of <= %u over %u device(s) x %u slot(s); parse+pack %.3f ms (line index %.3f ms), wait %.3f ms, format+write %.3f ms, loop %.3f ms, steady %.4g pairs/s (in the loop: pack join %.3f ms, writer hand-over %.3f ms, submit %.3f ms); input %s, output %s; %u lane(s) x (%d + %d) threads%s, device set + pinned buffers %.3f ms%s\n",
+           (unsigned long long)done, (unsigned long long)n_jobs, batch, gpus, slots, parse_ms, index_ms, wait_ms, write_ms, loop_ms, steady, join_ms, wrwait_ms, submit_ms,
            packed_input ? "packed batch file" : (no_pack ? "ASCII rows" : "packed 2 bit/base"), !backtrace ? "{idx, score}" : (full_ops ? "ops rows" : "device-side RLE"),
-           n_lanes, pack_threads, fmt_threads, pin ? ", pinned" : "");
+           n_lanes, pack_threads, fmt_threads, pin ? ", pinned" : "", lane_setup_ms, getenv("AIM_HOST_DRY") ? " [AIM_HOST_DRY: no device work, results void]" : "");
+    (void)t_end;
+    if (getenv("AIM_HOST_RUSAGE")) {   /* measurement aid: where the process's time went (user / system), page faults, context switches */
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "[rusage] user %.3f s, system %.3f s, minor faults %ld, major faults %ld, voluntary switches %ld, involuntary %ld, max RSS %ld MB\n",
+                ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6, ru.ru_minflt, ru.ru_majflt, ru.ru_nvcsw, ru.ru_nivcsw,
+                ru.ru_maxrss / 1024);
+    }
 
     free(lanes); free(inp.line_start);
     if (inp.size) munmap((void *)inp.data, inp.size);
