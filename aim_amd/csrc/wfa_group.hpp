@@ -3,7 +3,7 @@
 //
 // Same results as affine_wfa_compute (WFA/DPU-WRAM/dpu/wfa.c:342-379, with -DREDUCE wfa.c:69-140).  The static
 // kernel (wfa_lane.hpp) covers the reference's default penalties at MAX_SCORE <= 5 (<= 10 score-only); this one covers
-// the rest (READ_SIZE <= 2048, MAX_SCORE <= 400; beyond that wfa_wave.hpp) at run-time parameters:
+// the rest (READ_SIZE <= 16 368, MAX_SCORE <= 4000 as far as LDS admits the shape; beyond that wfa_wave.hpp) at run-time parameters:
 //   * a pair is owned by G consecutive lanes (G = 1 .. 64, picked by wfa_group_plan from the LDS one pair's window
 //     needs and the residency that leaves); the lanes of a group take the diagonals k = lo+g, lo+g+G, ...
 //   * the live window of wavefronts -- M for the last max(x,o+e)+1 scores, I and D for the last e+1 -- lives in
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         {
                             const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
                             const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? raw_ie_m1 : kGrpNull;
-                            // (offsets are <= READ_SIZE <= 2048 or kGrpNull: the reference's int16 store of offset + 1 never wraps, so no cast is spelled out)
+                            // (offsets are <= READ_SIZE <= 16 368 or kGrpNull: the reference's int16 store of offset + 1 never wraps, so no cast is spelled out)
                             const int v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : max(ins_g, ins_i) + 1;
                             if (!i_out_null) {
                                 ins = v;
@@ -664,7 +664,10 @@ inline bool wfa_group_plan_rows(const aim_params_t &p, uint32_t n_pairs, const K
                                 size_t *lds, size_t *hist_pair_bytes)   // rows: entries per LDS ring row asked for; < 0 = the default rule
 {
     if (p.algo != AIM_ALGO_WFA) return false;
-    if (p.read_size > 2048 || p.max_score > 400) return false;
+    // int16 offsets with NULL = -16384 (offset + 1 must stay above it) and 24-bit home arithmetic bound the shapes; what really decides is LDS below:
+    // the packed image (READ_SIZE / 2 bytes per pair) and, without the reduction, rows of 2 * MAX_SCORE + 3 entries. (Rounds 1-3 stopped at READ_SIZE
+    // 2048 / MAX_SCORE 400: WFA-adaptive l = 10 000 e = 1 % then ran one pair per wavefront on wfa_wave_kernel, ~11x off cfg3's per-cell rate.)
+    if (p.read_size > 16368 || p.max_score > 4000) return false;
     const int R = p.mismatch > p.gap_o + p.gap_e ? p.mismatch : p.gap_o + p.gap_e;
     int ring_m = 1, ring_e = 1;
     ring_m = R + 1;

@@ -1487,3 +1487,28 @@ def test_host_cli_out_shards_concatenate_to_the_single_file(gpu, sample_bytes, e
     want = {c["name"]: c["output_md5"] for c in judge_dataset_cases()}
     assert md5(run(err, 15000, ["--backtrace", "--reduce", "--nr-dpus", "4"])) == want["err240727_wfa_mram_bt_red"]
     assert md5(run(err, 15000, ["--reduce", "--nr-dpus", "4"])) == want["err240727_wfa_sc_red"]
+
+
+@pytest.mark.parametrize("l,err,n", [(10000, 0.01, 48), (4000, 0.02, 96), (2000, 0.05, 128), (16000, 0.01, 16), (5000, 0.05, 32)])
+def test_wfa_adaptive_long_reads_on_the_group_kernel(gpu, l, err, n):
+    """WFA-adaptive beyond READ_SIZE 2048 / MAX_SCORE 400 (the launcher's shapes for l = 10 000 e = 1 %: MAX_SCORE 500,
+    READ_SIZE 10 112) runs on wfa_group_kernel (packed image in LDS, rows of 96 / 128, history regions + traceback kernel) instead of one
+    pair per wavefront on wfa_wave_kernel -- bit-exact against the oracle, score-only and with CIGAR, through ASCII and packed batches."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("wfa", l, err)
+    req, pat, txt = engine.gen_pairs(4100 + l, 0, n, l, err, rs)
+    for kw in (dict(reduce=True), dict(reduce=True, backtrace=True)):
+        params = engine.make_params("wfa", ms, rs, **kw)
+        _compare("wfa", params, req, pat, txt)
+    with engine.DeviceSet(1) as s:
+        s.configure(engine.make_params("wfa", ms, rs, reduce=True), n)
+        s.push(0, req, pat, txt); s.launch(); s.pull(0)
+        assert s.plan_describe(0).startswith("wfa_group_kernel"), s.plan_describe(0)
+    params = engine.make_params("wfa", ms, rs, reduce=True, backtrace=True, req8=True)
+    want = _oracle_text("wfa", params, req, pat, txt)[1]
+    with engine.DeviceSet(1) as s:
+        cap = n * (rs // 4 + 2)
+        s.configure_slots(params, n, slots=1, max_raw=n, max_runs=cap)
+        s.submit(0, 0, req, packed=engine.pack_batch(req, pat, txt), cigar_runs_cap=cap)
+        out = s.wait(0, 0)
+    assert engine.format_output_runs(out["cig"], out["runs"]) == want

@@ -25,6 +25,11 @@ CONFIGS = {
     "wfa_l100_e5_cigar": dict(algo="wfa", l=100, e=0.05, n=1 << 19, kw=dict(backtrace=True, reduce=True)),
     "wfa_l1000_e5_cigar": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(backtrace=True, reduce=True)),
     "wfa_l1000_e5_score": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, kw=dict(reduce=True)),
+    # WFA-adaptive on long reads: beyond wfa_group's READ_SIZE <= 2048 / MAX_SCORE <= 400 -> wfa_wave_kernel, one pair per wavefront
+    "wfa_l10000_e1_score": dict(algo="wfa", l=10000, e=0.01, n=8192, kw=dict(reduce=True)),
+    "wfa_l10000_e1_cigar": dict(algo="wfa", l=10000, e=0.01, n=8192, kw=dict(backtrace=True, reduce=True)),
+    "wfa_l2000_e5_score": dict(algo="wfa", l=2000, e=0.05, n=1 << 14, kw=dict(reduce=True)),
+    "wfa_l4000_e2_score": dict(algo="wfa", l=4000, e=0.02, n=1 << 14, kw=dict(reduce=True)),
     "nw_l100_e1_cigar": dict(algo="nw", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "nw_l100_e1_score": dict(algo="nw", l=100, e=0.01, n=1 << 20, kw=dict()),
     "swg_l100_e1_cigar": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
