@@ -51,11 +51,14 @@ struct GroupCfg {
     int pair_dwords;  // LDS dwords per pair: window + descriptors + packed sequences (odd => conflict-free across pairs)
     int rows_per_wave;
     // BACKTRACE: every pair of the launch (chunk) owns a history region in HBM that outlives the compute kernel -- the traceback
-    // is a kernel of its own (wfa_group_tb_kernel):  [TbHead 16 B][TbRow table, (MAX_SCORE+2) x 16 B][pool of int16 offsets:
-    // per score the computed cells {M, I, D, -} of [lo, hi], contiguous][run scratch: (2*MAX_SCORE+16) x 4 B, compact CIGAR only]
+    // is a kernel of its own (wfa_group_tb_kernel):  [TbHead 16 B][TbRow table, (MAX_SCORE/unit+2) x 8 B][pool of cells {M, I, D, -} int16:
+    // the cell of (score s, diagonal k) sits at a CLOSED-FORM index -- narrow rows: s * wlds + home(k) (the LDS row's own image); one home per
+    // diagonal: s * s + s + k (row s holds diagonals -s .. s) -- so the traceback needs no descriptor to ADDRESS a cell and fetches the
+    // three descriptors and the five candidate cells of a step in ONE round trip (round 3: descriptors first, then cells: two)]
+    // [run scratch: (2*MAX_SCORE+16) x 4 B, compact CIGAR only]
     int hist_pair_bytes;  // bytes of one pair's region (multiple of 256)
     int pool_off;         // byte offset of the pool inside the region
-    int pool_cap;         // cells {M, I, D, -} (8 B) of the pool: sum over scores of min(2s+1, widest wavefront the plan admits)
+    int pool_cap;         // cells {M, I, D, -} (8 B) of the pool: rows x wlds, or rows^2
     int runs_off;         // byte offset of the run scratch
     int runs_cap;         // entries of it
     int wlds;         // entries per ring row IN LDS: wcap (every diagonal has its own home), or a power of two < wcap ("narrow
@@ -75,8 +78,22 @@ constexpr int kGrpNull = -16384;
 
 // Per-pair history (BACKTRACE): head + one 16-byte descriptor per score + the offsets (see GroupCfg).
 struct TbHead { int32_t final_score; int32_t walk; int32_t pad[2]; };   // walk: 1 = the traceback kernel owns this pair, 0 = to-do list / not computed
-struct TbRow { uint32_t off; int16_t lo, hi, klo, khi, flags, pad; };   // off: pool index of cell lo of this score's row; one cell = {M, I, D, -} int16 (8 B)
-static_assert(sizeof(TbHead) == 16 && sizeof(TbRow) == 16, "history layout");
+struct TbRow { int16_t klo, khi, flags, pad; };   // the score's final (reduced) bounds and flags: what the traceback's range / null tests read
+static_assert(sizeof(TbHead) == 16 && sizeof(TbRow) == 8, "history layout");
+
+// Pool index of the cell of (score su in units, diagonal k): see GroupCfg. The traceback reads neighbours of cells that exist, so k may
+// lie one or two outside the row: clamped here (such a cell is never selected -- the caller's range test fails).
+template <bool MODW>
+__device__ __forceinline__ int group_cell_index(const GroupCfg &c, int su, int k)
+{
+    if (c.wlds != c.wcap) {   // narrow rows: the row's LDS image
+        const int t = max(k + c.kbias, 0);
+        const int h = MODW ? t - (int)__umul24(__umul24((uint32_t)t, (uint32_t)c.wmagic) >> 16, (uint32_t)c.wlds) : (t & c.wmask);
+        return su * c.wlds + h;
+    }
+    const int kc = min(max(k, -su), su);
+    return su * su + su + kc;
+}
 
 // minimum over the G lanes of a group (G-aligned inside a 16-lane DPP row); every lane of the group gets it
 template <int G>
@@ -285,15 +302,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         // Every later wavefront is extended by the lane that computes it (below); score 0 has no compute step.
         int part = 0x7fffffff;                     // min over my diagonals of the distance to the end (for the reduction)
         int dist0 = 0x7fffffff, dist1 = 0x7fffffff; // that distance on my first and second diagonal of the current row
-        // history region of this pair (BACKTRACE): descriptor table + pool; h_off / h_lo / h_hi describe the current score's row
+        // history region of this pair (BACKTRACE): descriptor table + pool
         char *hreg = BT ? hist_base + (size_t)(active ? pair : 0u) * (size_t)c.hist_pair_bytes : nullptr;
         TbRow *htab = reinterpret_cast<TbRow *>(hreg + sizeof(TbHead));
-        uint2 *hpool = reinterpret_cast<uint2 *>(hreg + c.pool_off);   // cells {M, I, D, -}: ONE 8-byte store per computed cell
-        int htop = 1, h_off = 0, h_lo = 0, h_hi = 0;   // score 0: cell 0 of the pool
+        uint2 *hpool = reinterpret_cast<uint2 *>(hreg + c.pool_off);   // cells {M, I, D, -}: ONE 8-byte store per computed cell, at its closed-form index (GroupCfg)
+        const bool hnarrow = c.wlds != c.wcap;
         if (g == 0) {
             const int m00 = done ? 0 : extend(0, 0);
             mrow_at(0)[H(0)] = (int16_t)m00;
-            if (BT && !done) hpool[0] = make_uint2((uint32_t)(uint16_t)m00, 0u);
+            if (BT && !done) hpool[hnarrow ? H(0) : 0] = make_uint2((uint32_t)(uint16_t)m00, 0u);
             meta[0] = 0; meta[1] = 0; meta[2] = (int16_t)flags;
         }
         if (BT && a.cig == nullptr && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465 (ops-row output only)
@@ -342,15 +359,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     }
                     fence();
                 }
-                if (BT && g == 0) {   // final descriptor of this score (after reduction): one 16-byte store
-                    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                    aim_u32x4 d4;
-                    d4.x = (uint32_t)h_off;
-                    d4.y = (uint32_t)(uint16_t)h_lo | ((uint32_t)(uint16_t)h_hi << 16);
-                    d4.z = (uint32_t)(uint16_t)klo | ((uint32_t)(uint16_t)khi << 16);
-                    d4.w = (uint32_t)(uint16_t)flags;
-                    *reinterpret_cast<aim_u32x4 *>(htab + score) = d4;
-                }
+                if (BT && g == 0)   // final descriptor of this score (after reduction): one 8-byte store
+                    *reinterpret_cast<uint2 *>(htab + score) = make_uint2((uint32_t)(uint16_t)klo | ((uint32_t)(uint16_t)khi << 16), (uint32_t)(uint16_t)flags);
                 // affine_wfa_end_reached, wfa.c:210-230
                 if ((flags & GF_PRESENT) && !(flags & GF_MNULL) && klo <= ak && khi >= ak && (int)mrow[H(ak)] >= tlen) {
                     done = true;
@@ -394,7 +404,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                 AIM_GSTAMP(2);   // score++, source descriptors
                 if (m_sub_null && i_out_null && d_out_null) {
                     flags = 0; klo = 0; khi = -1;
-                    if (BT) { h_off = 0; h_lo = 0; h_hi = -1; }
                 } else {
                     if (m_sub_null) { sub_lo = 1; sub_hi = -1; }
                     if (m_o_null) { o_lo = 1; o_hi = -1; }
@@ -409,9 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         done = true;
                         hi_run = lo - 1;               // nothing more is computed or stored for it (its history pool is sized for admitted widths only)
                     }
-                    const int hw = hi_run - lo + 1;    // BACKTRACE: this score's row in the pool: hw cells
-                    uint2 *hrow = hpool + htop - lo;   // cell of diagonal k: hrow[k]
-                    if (BT) { h_off = htop; h_lo = lo; h_hi = hi_run; htop += (hw > 0 ? hw : 0); }
+                    uint2 *hrow = hpool + (hnarrow ? score * wl : score * score + score);   // BACKTRACE: this score's row of the pool (narrow: cell of k at hrow[H(k)], else hrow[k])
 #ifdef AIM_GROUP_COUNT_WIDTHS
                     dbg_wsum += hi - lo + 1; dbg_w32 += (hi - lo + 1) > 32; dbg_w64 += (hi - lo + 1) > 64;
 #endif
@@ -420,41 +427,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
                     part = 0x7fffffff;
                     int trip = 0;
-                    for (int k = lo + g; k <= hi_run; k += G, ++trip) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
+                    // homes advance with k: one conditional subtraction per step instead of a modulo per address (3 per trip)
+                    auto wrap_up = [&](int h_) { if constexpr (MODW) return h_ >= wl ? h_ - wl : h_; else return h_ & wmask; };
+                    auto wrap_dn = [&](int h_) { if constexpr (MODW) return h_ < 0 ? h_ + wl : h_; else return h_ & wmask; };
+                    int hk = H(lo + g);
+                    for (int k = lo + g; k <= hi_run; k += G, ++trip, hk = wrap_up(hk + G)) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
                         // The five source cells are fetched TOGETHER and unconditionally (every row is a valid LDS row of
                         // wcap = 2*MAX_SCORE+3 entries and |k +- 1| <= MAX_SCORE+1, so the addresses are always in bounds);
                         // AFFINE_WAVEFRONT_COND_FETCH's range / null tests then select. Guarded reads compiled to one
-                        // exec-masked branch and one LDS round trip EACH: five dependent round trips per cell.
-                        const int hk = H(k), hkm = H(k - 1), hkp = H(k + 1);
+                        // exec-masked branch and one LDS round trip EACH: five dependent round trips per cell. (Round 4: I and D are
+                        // COMPUTED unconditionally too and only their stores are predicated -- as `if (!i_out_null) { ... }` blocks the
+                        // compiler sank two of the five loads into the blocks, i.e. back into a second round trip.)
+                        const int hkm = wrap_dn(hk - 1), hkp = wrap_up(hk + 1);
                         const int raw_mo_m1 = r_mo[hkm], raw_ie_m1 = r_ie[hkm], raw_mo_p1 = r_mo[hkp], raw_de_p1 = r_de[hkp],
                                   raw_ms = r_ms[hk];
-                        int ins = -10;
-                        {
-                            const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
-                            const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? raw_ie_m1 : kGrpNull;
-                            // (offsets are <= READ_SIZE <= 16 368 or kGrpNull: the reference's int16 store of offset + 1 never wraps, so no cast is spelled out)
-                            const int v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : max(ins_g, ins_i) + 1;
-                            if (!i_out_null) {
-                                ins = v;
-                                oi[hk] = (int16_t)ins;
-                            }
-                        }
-                        int del = -10;
-                        {
-                            const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? raw_mo_p1 : kGrpNull;
-                            const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? raw_de_p1 : kGrpNull;
-                            if (!d_out_null) {
-                                del = max(del_g, del_d);
-                                od[hk] = (int16_t)del;
-                            }
-                        }
+                        const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
+                        const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? raw_ie_m1 : kGrpNull;
+                        // (offsets are <= READ_SIZE <= 16 368 or kGrpNull: the reference's int16 store of offset + 1 never wraps, so no cast is spelled out)
+                        const int ins_v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : max(ins_g, ins_i) + 1;
+                        const int ins = i_out_null ? -10 : ins_v;
+                        if (!i_out_null) oi[hk] = (int16_t)ins;
+                        const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? raw_mo_p1 : kGrpNull;
+                        const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? raw_de_p1 : kGrpNull;
+                        const int del = d_out_null ? -10 : max(del_g, del_d);
+                        if (!d_out_null) od[hk] = (int16_t)del;
                         int sub = -10;
                         if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? raw_ms + 1 : kGrpNull;
                         // M[s][k] as the reference stores it (int16), then affine_wfa_extend (wfa.c:186-208) on that value: a
                         // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
                         const int ext = extend(k, max(del, max(sub, ins)));
                         om[hk] = (int16_t)ext;
-                        if (BT) hrow[k] = make_uint2((uint32_t)(uint16_t)ext | ((uint32_t)(uint16_t)ins << 16), (uint32_t)(uint16_t)del);   // I / D: -10 when absent (never selected)
+                        if (BT) hrow[hnarrow ? hk : k] = make_uint2((uint32_t)(uint16_t)ext | ((uint32_t)(uint16_t)ins << 16), (uint32_t)(uint16_t)del);   // I / D: -10 when absent (never selected)
                         const int dist = max(plen - (ext - k), tlen - ext);
                         part = min(part, dist);
                         if (REDUCE) { dist0 = trip == 0 ? dist : dist0; dist1 = trip == 1 ? dist : dist1; }
@@ -509,12 +512,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
 // affine_wavefronts_backtrace (wfa_backtracing.c:210-351) as a kernel of its own: ONE PAIR PER LANE over the history regions
 // the compute kernel left in HBM. (Round 2 walked inside the compute kernel: one lane of a group walked while the others
 // idled, and the walk's registers held the CIGAR variants at 87-100 VGPRs.) Every address of a step depends on (score, k)
-// only: the three descriptors come back in one round trip, the five candidate offsets in a second, and the range tests of
-// the reference then select -- a cell outside its row is read at a clamped index and never selected. Output: result_t +
+// only -- cells sit at closed-form indices (GroupCfg) -- so the three descriptors AND the five candidate offsets come back in ONE
+// round trip (round 3 needed the descriptors to address the cells: two dependent trips per step of a walk that waits 93 % of its
+// cycles), and the range tests of the reference then select -- a cell outside its row is read at a clamped index and never selected. Output: result_t +
 // edit operations patched into the ops row the compute kernel pre-filled with 'M' (default ABI), or aim_cigar_t + runs
 // (RUNS: the compact CIGAR; runs are collected backwards in the pair's own run scratch and copied out forwards).
-template <typename Sink>
-__device__ __forceinline__ int group_tb_walk(const TbRow *tab, const int16_t *pool, int final_score, int plen, int tlen, int X, int OE, int E, Sink &sink)
+template <bool MODW, typename Sink>
+__device__ __forceinline__ int group_tb_walk(const GroupCfg &c, const TbRow *tab, const int16_t *pool, int final_score, int plen, int tlen, int X, int OE, int E, Sink &sink)
 {
     enum { BT_M = 0, BT_I = 1, BT_D = 2 };
     const int ak = tlen - plen;
@@ -523,26 +527,18 @@ __device__ __forceinline__ int group_tb_walk(const TbRow *tab, const int16_t *po
         const int v_ = off_ - kk_, h_ = off_;
         return v_ > 0 && v_ <= plen && h_ > 0 && h_ <= tlen;
     };
-    struct Row { int off, lo, w, klo, khi, f; };
+    struct Row { int klo, khi, f; };
     auto row = [&](int s_) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(tab + s_);
+        const uint2 q = *reinterpret_cast<const uint2 *>(tab + s_);
         Row r;
-        r.off = (int)q.x; r.lo = (int16_t)(q.y & 0xffffu); r.w = (int16_t)(q.y >> 16) - r.lo + 1;
-        r.klo = (int16_t)(q.z & 0xffffu); r.khi = (int16_t)(q.z >> 16); r.f = (int)(q.w & 0xffffu);
+        r.klo = (int16_t)(q.x & 0xffffu); r.khi = (int16_t)(q.x >> 16); r.f = (int)(q.y & 0xffffu);
         return r;
     };
-    auto cell = [&](const Row &r, int which, int k_) -> int {   // which: 0 = M, 1 = I, 2 = D; clamped, selected by the caller's range test
-        const int w = r.w > 0 ? r.w : 1;
-        int i = k_ - r.lo;
-        i = i < 0 ? 0 : (i >= w ? w - 1 : i);
-        return pool[4 * (r.off + i) + which];   // cells are {M, I, D, -} int16
+    auto cell = [&](int s_, int which, int k_) -> int {   // which: 0 = M, 1 = I, 2 = D; index clamped into the row, selected by the caller's range test
+        return pool[4 * group_cell_index<MODW>(c, s_, k_) + which];   // cells are {M, I, D, -} int16
     };
     int sc = final_score, k = ak;
-    int offset;
-    {
-        const Row r0 = row(sc);
-        offset = cell(r0, 0, k);
-    }
+    int offset = cell(sc, 0, k);
     bool valid = valid_loc(k, offset);
     int bt = BT_M;
     int v = offset - k, h = offset;
@@ -555,9 +551,10 @@ __device__ __forceinline__ int group_tb_walk(const TbRow *tab, const int16_t *po
             }
         }
         const int s_o = sc - OE, s_e = sc - E, s_x = sc - X;
-        const Row ro = row(max(s_o, 0)), re = row(max(s_e, 0)), rx = row(max(s_x, 0));
-        const int v_de = cell(re, 2, k + 1), v_do = cell(ro, 0, k + 1);
-        const int v_ie = cell(re, 1, k - 1), v_io = cell(ro, 0, k - 1), v_mx = cell(rx, 0, k);
+        const int c_o = max(s_o, 0), c_e = max(s_e, 0), c_x = max(s_x, 0);
+        const Row ro = row(c_o), re = row(c_e), rx = row(c_x);   // these eight loads depend on (sc, k) only: one round trip
+        const int v_de = cell(c_e, 2, k + 1), v_do = cell(c_o, 0, k + 1);
+        const int v_ie = cell(c_e, 1, k - 1), v_io = cell(c_o, 0, k - 1), v_mx = cell(c_x, 0, k);
         int o_lo = ro.klo, o_hi = ro.khi, o_f = ro.f, e_lo = re.klo, e_hi = re.khi, e_f = re.f, x_lo = rx.klo, x_hi = rx.khi, x_f = rx.f;
         if (s_o < 0) { o_lo = 1; o_hi = -1; o_f = 0; }
         if (s_e < 0) { e_lo = 1; e_hi = -1; e_f = 0; }
@@ -605,7 +602,7 @@ __device__ __forceinline__ int group_tb_walk(const TbRow *tab, const int16_t *po
     return status;
 }
 
-template <bool RUNS>
+template <bool RUNS, bool MODW>
 __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
 {
     const int lane = threadIdx.x;
@@ -628,7 +625,7 @@ __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
     int status = AIM_PAIR_OK;
     if constexpr (RUNS) {
         RunCollector<1> coll(plen + tlen - 1, reinterpret_cast<uint32_t *>(hreg + c.runs_off), c.runs_cap);
-        if (walk) status = group_tb_walk(tab, pool, final_score / U, plen, tlen, X, OE, E, coll);
+        if (walk) status = group_tb_walk<MODW>(c, tab, pool, final_score / U, plen, tlen, X, OE, E, coll);
         coll.flush();
         if (coll.n == 0) {   // nothing inside [0, end): edit_cigar_print still prints operations[begin_offset] = 'M'
             coll.cur_op = (uint32_t)'M'; coll.cur_len = 1u;
@@ -641,7 +638,7 @@ __global__ __launch_bounds__(64) void wfa_group_tb_kernel(KArgs a, GroupCfg c)
         sink.cap = 2 * rs;
         sink.pos = plen + tlen - 1;                       // edit_cigar_allocate, wfa.c:57-67
         if (walk) {
-            status = group_tb_walk(tab, pool, final_score / U, plen, tlen, X, OE, E, sink);
+            status = group_tb_walk<MODW>(c, tab, pool, final_score / U, plen, tlen, X, OE, E, sink);
             if (status == AIM_PAIR_OK) ++sink.pos;
         }
         if (active) {
@@ -768,15 +765,15 @@ inline bool wfa_group_plan_rows(const aim_params_t &p, uint32_t n_pairs, const K
     if (kn.plan_debug)
         fprintf(stderr, "[aim plan] wfa_group G=%d ring_m=%d ring_e=%d wcap=%d pair_lds=%d B wg_lds=%zu B lds_fit=%zu per_cu=%u grid=%u wlds=%d unit=%d\n", g, ring_m, ring_e,
                 c->wcap, dw * 4, *lds, lds_fit, per_cu, gr, c->wlds, c->unit);
-    // BACKTRACE: the per-pair history region (GroupCfg). The pool holds, per score, the 3 * width cells the compute kernel
-    // stores; a wavefront is at most 2s+1 diagonals wide and at most what the LDS row admits (a pair beyond that leaves for
-    // the to-do list before anything of the offending score is stored).
+    // BACKTRACE: the per-pair history region (GroupCfg). One row of the pool per score (in units): narrow rows -- the image of the LDS
+    // row (wlds cells; a pair whose wavefront outgrows it leaves for the to-do list before anything of the offending score is stored);
+    // one home per diagonal -- row s holds the 2s+1 diagonals a wavefront of score s can reach at most.
     {
-        const int wmax = c->wlds == c->wcap ? c->wcap : c->wlds - 2;
-        uint64_t cells = 0;
-        for (int sc = 0; sc <= p.max_score + 1; ++sc) cells += (uint64_t)std::min(2 * sc + 1, wmax);
-        c->pool_off = (int)(sizeof(TbHead) + (size_t)(p.max_score + 2) * sizeof(TbRow));
-        c->pool_cap = (int)cells + 2;                         // cells of 8 bytes {M, I, D, -}
+        const uint64_t rows = (uint64_t)p.max_score / (uint64_t)c->unit + 2;
+        const uint64_t cells = c->wlds != c->wcap ? rows * (uint64_t)c->wlds : rows * rows;
+        if (cells * 8 > (1ull << 30)) return false;
+        c->pool_off = (int)(sizeof(TbHead) + (size_t)rows * sizeof(TbRow));
+        c->pool_cap = (int)cells;                             // cells of 8 bytes {M, I, D, -}
         c->runs_off = (c->pool_off + c->pool_cap * 8 + 15) & ~15;
         c->runs_cap = 2 * p.max_score + 16;
         c->hist_pair_bytes = (c->runs_off + c->runs_cap * 4 + 255) & ~255;
@@ -810,8 +807,13 @@ void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pa
 {
     (void)p;
     const uint32_t grid = (n_pairs + kWave - 1) / kWave;
-    if (ka.cig) hipLaunchKernelGGL((wfa_group_tb_kernel<true>), dim3(grid), dim3(kWave), 0, s, ka, c);
-    else hipLaunchKernelGGL((wfa_group_tb_kernel<false>), dim3(grid), dim3(kWave), 0, s, ka, c);
+    if (c.wmagic) {
+        if (ka.cig) hipLaunchKernelGGL((wfa_group_tb_kernel<true, true>), dim3(grid), dim3(kWave), 0, s, ka, c);
+        else hipLaunchKernelGGL((wfa_group_tb_kernel<false, true>), dim3(grid), dim3(kWave), 0, s, ka, c);
+    } else {
+        if (ka.cig) hipLaunchKernelGGL((wfa_group_tb_kernel<true, false>), dim3(grid), dim3(kWave), 0, s, ka, c);
+        else hipLaunchKernelGGL((wfa_group_tb_kernel<false, false>), dim3(grid), dim3(kWave), 0, s, ka, c);
+    }
 }
 #else
 void wfa_group_tb_launch(const aim_params_t &p, const GroupCfg &c, uint32_t n_pairs, const KArgs &ka, hipStream_t s);

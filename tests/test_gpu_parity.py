@@ -1252,7 +1252,7 @@ def test_fused_group_kernel_against_oracle(gpu, l, err, n, cost, bt):
             assert np.array_equal(out["res"]["score"], ores["score"])
 
 
-@pytest.mark.parametrize("env", [dict(AIM_GROUP_WLDS="64"), dict(AIM_SCRATCH_GB="3"), dict(AIM_GROUP_G="64"), dict(AIM_GROUP_G="2")])
+@pytest.mark.parametrize("env", [dict(AIM_GROUP_WLDS="64"), dict(AIM_SCRATCH_GB="4"), dict(AIM_GROUP_G="64"), dict(AIM_GROUP_G="2")])
 def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
     """The side roads of the fused group path: a narrow LDS window that pairs outgrow (they reach the general kernel through the
     to-do list: their packed rows are expanded for it and its ops rows are run-length encoded afterwards), a scratch bound that
@@ -1260,7 +1260,7 @@ def test_fused_group_kernel_todo_list_chunks_and_plans(gpu, monkeypatch, env):
     from aim_amd import engine
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    l, err, n = 1000, 0.05, (9600 if "AIM_SCRATCH_GB" in env else 1500)   # 9600 history regions of 178 KB (rows of 96) do not fit half of a 3 GB bound
+    l, err, n = 1000, 0.05, (12000 if "AIM_SCRATCH_GB" in env else 1500)   # 12 000 history regions of 193 KB (252 rows of 96 cells) do not fit half of a 4 GB bound: three chunks
     ms, rs = engine.launcher_sizes("wfa", l, err)
     req, pat, txt = engine.gen_pairs(17, 0, n, l, err, rs)
     pat[5, 17] = ord("N")
