@@ -28,6 +28,7 @@
 #include "dp_lane.hpp"
 #include "dp_wave.hpp"
 #include "dp_strip.hpp"
+#include "dp_reg.hpp"
 #include "batch_io.hpp"
 #include "genasm_wave.hpp"
 
@@ -55,7 +56,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6, K_DP_STRIP = 7 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6, K_DP_STRIP = 7, K_DP_REG = 8 };
 
 // What a launch is asked to consume / produce besides the default ABI (ASCII rows in, result_t + ops rows out). A plan
 // honours a mode bit only when its kernel can (Plan::pk / Plan::emits_runs); otherwise the caller runs the conversion
@@ -116,6 +117,8 @@ aim::Knobs read_knobs()
     k.dpl_seq_lds = env_int("AIM_DPL_SEQ_LDS", -1);
     k.dpl_no_reg = env_int("AIM_DPL_NO_REG", 0);
     k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
+    k.no_nw_reg = env_flag("AIM_NO_NW_REG");
+    k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
@@ -402,6 +405,39 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
                    ? AIM_OK
                    : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
     }
+    // NW short reads: the row in registers (dp_reg.hpp); pairs it cannot take (tail cells: plen >= tlen + 2, short outliers) reach
+    // nw_lane_kernel through a to-do list. [table slabs of max(grid) wavefronts | to-do region]
+    if (p.algo == AIM_ALGO_NW && !kn.no_nw_reg && !kn.force_dpwave && aim::nw_reg_supported(p)) {
+        Plan fb;
+        memset(&fb, 0, sizeof fb);
+        aim::Knobs kq = kn;
+        kq.dpl_seq_lds = 0;   // the to-do pass reads its pairs' rows from global memory (they are not consecutive)
+        if (!aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds))
+            return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+        const int npk = aim::nw_reg_npk(p.read_size);
+        const uint64_t slab = bt ? (uint64_t)aim::nw_reg_slab_bytes(npk, p.read_size) : 256;
+        // resident wavefronts: 174 (score-only) / 256 (with the table's stores) VGPRs at READ_SIZE <= 112, 141 / 209 at <= 80
+        uint32_t per_cu = npk <= 42 ? (bt ? 8u : 12u) : (bt ? 4u : 8u);
+        if (kn.nw_reg_per_cu > 0) per_cu = (uint32_t)kn.nw_reg_per_cu;
+        pl->lds = aim::nw_reg_lds_bytes(p);
+        per_cu = (uint32_t)std::min<size_t>(per_cu, aim::lds_workgroups_per_cu(pl->lds));
+        const uint32_t n_groups = (n_pairs + 63u) / 64u;
+        uint32_t g = aim::resident_grid(kn, per_cu);
+        const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
+        if (g > need) g = need < 8u ? 8u : need;
+        const uint64_t per = std::max<uint64_t>((slab + 255) & ~255ull, fb.scratch_per_wg);
+        while (g > 8 && per * g > budget / 2) g -= 8;
+        if (per * std::max(g, fb.grid) > budget) return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+        pl->kid = K_DP_REG;
+        pl->grid = g;
+        pl->block = 64;
+        pl->scratch_per_wg = per;
+        pl->fb_grid = fb.grid;
+        pl->fb_lds = fb.lds;
+        pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
+        pl->scratch_total = (size_t)(per * std::max(g, fb.grid)) + pl->todo_bytes;
+        return AIM_OK;
+    }
     // NW / SWG short reads: one pair per lane, flat DP table in per-wave HBM scratch
     pl->kid = K_DP_LANE;
     return aim::dp_lane_plan(p, n_pairs, budget, kn, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total,
@@ -418,6 +454,7 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
     case K_WFA_LANE_PK: return "wfa_lane_packed_kernel";
     case K_WFA_GROUP: return "wfa_group_kernel";
     case K_DP_LANE: return p_is_nw(&p) ? "nw_lane_kernel" : "swg_lane_kernel";
+    case K_DP_REG: return "nw_reg_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
     case K_DP_STRIP: return "dp_strip_kernel";
     case K_GENASM: return "genasm_wave_kernel";
@@ -435,6 +472,7 @@ int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint6
     else if (pl.kid == K_DP_STRIP) snprintf(extra, sizeof extra, " wavefronts_per_pair=%u cells_per_lane=%d", pl.block / 64, pl.strip_k);
     else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
     else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
+    else if (pl.kid == K_DP_REG) snprintf(extra, sizeof extra, " fb_grid=%u fb_lds=%zu", pl.fb_grid, pl.fb_lds);
     return snprintf(out, cap, "%s n=%u grid=%u block=%u lds=%zu scratch=%zu budget=%llu%s", kernel_name(pl, p), n_pairs, pl.grid,
                     pl.block, pl.lds, pl.scratch_total, (unsigned long long)budget, extra);
 }
@@ -672,6 +710,19 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     case K_DP_LANE:
         aim::dp_lane_launch(p, kn, pl.grid, pl.lds, pl.seq_lds, ka, stream);
         break;
+    case K_DP_REG: {
+        // [table slabs | to-do region]: count zeroed per launch; the register kernel; then nw_lane_kernel over the pairs it left
+        uint32_t *todo_d = reinterpret_cast<uint32_t *>((char *)d_scratch + (pl.scratch_total - pl.todo_bytes));
+        HIP_TRY(hipMemsetAsync(todo_d, 0, 64, stream));
+        ka.todo = todo_d;
+        aim::nw_reg_launch(p, pl.grid, pl.lds, ka, stream);
+        HIP_TRY(hipGetLastError());
+        aim::Knobs kq = kn;
+        kq.dpl_seq_lds = 0;
+        ka.dbg_lds_bytes = (uint32_t)pl.fb_lds;
+        aim::dp_lane_launch(p, kq, pl.fb_grid, pl.fb_lds, false, ka, stream);
+        break;
+    }
     case K_DP_WAVE:
         aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);
         break;
@@ -1333,9 +1384,10 @@ int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback
     if (!s.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
     *n_fallback = 0;
     const Plan &pl = s.plan_last;   // the plan the launch actually followed, not a re-plan
-    if ((pl.kid != K_WFA_GROUP && !pl.pack_first) || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
+    if ((pl.kid != K_WFA_GROUP && pl.kid != K_DP_REG && !pl.pack_first) || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
     HIP_TRY(hipSetDevice(d.dev));
-    HIP_TRY(hipMemcpy(n_fallback, s.d_scratch, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const char *count_at = static_cast<const char *>(s.d_scratch) + (pl.kid == K_DP_REG ? pl.scratch_total - pl.todo_bytes : 0);   // the to-do count
+    HIP_TRY(hipMemcpy(n_fallback, count_at, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return AIM_OK;
 }
 

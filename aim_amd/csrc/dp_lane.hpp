@@ -21,6 +21,7 @@
 
 #include <cstdlib>
 #include "aim_device.hpp"
+#include "wfa_lane.hpp"   // LANE_TODO_* (the to-do list layout)
 
 namespace aim {
 
@@ -101,7 +102,9 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
     int16_t *R = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));    // [(rs+1)][64]
     int16_t *tb = BT ? reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
-    const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
+    // to-do mode (a.todo set; SEQ == 0 only: rows are read from global memory per lane): the pairs nw_reg_kernel (dp_reg.hpp) left over
+    const uint32_t n_work = (SEQ == 0 && a.todo) ? a.todo[LANE_TODO_COUNT] : a.n_pairs;
+    const uint32_t n_groups = (n_work + kWave - 1) / kWave;
     // HBM table slab: 8 consecutive slab indices of a lane form one 16-B unit, units lane-interleaved. With S a multiple
     // of 8 and the +7 offset every chunk of the row loop (v0 = 1, 9, 17, ...) starts a unit, so a guard-free chunk is ONE
     // 16-B store per lane (1 KB per wavefront) instead of eight 2-B stores: the table stream was bound by store
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         uint32_t grp;
         if (!xcd_unit(n_groups, it, &grp)) break;
         const uint32_t pair0 = grp * kWave;
-        const uint32_t pair = pair0 + lane;
-        const bool active = pair < a.n_pairs;
-        const int n_rows = min((uint32_t)kWave, a.n_pairs - pair0);
+        const bool active = pair0 + lane < n_work;
+        const uint32_t pair = (SEQ == 0 && a.todo) ? (active ? a.todo[LANE_TODO_LIST + pair0 + lane] : 0u) : pair0 + lane;
+        const int n_rows = min((uint32_t)kWave, n_work - pair0);
         __syncthreads();
         if (SEQ_LDS || SEQ == 2) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
         __syncthreads();

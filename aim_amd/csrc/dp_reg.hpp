@@ -1,0 +1,292 @@
+// dp_reg.hpp -- Needleman-Wunsch on short reads with the DP ROW IN REGISTERS: one pair per lane, two int16 cells per VGPR, no LDS
+// in the cell loop (round 4).
+//
+// Same values as nw_compute (NW/DPU-WRAM/dpu/nw.c:109-153) for the pairs it takes; nw_lane_kernel (dp_lane.hpp: rows in LDS, the
+// reference's cell order literally) keeps the rest. dp_lane.hpp needs an LDS read and an LDS write per cell because the reference
+// indexes its table flat with stride W = tlen + 1 while v runs to plen (quirk N1): for plen > tlen cell (h, W) IS row h + 1's
+// boundary cell and cells right of it read the CURRENT row's first cells -- positions that differ per lane, which a register file
+// indexed by instruction cannot serve. But what N1 does depends on plen - tlen only:
+//     plen <= tlen      no cell is aliased: plain NW, boundary cells h * GAP_I;
+//     plen == tlen + 1  the row's LAST cell (h, W) is row h + 1's boundary cell B(h + 1) -- and is itself an ordinary cell: the cell
+//                       "above" it that the flat index makes it read is B(h), i.e. its own previous value;
+//     plen >= tlen + 2  tail cells that read the current row: left to nw_lane_kernel (to-do list; about a sixth of the pairs at e = 5 %).
+// Rows are RIGHT-ALIGNED in the registers: column v of a lane lives at the static index i = v + s0, s0 = RSK - 1 - plen, so that
+// every lane's last column -- the final score, and for plen == tlen + 1 the next row's boundary -- is the high half of the last
+// register, whatever plen is. The row's start is then per lane (index s0, the boundary cell), and it needs no handling at all:
+// indices left of s0 hold a large value INF (kept large by the recurrence itself), so at index s0 the substitution and the gap chain
+// deliver INF and the insertion delivers R_{h-1}[0] + GAP_I = h * GAP_I -- the boundary cell, computed like any other. Only lanes with
+// plen == tlen + 1 inject their boundary (one v_bfi per register of a 16-register window in which s0 must lie; lanes left of it: to-do).
+//
+// Per register (two cells): diagonal via v_perm over the previous row's registers, "characters differ" as v_pk_min_u16(p ^ t, 1) on
+// 16-bit-expanded pattern characters, substitution / insertion / their minimum as packed int16 (v_pk_mad / v_pk_add / v_pk_min), and the
+// in-row gap chain  m[v] = min(A[v], m[v-1] + GAP_D)  as two 16-bit steps: 10 VALU instructions, no LDS, no branch. nw_reg_supported()
+// (costs small enough that INF stays above every cell and below int16's end) is the plan's precondition.
+#pragma once
+
+#include <type_traits>
+
+#include "aim_device.hpp"
+#include "dp_lane.hpp"
+#include "dp_strip.hpp"   // dps2, pk_ne01, opaque
+#include "wfa_lane.hpp"   // LANE_TODO_*
+
+namespace aim {
+
+constexpr int kRegWin = 16;        // registers (32 indices) in which a row may start
+constexpr int kRegInf = 16000;     // the value left of a row's start
+
+// Shapes: NPK registers per row = 2 * NPK indices > READ_SIZE
+inline int nw_reg_npk(int read_size) { return read_size <= 80 ? 42 : (read_size <= 112 ? 58 : 0); }
+
+inline bool nw_reg_supported(const aim_params_t &p)
+{
+    if (p.algo != AIM_ALGO_NW || nw_reg_npk(p.read_size) == 0 || p.read_size < 40) return false;
+    if (p.gap_i <= 0 || p.gap_d <= 0 || p.mismatch <= 0) return false;
+    const long g = std::max(p.mismatch, std::max(p.gap_i, p.gap_d));
+    return (2L * p.read_size + 8) * g < 8000;   // every cell < 8000 < INF; INF + READ_SIZE * g < 24000: nothing wraps, nothing left of a row's start wins
+}
+
+template <int NPK, bool BT>
+__global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
+    constexpr int RSK = 2 * NPK;          // indices of a row of registers
+    constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
+    constexpr int TBS = (RSK + 7) & ~7;   // table slab: cells per row (units of 8 cells = 16 bytes)
+    const int lane = threadIdx.x;
+    const int rs = a.p.read_size, rsw = rs >> 2;
+    const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
+    uint32_t *todo = const_cast<uint32_t *>(a.todo);                     // OUT: pairs left to nw_lane_kernel ({count @0, pair ids @16..})
+    int16_t *tb = BT ? reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
+    const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
+    uint32_t ones = 0x00010001u;
+    opaque(ones);
+    const dps2 gi2 = dps_splat(GAP_I), x2 = dps_splat(MISMATCH);
+    const short gd = (short)GAP_D;
+    (void)gd;
+    // table slab: index i of row h of this lane at TB(TBS * h + i); 8 consecutive indices = one 16-byte unit, units lane-interleaved
+#define TBI(idx) ((((size_t)(idx) >> 3) * kWave + lane) * 8 + (size_t)((idx) & 7))
+#define TB(idx) tb[TBI(idx)]
+
+    for (uint32_t it = 0;; ++it) {
+        uint32_t grp;
+        if (!xcd_unit(n_groups, it, &grp)) break;
+        const uint32_t pair = grp * kWave + lane;
+        const bool active = pair < a.n_pairs;
+        aim_request_t rq;
+        rq.pattern_len = rq.text_len = 0; rq.padding = 0; rq.idx = 0;
+        if (active) rq = load_request(a, pair);
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const int W = tlen + 1;
+        // this kernel's pairs: no tail cells (plen <= tlen + 1) and a row start inside the window
+        const bool mine = active && plen >= 1 && tlen >= 1 && plen <= W && plen >= RSK - 2 * kRegWin;
+        {   // everything else: the to-do list of nw_lane_kernel (one atomic per wavefront)
+            const unsigned long long rest = __ballot(active && !mine);
+            if (rest) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(rest));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (active && !mine) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(rest & ((1ull << lane) - 1ull))] = pair;
+            }
+        }
+        if (!__any(mine)) continue;
+        const bool isW = mine && plen == W;                  // the row's last cell is the next row's boundary cell
+        const int s0 = mine ? RSK - 1 - plen : 0;             // index of column 0 (0 .. 31)
+        const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)(mine ? pair : grp * kWave) * rs);
+        const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)(mine ? pair : grp * kWave) * rs);
+        // the text row goes to LDS, transposed [dword][lane] (one conflict-free ds_read per ROW of the table), the pattern row into
+        // registers as 16-bit fields, shifted so that character v - 1 sits at index v + s0 (column v)
+        uint32_t *ldsT = reinterpret_cast<uint32_t *>(smem);
+        uint32_t pc[NPK];
+        __syncthreads();                                      // (single wavefront: the previous group's traceback is done with this area)
+#pragma unroll
+        for (int i = 0; i < NWD; ++i) {
+            const uint32_t pw = i < rsw ? gP[i] : 0u;
+            ldsT[i * kWave + lane] = i < rsw ? gT[i] : 0u;
+            if (2 * i < NPK) pc[2 * i] = __builtin_amdgcn_perm(0u, pw, 0x0c010c00u);           // bytes 0, 1 -> 16-bit fields (indices 4i, 4i + 1)
+            if (2 * i + 1 < NPK) pc[2 * i + 1] = __builtin_amdgcn_perm(0u, pw, 0x0c030c02u);   // bytes 2, 3
+        }
+        {   // shift right by d = s0 + 1 fields (1 .. 32): whole registers by 16 / 8 / 4 / 2 / 1, then one field
+            const int d = s0 + 1;
+#pragma unroll
+            for (int k = 16; k >= 1; k >>= 1) {
+                const bool on = ((d >> 1) & k) != 0;
+#pragma unroll
+                for (int j = NPK - 1; j >= 0; --j) { const uint32_t from = j - k >= 0 ? pc[j - k] : 0u; pc[j] = on ? from : pc[j]; }
+            }
+            if (d & 1) {
+#pragma unroll
+                for (int j = NPK - 1; j >= 0; --j) pc[j] = __builtin_amdgcn_alignbit(pc[j], j ? pc[j - 1] : 0u, 16);
+            }
+        }
+        // row 0: column v = v * GAP_D at index v + s0, INF left of it
+        uint32_t Mp[NPK];
+#pragma unroll
+        for (int j = 0; j < NPK; ++j) {
+            const int v0 = 2 * j - s0, v1 = v0 + 1;
+            Mp[j] = (uint32_t)(v0 >= 0 ? v0 * GAP_D : kRegInf) | ((uint32_t)(v1 >= 0 ? v1 * GAP_D : kRegInf) << 16);
+        }
+        // plen == tlen + 1: flat cell (0, W) IS cell (1, 0), and the column initialisation wrote 1 * GAP_I there after the row's (nw.c:116-128)
+        if (isW) Mp[NPK - 1] = (Mp[NPK - 1] & 0xffffu) | ((uint32_t)GAP_I << 16);
+        // isW lanes: where the boundary is injected (index s0 as an all-ones field of the window's registers)
+        uint32_t inj[kRegWin];
+#pragma unroll
+        for (int j = 0; j < kRegWin; ++j) {
+            inj[j] = isW ? ((2 * j == s0 ? 0x0000ffffu : 0u) | (2 * j + 1 == s0 ? 0xffff0000u : 0u)) : 0u;
+            opaque(inj[j]);
+        }
+        int score = 0;
+        const int hmax = -wave_min_i32(mine ? -tlen : 0);
+        if (BT && mine) {   // row 0 of the table
+#pragma unroll
+            for (int q = 0; q < (NPK + 3) / 4; ++q) {
+                typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                aim_u32x4 nv = {Mp[4 * q], 4 * q + 1 < NPK ? Mp[4 * q + 1] : 0u, 4 * q + 2 < NPK ? Mp[4 * q + 2] : 0u, 4 * q + 3 < NPK ? Mp[4 * q + 3] : 0u};
+                __builtin_nontemporal_store(nv, reinterpret_cast<aim_u32x4 *>(tb + TBI(8 * q)));
+            }
+        }
+        // one row: `src` (row h - 1) -> `dst` (row h). The row loop alternates between two register arrays: updated in place, the old value
+        // of register j - 1 (the next cell's diagonal input) had to be copied aside before every overwrite -- one v_mov per register and row.
+        // Registers entirely left of EVERY lane's row start hold INF and stay INF: the row starts at the first register that holds a
+        // lane's column 0 (J0: a compile-time lower bound of it, chosen per wavefront below).
+        uint32_t Mq[NPK];
+#pragma unroll
+        for (int j = 0; j < NPK; ++j) Mq[j] = j < kRegWin ? ((uint32_t)kRegInf * 0x00010001u) : 0u;
+        auto do_row = [&](auto j0_tag, int h, uint32_t (&src)[NPK], uint32_t (&dst)[NPK]) __attribute__((always_inline)) {
+            constexpr int J0 = decltype(j0_tag)::value;
+            const uint32_t tword = ldsT[((h - 1) >> 2) * kWave + lane];
+            const uint32_t tch2 = ((tword >> (((h - 1) & 3) * 8)) & 0xffu) * 0x00010001u;
+            // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, which the recurrence delivers by itself)
+            const uint32_t binj = (h == 1 ? (uint32_t)GAP_I : (src[NPK - 1] >> 16)) * 0x00010001u;
+            uint32_t rprev = (uint32_t)kRegInf << 16;         // the register left of this one: m[index - 1] in its HIGH half
+            uint32_t oldprev = (uint32_t)kRegInf << 16;
+#pragma unroll
+            for (int j = J0; j < NPK; ++j) {
+                const uint32_t oldj = src[j];
+                const dps2 diag = dps_from(__builtin_amdgcn_alignbit(oldj, oldprev, 16));   // {R_{h-1}[2j - 1], R_{h-1}[2j]}
+                const dps2 f = dps_from(pk_ne01(pc[j], tch2, ones));
+                const dps2 sub = f * x2 + diag;
+                const dps2 ins = dps_from(oldj) + gi2;
+                dps2 A = dps_min(sub, ins);
+                if (j < kRegWin) A = dps_from((binj & inj[j]) | (dps_bits(A) & ~inj[j]));
+                // the gap chain, two cells: lo = min(A.lo, m[index - 1] + GAP_D), hi = min(A.hi, lo + GAP_D), result packed {hi, lo}. SDWA by hand:
+                // the second minimum writes the HIGH half of the register that holds lo (dst_unused:UNUSED_PRESERVE) and the next register's
+                // first addition reads it from there -- as C the compiler keeps lo and hi in two registers and packs them with a v_perm.
+                uint32_t t1, res;   // (ONE asm statement: the compiler pads every asm statement with an s_nop)
+                asm("v_add_u16_sdwa %1, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                    "v_min_i16 %0, %3, %1\n\t"
+                    "v_add_u16 %1, %0, %4\n\t"
+                    "v_min_i16_sdwa %0, %3, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
+                    : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)), "v"((uint32_t)(uint16_t)gd));
+                dst[j] = res;
+                rprev = res;
+                oldprev = oldj;
+            }
+            if (h == tlen) score = (int)(dst[NPK - 1] >> 16); // R_tlen[plen]
+            if (BT && mine && h <= tlen) {                     // the row into the lane-interleaved table slab: four registers = one 16-byte store
+                const int row = TBS * h;
+#pragma unroll
+                for (int q = 0; q < (NPK + 3) / 4; ++q) {
+                    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                    aim_u32x4 nv = {dst[4 * q], 4 * q + 1 < NPK ? dst[4 * q + 1] : 0u, 4 * q + 2 < NPK ? dst[4 * q + 2] : 0u, 4 * q + 3 < NPK ? dst[4 * q + 3] : 0u};
+                    __builtin_nontemporal_store(nv, reinterpret_cast<aim_u32x4 *>(tb + TBI(row + 8 * q)));
+                }
+            }
+        };
+        auto rows = [&](auto j0_tag) __attribute__((always_inline)) {
+            for (int h = 1; h <= hmax; h += 2) {
+                do_row(j0_tag, h, Mp, Mq);
+                do_row(j0_tag, h + 1, Mq, Mp);                 // (a row past hmax computes on and is read by nobody)
+            }
+        };
+        // (Tried: compile-time variants of the row that skip the registers left of every lane's row start -- 4 .. 10 of 58, chosen per
+        // wavefront. Five copies of the row loop pushed the kernel from 178 to 256 VGPRs (one wavefront per SIMD): dropped.)
+        rows(std::integral_constant<int, 0>{});
+        if (!BT) {
+            if (mine) {
+                aim_result_t res;
+                res.max_operations = plen + tlen;
+                res.begin_offset = plen + tlen - 1;
+                res.end_offset = plen + tlen;
+                res.score = score;
+                res.status = AIM_PAIR_OK;
+                res.idx = rq.idx;
+                store_result(a, pair, res);
+            }
+            continue;
+        }
+        // nw_traceback (nw.c:67-107) over the slab, the walk of nw_lane_kernel (dp_lane.hpp) with this kernel's cell addresses: flat index
+        // -> (row, column) as there, column v of row h at TBS * h + v + s0 (boundary cells are cells of the row here). Ops staged in LDS
+        // (the text image is dead by now), copied out in 16-byte pieces.
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (mine) {
+            auto cell = [&](int f) -> int {
+                int hq = f / W, vq = f - hq * W;
+                if (hq > tlen) { vq = f - W * tlen; hq = tlen; }
+                else if (vq == 0 && hq >= 2 && plen >= W) { hq -= 1; vq = W; }
+                return (int)TB(TBS * hq + vq + s0);
+            };
+            int begin_offset = plen + tlen - 1;
+            const int end_offset = plen + tlen;
+            char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+            unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem);
+#define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
+            int sentinel = end_offset - 1;
+            int h = tlen, v = plen;
+            int c = cell(W * h + v);
+            while (h > 0 && v > 0) {
+                const int at = W * h + v;
+                const int cl = cell(at - 1), cu = cell(at - W), cd = cell(at - W - 1);
+                if (c == cl + GAP_D) { OPS(sentinel) = 'D'; --sentinel; --v; c = cl; }
+                else if (c == cu + GAP_I) { OPS(sentinel) = 'I'; --sentinel; --h; c = cu; }
+                else { OPS(sentinel) = (c == cd + MISMATCH) ? 'X' : 'M'; --sentinel; --h; --v; c = cd; }
+            }
+            while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+            while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
+            begin_offset = sentinel + 1;
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+                uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q * kWave + lane];
+            }
+#undef OPS
+            aim_result_t res;
+            res.max_operations = plen + tlen;
+            res.begin_offset = begin_offset;
+            res.end_offset = end_offset;
+            res.score = score;
+            res.status = AIM_PAIR_OK;
+            res.idx = rq.idx;
+            store_result(a, pair, res);
+        }
+    }
+#undef TB
+#undef TBI
+}
+
+// bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
+inline size_t nw_reg_slab_bytes(int npk, int read_size) { return (size_t)((2 * npk + 7) & ~7) * (size_t)(read_size + 2) * kWave * 2; }
+inline size_t nw_reg_lds_bytes(const aim_params_t &p) { const size_t t = (size_t)((2 * nw_reg_npk(p.read_size) + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave; return (p.flags & AIM_FLAG_BACKTRACE) ? std::max(t, o) : t; }
+
+// Kernels are instantiated in ONE translation unit (tu_dp_reg.hip defines AIM_TU_DP_REG); every other includer sees the declaration only.
+#ifdef AIM_TU_DP_REG
+void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    const int npk = nw_reg_npk(p.read_size);
+#define AIM_NWREG(N)                                                                                           \
+    do {                                                                                                       \
+        if (bt) hipLaunchKernelGGL((nw_reg_kernel<N, true>), dim3(grid), dim3(kWave), lds, s, ka);             \
+        else hipLaunchKernelGGL((nw_reg_kernel<N, false>), dim3(grid), dim3(kWave), lds, s, ka);               \
+    } while (0)
+    if (npk == 42) AIM_NWREG(42);
+    else if (npk == 58) AIM_NWREG(58);
+#undef AIM_NWREG
+}
+#else
+void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
+
+}  // namespace aim

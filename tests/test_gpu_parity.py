@@ -623,7 +623,7 @@ def test_dp_lane_all_length_relations(gpu):
     for algo, ms, kw in (("nw", 40, dict(backtrace=True)), ("nw", 40, dict()), ("swg", 40, dict(backtrace=True)),
                          ("swg", 200, dict(backtrace=True)), ("swg", 40, dict())):
         params = engine.make_params(algo, ms, 112, **kw)
-        assert capi.load().aim_kernel_name(C.byref(params)) in (b"nw_lane_kernel", b"swg_lane_kernel")
+        assert capi.load().aim_kernel_name(C.byref(params)) in (b"nw_reg_kernel", b"nw_lane_kernel", b"swg_lane_kernel")   # (nw_reg: nearly all of these pairs take its to-do list to nw_lane_kernel)
         _compare(algo, params, req, pat, txt, threads=4)
 
 
@@ -1512,3 +1512,40 @@ def test_wfa_adaptive_long_reads_on_the_group_kernel(gpu, l, err, n):
         s.submit(0, 0, req, packed=engine.pack_batch(req, pat, txt), cigar_runs_cap=cap)
         out = s.wait(0, 0)
     assert engine.format_output_runs(out["cig"], out["runs"]) == want
+
+
+@pytest.mark.parametrize("l,err", [(100, 0.01), (100, 0.05), (100, 0.10), (70, 0.02), (60, 0.10), (90, 0.03), (104, 0.0)])
+@pytest.mark.parametrize("bt", [False, True])
+def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
+    """nw_reg_kernel (dp_reg.hpp: the DP row in registers, right-aligned, two int16 cells per VGPR) against the oracle --
+    all three length relations it takes (plen < / == / == tlen + 1: the aliased boundary cell of quirk N1), the pairs it hands to
+    nw_lane_kernel (plen >= tlen + 2, short outliers), READ_SIZE 72 .. 112, penalties other than the default, and equality with the
+    LDS-row kernel alone (AIM_NO_NW_REG=1)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("nw", l, max(err, 0.01))
+    n = 6000
+    req, pat, txt = engine.gen_pairs(7000 + l, 0, n, l, err, rs)
+    # outliers: a few short pairs and a few long tails
+    for i in range(0, n, 97):
+        req["pattern_len"][i] = max(1, l // 3)
+    for i in range(5, n, 131):
+        req["text_len"][i] = max(1, int(req["text_len"][i]) - 7)
+    for mism, gap in ((3, 4), (2, 5), (7, 3)):
+        params = engine.make_params("nw", ms, rs, backtrace=bt, mismatch=mism, gap=gap)
+        res, ops, _ = _compare("nw", params, req, pat, txt)
+        with engine.DeviceSet(1) as s:
+            s.configure(params, n)
+            s.push(0, req, pat, txt); s.launch(); s.pull(0)
+            if rs > 112:                                                     # (READ_SIZE 120: beyond the shapes the register kernel is built for)
+                assert s.plan_describe(0).startswith("nw_lane_kernel"), s.plan_describe(0)
+                continue
+            assert s.plan_describe(0).startswith("nw_reg_kernel"), s.plan_describe(0)
+            fb = s.fallback_pairs(0)
+            tails = int((req["pattern_len"] > req["text_len"] + 1).sum())
+            assert tails <= fb <= tails + n // 40, (fb, tails)               # the to-do list: tail pairs + the short outliers
+    monkeypatch.setenv("AIM_NO_NW_REG", "1")
+    params = engine.make_params("nw", ms, rs, backtrace=bt)
+    res2, ops2 = engine.align(params, req, pat, txt)
+    monkeypatch.delenv("AIM_NO_NW_REG")
+    res1, ops1 = engine.align(params, req, pat, txt)
+    assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
