@@ -416,8 +416,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
         const int npk = aim::nw_reg_npk(p.read_size);
         const uint64_t slab = bt ? (uint64_t)aim::nw_reg_slab_bytes(npk, p.read_size) : 256;
-        // resident wavefronts: 174 (score-only) / 256 (with the table's stores) VGPRs at READ_SIZE <= 112, 141 / 209 at <= 80
-        uint32_t per_cu = npk <= 42 ? (bt ? 8u : 12u) : (bt ? 4u : 8u);
+        uint32_t per_cu = npk <= 42 ? (bt ? 8u : 8u) : 8u;   // (178 - 255 VGPRs: two wavefronts per SIMD)
         if (kn.nw_reg_per_cu > 0) per_cu = (uint32_t)kn.nw_reg_per_cu;
         pl->lds = aim::nw_reg_lds_bytes(p);
         per_cu = (uint32_t)std::min<size_t>(per_cu, aim::lds_workgroups_per_cu(pl->lds));

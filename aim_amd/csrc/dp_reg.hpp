@@ -21,6 +21,14 @@
 // 16-bit-expanded pattern characters, substitution / insertion / their minimum as packed int16 (v_pk_mad / v_pk_add / v_pk_min), and the
 // in-row gap chain  m[v] = min(A[v], m[v-1] + GAP_D)  as two 16-bit steps: 10 VALU instructions, no LDS, no branch. nw_reg_supported()
 // (costs small enough that INF stays above every cell and below int16's end) is the plan's precondition.
+//
+// BACKTRACE: the table is TWO BITS per cell. nw_traceback (nw.c:67-107) asks of a cell c, in this order: c == left + GAP_D ('D')?
+// c == up + GAP_I ('I')? else 'X' / 'M' by c == diag + MISMATCH. For the pairs this kernel takes every cell the walk compares with
+// still holds the value the fill read (aliasing only touches boundary cells, and those are cells of the row here), so both answers
+// are known when the cell is computed: "not D" = the gap chain lost strictly (sign of A - chain), "not I" = the insertion lost
+// strictly (sign of sub - ins), and 'X' vs 'M' is the character comparison, which the walk redoes from the sequences. 116 cells of
+// a row are 8 dwords per lane instead of 232 bytes: with int16 cells the fill was bound by its own table stream (28.6 GB per 1 M pairs
+// at l = 100 = the time of nw_lane_kernel), and the walk follows ONE dependent load per step instead of three.
 #pragma once
 
 #include <type_traits>
@@ -53,7 +61,6 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
     debug_poison_lds(a, smem);
     constexpr int RSK = 2 * NPK;          // indices of a row of registers
     constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
-    constexpr int TBS = (RSK + 7) & ~7;   // table slab: cells per row (units of 8 cells = 16 bytes)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
@@ -65,9 +72,10 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
     const dps2 gi2 = dps_splat(GAP_I), x2 = dps_splat(MISMATCH);
     const short gd = (short)GAP_D;
     (void)gd;
-    // table slab: index i of row h of this lane at TB(TBS * h + i); 8 consecutive indices = one 16-byte unit, units lane-interleaved
-#define TBI(idx) ((((size_t)(idx) >> 3) * kWave + lane) * 8 + (size_t)((idx) & 7))
-#define TB(idx) tb[TBI(idx)]
+    // direction table: 8 dwords per row and lane (dword q: registers 8q .. 8q + 7, register k's two cells at bits 2k (low half) and
+    // 16 + 2k (high half); bit 0 "not D", bit 1 "not I"); 4 dwords = one 16-byte unit, units lane-interleaved
+    uint32_t *tbw = reinterpret_cast<uint32_t *>(tb);
+#define TBW(h, q) tbw[((size_t)((h) * 2 + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
 
     for (uint32_t it = 0;; ++it) {
         uint32_t grp;
@@ -138,14 +146,6 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
         }
         int score = 0;
         const int hmax = -wave_min_i32(mine ? -tlen : 0);
-        if (BT && mine) {   // row 0 of the table
-#pragma unroll
-            for (int q = 0; q < (NPK + 3) / 4; ++q) {
-                typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                aim_u32x4 nv = {Mp[4 * q], 4 * q + 1 < NPK ? Mp[4 * q + 1] : 0u, 4 * q + 2 < NPK ? Mp[4 * q + 2] : 0u, 4 * q + 3 < NPK ? Mp[4 * q + 3] : 0u};
-                __builtin_nontemporal_store(nv, reinterpret_cast<aim_u32x4 *>(tb + TBI(8 * q)));
-            }
-        }
         // one row: `src` (row h - 1) -> `dst` (row h). The row loop alternates between two register arrays: updated in place, the old value
         // of register j - 1 (the next cell's diagonal input) had to be copied aside before every overwrite -- one v_mov per register and row.
         // Registers entirely left of EVERY lane's row start hold INF and stay INF: the row starts at the first register that holds a
@@ -160,6 +160,10 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, which the recurrence delivers by itself)
             const uint32_t binj = (h == 1 ? (uint32_t)GAP_I : (src[NPK - 1] >> 16)) * 0x00010001u;
             uint32_t rprev = (uint32_t)kRegInf << 16;         // the register left of this one: m[index - 1] in its HIGH half
+            dps2 code[8];                                     // BACKTRACE: direction bits of the registers of the current group of eight
+            uint32_t dirw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { code[k] = dps_splat(0); dirw[k] = 0u; }
             uint32_t oldprev = (uint32_t)kRegInf << 16;
 #pragma unroll
             for (int j = J0; j < NPK; ++j) {
@@ -174,30 +178,55 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
                 // the second minimum writes the HIGH half of the register that holds lo (dst_unused:UNUSED_PRESERVE) and the next register's
                 // first addition reads it from there -- as C the compiler keeps lo and hi in two registers and packs them with a v_perm.
                 uint32_t t1, res;   // (ONE asm statement: the compiler pads every asm statement with an s_nop)
-                asm("v_add_u16_sdwa %1, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                    "v_min_i16 %0, %3, %1\n\t"
-                    "v_add_u16 %1, %0, %4\n\t"
-                    "v_min_i16_sdwa %0, %3, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
-                    : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)), "v"((uint32_t)(uint16_t)gd));
+                if (!BT) {
+                    asm("v_add_u16_sdwa %1, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                        "v_min_i16 %0, %3, %1\n\t"
+                        "v_add_u16 %1, %0, %4\n\t"
+                        "v_min_i16_sdwa %0, %3, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
+                        : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)), "v"((uint32_t)(uint16_t)gd));
+                } else {
+                    // the same chain with both gap candidates kept, packed {m[2j] + GAP_D, m[2j - 1] + GAP_D} (t1), for the direction bits (a
+                    // write with dst_sel needs one wait state before the next instruction reads the register: s_nop)
+                    asm volatile("v_add_u16_sdwa %1, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
+                        "v_min_i16 %0, %3, %1\n\t"
+                        "v_add_u16_sdwa %1, %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:DWORD\n\t"
+                        "s_nop 0\n\t"
+                        "v_min_i16_sdwa %0, %3, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1"
+                        : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)), "v"((uint32_t)(uint16_t)gd));
+                    const uint32_t sD = dps_bits(A - dps_from(t1)), sI = dps_bits(sub - ins);   // sign bits: chain lost strictly / insertion lost strictly
+                    const uint32_t neD = (sD >> 15) & 0x00010001u;
+                    uint32_t cj = ((sI >> 14) & 0x00020002u) | neD;
+                    opaque(cj);   // (volatile, like the chain above: the bits are made HERE -- left to itself the compiler makes all 58 registers' bits at the end of the row, with every register's sub / ins / A / chain live until then: ~400 VGPRs)
+                    code[j & 7] = dps_from(cj);
+                    if ((j & 7) == 7 || j == NPK - 1) {   // eight registers' codes -> one dword (v_pk_mad_u16: fields never carry into each other)
+                        const dps2 c4 = dps_splat(4), c16 = dps_splat(16), c256 = dps_splat(256);
+                        const dps2 c01 = code[1] * c4 + code[0], c23 = code[3] * c4 + code[2], c45 = code[5] * c4 + code[4], c67 = code[7] * c4 + code[6];
+                        dirw[j >> 3] = dps_bits((c67 * c16 + c45) * c256 + (c23 * c16 + c01));
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) code[k] = dps_splat(0);
+                    }
+                }
                 dst[j] = res;
                 rprev = res;
                 oldprev = oldj;
+
             }
             if (h == tlen) score = (int)(dst[NPK - 1] >> 16); // R_tlen[plen]
-            if (BT && mine && h <= tlen) {                     // the row into the lane-interleaved table slab: four registers = one 16-byte store
-                const int row = TBS * h;
-#pragma unroll
-                for (int q = 0; q < (NPK + 3) / 4; ++q) {
-                    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                    aim_u32x4 nv = {dst[4 * q], 4 * q + 1 < NPK ? dst[4 * q + 1] : 0u, 4 * q + 2 < NPK ? dst[4 * q + 2] : 0u, 4 * q + 3 < NPK ? dst[4 * q + 3] : 0u};
-                    __builtin_nontemporal_store(nv, reinterpret_cast<aim_u32x4 *>(tb + TBI(row + 8 * q)));
-                }
+            if (BT && mine && h <= tlen) {                     // the row's direction bits: two 16-byte stores per lane
+                typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]}, w1 = {dirw[4], dirw[5], dirw[6], dirw[7]};
+                __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0)));
+                __builtin_nontemporal_store(w1, reinterpret_cast<aim_u32x4 *>(&TBW(h, 4)));
             }
         };
         auto rows = [&](auto j0_tag) __attribute__((always_inline)) {
-            for (int h = 1; h <= hmax; h += 2) {
-                do_row(j0_tag, h, Mp, Mq);
-                do_row(j0_tag, h + 1, Mq, Mp);                 // (a row past hmax computes on and is read by nobody)
+            if (BT) {   // (with the direction bits the two-array form needs more than 256 VGPRs = one wavefront per SIMD: in place, one copy per register and row)
+                for (int h = 1; h <= hmax; ++h) do_row(j0_tag, h, Mp, Mp);
+            } else {
+                for (int h = 1; h <= hmax; h += 2) {
+                    do_row(j0_tag, h, Mp, Mq);
+                    do_row(j0_tag, h + 1, Mq, Mp);             // (a row past hmax computes on and is read by nobody)
+                }
             }
         };
         // (Tried: compile-time variants of the row that skip the registers left of every lane's row start -- 4 .. 10 of 58, chosen per
@@ -216,32 +245,26 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             }
             continue;
         }
-        // nw_traceback (nw.c:67-107) over the slab, the walk of nw_lane_kernel (dp_lane.hpp) with this kernel's cell addresses: flat index
-        // -> (row, column) as there, column v of row h at TBS * h + v + s0 (boundary cells are cells of the row here). Ops staged in LDS
-        // (the text image is dead by now), copied out in 16-byte pieces.
+        // nw_traceback (nw.c:67-107) over the direction bits (see the header): one dependent load per step; 'X' / 'M' from the sequences.
+        // Ops staged in LDS (the text image is dead by now), copied out in 16-byte pieces.
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (mine) {
-            auto cell = [&](int f) -> int {
-                int hq = f / W, vq = f - hq * W;
-                if (hq > tlen) { vq = f - W * tlen; hq = tlen; }
-                else if (vq == 0 && hq >= 2 && plen >= W) { hq -= 1; vq = W; }
-                return (int)TB(TBS * hq + vq + s0);
-            };
             int begin_offset = plen + tlen - 1;
             const int end_offset = plen + tlen;
             char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+            const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
             unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem);
 #define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
-            int c = cell(W * h + v);
             while (h > 0 && v > 0) {
-                const int at = W * h + v;
-                const int cl = cell(at - 1), cu = cell(at - W), cd = cell(at - W - 1);
-                if (c == cl + GAP_D) { OPS(sentinel) = 'D'; --sentinel; --v; c = cl; }
-                else if (c == cu + GAP_I) { OPS(sentinel) = 'I'; --sentinel; --h; c = cu; }
-                else { OPS(sentinel) = (c == cd + MISMATCH) ? 'X' : 'M'; --sentinel; --h; --v; c = cd; }
+                const int i = v + s0, j = i >> 1;
+                const uint32_t word = TBW(h, j >> 3);
+                const uint32_t code = (word >> (16 * (i & 1) + 2 * (j & 7))) & 3u;
+                if (!(code & 1u)) { OPS(sentinel) = 'D'; --sentinel; --v; }
+                else if (!(code & 2u)) { OPS(sentinel) = 'I'; --sentinel; --h; }
+                else { OPS(sentinel) = (pb[v - 1] != tbytes[h - 1]) ? 'X' : 'M'; --sentinel; --h; --v; }
             }
             while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
             while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
@@ -262,12 +285,11 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             store_result(a, pair, res);
         }
     }
-#undef TB
-#undef TBI
+#undef TBW
 }
 
 // bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
-inline size_t nw_reg_slab_bytes(int npk, int read_size) { return (size_t)((2 * npk + 7) & ~7) * (size_t)(read_size + 2) * kWave * 2; }
+inline size_t nw_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * 8 * 4 * kWave; }   // 8 dwords of direction bits per row and lane
 inline size_t nw_reg_lds_bytes(const aim_params_t &p) { const size_t t = (size_t)((2 * nw_reg_npk(p.read_size) + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave; return (p.flags & AIM_FLAG_BACKTRACE) ? std::max(t, o) : t; }
 
 // Kernels are instantiated in ONE translation unit (tu_dp_reg.hip defines AIM_TU_DP_REG); every other includer sees the declaration only.

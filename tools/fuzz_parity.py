@@ -49,11 +49,12 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cells", type=float, default=4e8, help="bound on n * l * l per case (oracle time)")
-    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa", "fused", "dp"], default="all",
+    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa", "fused", "dp", "dplane"], default="all",
                     help="'lane': stay inside the one-pair-per-lane kernels' eligibility window (wfa_lane_kernel, wfa_lane_packed_kernel); 'genasm': GenASM only; "
                          "'wfa': the general generator restricted to WFA (wfa_group / wfa_wave / wfa_lane); 'fused': WFA batches through aim_set_submit as PACKED "
                          "rows with the compact CIGAR back (one kernel per batch: wfa_lane_packed / wfa_group + traceback kernel), output text against the oracle's; "
-                         "'dp': NW / SWG long reads (dp_strip_kernel with every cells-per-lane shape, dp_wave_kernel)")
+                         "'dp': NW / SWG long reads (dp_strip_kernel with every cells-per-lane shape, dp_wave_kernel); "
+                         "'dplane': NW / SWG short reads (nw_reg_kernel + its to-do pass, nw_lane_kernel, swg_lane_kernel): every length relation, outliers, costs")
     a = ap.parse_args()
     rng = random.Random(a.seed)
     lib = capi.load()
@@ -78,6 +79,45 @@ def main():
             case = dict(algo="wfa", l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, **{k: int(v) for k, v in kw.items()})
             try:
                 err = compare("wfa", params, req, pat, txt)
+            except Exception as ex:
+                err = "exception: %r" % (ex,)
+            cases += 1
+            kernels[kn] = kernels.get(kn, 0) + 1
+            if err:
+                print(json.dumps(dict(case, ok=False)), flush=True)
+                print("MISMATCH:", err, flush=True)
+                return 1
+            continue
+        if a.focus == "dplane":
+            # short-read NW / SWG: READ_SIZE 40 .. 128, lengths anywhere inside it, per-pair length outliers (tails plen >= tlen + 2, short reads
+            # left of nw_reg_kernel's window), penalties on both sides of nw_reg_supported(), with and without the register kernel
+            algo = rng.choice(["nw", "nw", "nw", "swg"])
+            rs = rng.choice([40, 48, 64, 72, 80, 88, 96, 104, 112, 112, 112, 120, 128])
+            l = rng.randint(max(1, rs - 40), rs - 8)
+            e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10])
+            if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
+            cost = dict(mismatch=rng.randint(1, 9), gap=rng.choice([1, 2, 3, 4, 5, 9, 30, 60])) if (algo == "nw" and rng.random() < 0.5) else {}
+            n = rng.choice([1, 63, 64, 65, 1000, 4097, 9000])
+            bt = rng.random() < 0.6
+            ms = rng.randint(1, 60)
+            params = engine.make_params(algo, ms, rs, backtrace=bt, **cost)
+            for k in list(os.environ):
+                if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
+            env = {}
+            if rng.random() < 0.15: env["AIM_NO_NW_REG"] = "1"
+            if rng.random() < 0.2: env["AIM_NW_REG_PER_CU"] = rng.choice(["1", "3", "16"])
+            if rng.random() < 0.2: env["AIM_DPL_PER_CU"] = rng.choice(["1", "3", "12"])
+            os.environ.update(env)
+            req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
+            for _ in range(rng.choice([0, 3, 40])):                     # outliers: shorter patterns / texts (contents stay what they were)
+                i = rng.randrange(n)
+                if rng.random() < 0.5: req["pattern_len"][i] = rng.randint(0, int(req["pattern_len"][i]))
+                else: req["text_len"][i] = rng.randint(0, int(req["text_len"][i]))
+            if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")
+            kn = lib.aim_kernel_name(C.byref(params)).decode()
+            case = dict(algo=algo, l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, backtrace=int(bt), cost=cost, env=env)
+            try:
+                err = compare(algo, params, req, pat, txt)
             except Exception as ex:
                 err = "exception: %r" % (ex,)
             cases += 1
