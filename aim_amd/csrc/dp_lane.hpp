@@ -102,8 +102,10 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
     int16_t *R = reinterpret_cast<int16_t *>(imgP + (SEQ_LDS ? rsw * kWave : 0));    // [(rs+1)][64]
     int16_t *tb = BT ? reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
-    // to-do mode (a.todo set; SEQ == 0 only: rows are read from global memory per lane): the pairs nw_reg_kernel (dp_reg.hpp) left over
-    const uint32_t n_work = (SEQ == 0 && a.todo) ? a.todo[LANE_TODO_COUNT] : a.n_pairs;
+    // to-do mode (a.todo set; SEQ != 1: every lane reads its own pair's rows from global memory -- the listed pairs are not consecutive):
+    // the pairs nw_reg_kernel (dp_reg.hpp) left over
+    const bool todo_mode = SEQ != 1 && a.todo != nullptr;
+    const uint32_t n_work = todo_mode ? a.todo[LANE_TODO_COUNT] : a.n_pairs;
     const uint32_t n_groups = (n_work + kWave - 1) / kWave;
     // HBM table slab: 8 consecutive slab indices of a lane form one 16-B unit, units lane-interleaved. With S a multiple
     // of 8 and the +7 offset every chunk of the row loop (v0 = 1, 9, 17, ...) starts a unit, so a guard-free chunk is ONE
@@ -118,15 +120,16 @@ __global__ __launch_bounds__(64) void nw_lane_kernel(KArgs a)
         if (!xcd_unit(n_groups, it, &grp)) break;
         const uint32_t pair0 = grp * kWave;
         const bool active = pair0 + lane < n_work;
-        const uint32_t pair = (SEQ == 0 && a.todo) ? (active ? a.todo[LANE_TODO_LIST + pair0 + lane] : 0u) : pair0 + lane;
+        const uint32_t pair = todo_mode ? (active ? a.todo[LANE_TODO_LIST + pair0 + lane] : 0u) : pair0 + lane;
         const int n_rows = min((uint32_t)kWave, n_work - pair0);
         __syncthreads();
-        if (SEQ_LDS || SEQ == 2) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
+        if ((SEQ_LDS || SEQ == 2) && !todo_mode) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
         __syncthreads();
         dpl_u32x32 preg = {};
         if (SEQ == 2) {
+            const uint32_t *own = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
 #pragma unroll
-            for (int j = 0; j < 32; ++j) preg[j] = j < rsw ? imgP[j * kWave + lane] : 0u;
+            for (int j = 0; j < 32; ++j) preg[j] = j < rsw ? (todo_mode ? own[j] : imgP[j * kWave + lane]) : 0u;
             __syncthreads();                          // every lane holds its row before the row area is initialised
         }
         if (!active) continue;

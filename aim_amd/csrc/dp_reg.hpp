@@ -44,14 +44,22 @@ constexpr int kRegWin = 16;        // registers (32 indices) in which a row may 
 constexpr int kRegInf = 16000;     // the value left of a row's start
 
 // Shapes: NPK registers per row = 2 * NPK indices > READ_SIZE
-inline int nw_reg_npk(int read_size) { return read_size <= 80 ? 42 : (read_size <= 112 ? 58 : 0); }
+inline int nw_reg_npk(int read_size, bool bt = false) { return read_size <= 80 ? 42 : (read_size <= 112 ? 58 : (read_size <= 128 && !bt ? 66 : 0)); }   // (66: score-only -- with the direction bits it would not fit 256 VGPRs)
 
 inline bool nw_reg_supported(const aim_params_t &p)
 {
-    if (p.algo != AIM_ALGO_NW || nw_reg_npk(p.read_size) == 0 || p.read_size < 40) return false;
+    if (p.algo != AIM_ALGO_NW || nw_reg_npk(p.read_size, (p.flags & AIM_FLAG_BACKTRACE) != 0) == 0 || p.read_size < 40) return false;
     if (p.gap_i <= 0 || p.gap_d <= 0 || p.mismatch <= 0) return false;
     const long g = std::max(p.mismatch, std::max(p.gap_i, p.gap_d));
     return (2L * p.read_size + 8) * g < 8000;   // every cell < 8000 < INF; INF + READ_SIZE * g < 24000: nothing wraps, nothing left of a row's start wins
+}
+
+__host__ __device__ inline size_t nw_reg_lds_bytes(const aim_params_t &p)   // text image / ops staging + the pair queue (512 B)
+{
+    const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    const int npk = p.read_size <= 80 ? 42 : (p.read_size <= 112 ? 58 : 66);
+    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave;
+    return ((bt && o > t) ? o : t) + 512;
 }
 
 template <int NPK, bool BT>
@@ -77,32 +85,52 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
     uint32_t *tbw = reinterpret_cast<uint32_t *>(tb);
 #define TBW(h, q) tbw[((size_t)((h) * 2 + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
 
-    for (uint32_t it = 0;; ++it) {
-        uint32_t grp;
-        if (!xcd_unit(n_groups, it, &grp)) break;
-        const uint32_t pair = grp * kWave + lane;
-        const bool active = pair < a.n_pairs;
-        aim_request_t rq;
-        rq.pattern_len = rq.text_len = 0; rq.padding = 0; rq.idx = 0;
-        if (active) rq = load_request(a, pair);
-        const int plen = rq.pattern_len, tlen = rq.text_len;
-        const int W = tlen + 1;
-        // this kernel's pairs: no tail cells (plen <= tlen + 1) and a row start inside the window
-        const bool mine = active && plen >= 1 && tlen >= 1 && plen <= W && plen >= RSK - 2 * kRegWin;
-        {   // everything else: the to-do list of nw_lane_kernel (one atomic per wavefront)
-            const unsigned long long rest = __ballot(active && !mine);
-            if (rest) {
+    // Pairs are taken through a small LDS queue: groups of 64 consecutive pairs are classified (this kernel's / to-do list) and the
+    // kernel's own are queued; the row loop runs on 64 QUEUED pairs at a time. (Without it the to-do pairs' lanes idle through the whole
+    // table: a sixth of the lanes at e = 5 % -- the kernel was slower than nw_lane_kernel there.)
+    uint32_t *queue = reinterpret_cast<uint32_t *>(smem + nw_reg_lds_bytes(a.p) - 512);   // 128 entries behind the text / ops area
+    uint32_t qn = 0, it = 0;                                 // wave-uniform
+    bool more = true;
+    for (;;) {
+        while (qn < (uint32_t)kWave && more) {
+            uint32_t grp;
+            more = xcd_unit(n_groups, it, &grp);
+            if (!more) break;
+            ++it;
+            const uint32_t cand = grp * kWave + lane;
+            const bool act = cand < a.n_pairs;
+            aim_request_t rc;
+            rc.pattern_len = rc.text_len = 0; rc.padding = 0; rc.idx = 0;
+            if (act) rc = load_request(a, cand);
+            // this kernel's pairs: no tail cells (plen <= tlen + 1) and a row start inside the window
+            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 && rc.pattern_len >= RSK - 2 * kRegWin;
+            const unsigned long long rest = __ballot(act && !take), mask_below = (1ull << lane) - 1ull;
+            if (rest) {   // everything else: the to-do list of nw_lane_kernel (one atomic per wavefront)
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(rest));
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (active && !mine) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(rest & ((1ull << lane) - 1ull))] = pair;
+                if (act && !take) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(rest & mask_below)] = cand;
             }
+            const unsigned long long tk = __ballot(take);
+            if (take) queue[qn + (uint32_t)__builtin_popcountll(tk & mask_below)] = cand;
+            qn += (uint32_t)__builtin_popcountll(tk);
         }
-        if (!__any(mine)) continue;
+        if (qn == 0) break;
+        const uint32_t ntake = qn < (uint32_t)kWave ? qn : (uint32_t)kWave;
+        const bool mine = (uint32_t)lane < ntake;
+        const uint32_t pair = mine ? queue[lane] : 0u;
+        const uint32_t moved = (ntake + lane < qn) ? queue[ntake + lane] : 0u;   // the queue's remainder moves to its front (same-wave LDS traffic is ordered)
+        if (ntake + lane < qn) queue[lane] = moved;
+        qn -= ntake;
+        aim_request_t rq;
+        rq.pattern_len = rq.text_len = 0; rq.padding = 0; rq.idx = 0;
+        if (mine) rq = load_request(a, pair);
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const int W = tlen + 1;
         const bool isW = mine && plen == W;                  // the row's last cell is the next row's boundary cell
         const int s0 = mine ? RSK - 1 - plen : 0;             // index of column 0 (0 .. 31)
-        const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)(mine ? pair : grp * kWave) * rs);
-        const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)(mine ? pair : grp * kWave) * rs);
+        const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);   // (idle lanes: pair 0's rows, read and ignored)
+        const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
         // the text row goes to LDS, transposed [dword][lane] (one conflict-free ds_read per ROW of the table), the pattern row into
         // registers as 16-bit fields, shifted so that character v - 1 sits at index v + s0 (column v)
         uint32_t *ldsT = reinterpret_cast<uint32_t *>(smem);
@@ -290,14 +318,13 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
 
 // bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
 inline size_t nw_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * 8 * 4 * kWave; }   // 8 dwords of direction bits per row and lane
-inline size_t nw_reg_lds_bytes(const aim_params_t &p) { const size_t t = (size_t)((2 * nw_reg_npk(p.read_size) + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave; return (p.flags & AIM_FLAG_BACKTRACE) ? std::max(t, o) : t; }
 
 // Kernels are instantiated in ONE translation unit (tu_dp_reg.hip defines AIM_TU_DP_REG); every other includer sees the declaration only.
 #ifdef AIM_TU_DP_REG
 void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-    const int npk = nw_reg_npk(p.read_size);
+    const int npk = nw_reg_npk(p.read_size, bt);
 #define AIM_NWREG(N)                                                                                           \
     do {                                                                                                       \
         if (bt) hipLaunchKernelGGL((nw_reg_kernel<N, true>), dim3(grid), dim3(kWave), lds, s, ka);             \
@@ -305,6 +332,7 @@ void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs
     } while (0)
     if (npk == 42) AIM_NWREG(42);
     else if (npk == 58) AIM_NWREG(58);
+    else if (npk == 66 && !bt) hipLaunchKernelGGL((nw_reg_kernel<66, false>), dim3(grid), dim3(kWave), lds, s, ka);
 #undef AIM_NWREG
 }
 #else

@@ -32,6 +32,10 @@ CONFIGS = {
     "wfa_l4000_e2_score": dict(algo="wfa", l=4000, e=0.02, n=1 << 14, kw=dict(reduce=True)),
     "nw_l100_e1_cigar": dict(algo="nw", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "nw_l100_e1_score": dict(algo="nw", l=100, e=0.01, n=1 << 20, kw=dict()),
+    "nw_l100_e5_score": dict(algo="nw", l=100, e=0.05, n=1 << 20, kw=dict()),
+    "nw_l100_e5_cigar": dict(algo="nw", l=100, e=0.05, n=1 << 20, kw=dict(backtrace=True)),
+    "nw_l100_e10_score": dict(algo="nw", l=100, e=0.10, n=1 << 20, kw=dict()),
+    "nw_l70_e2_score": dict(algo="nw", l=70, e=0.02, n=1 << 20, kw=dict()),
     "swg_l100_e1_cigar": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "swg_l100_e1_score": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict()),
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
