@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--fetch-x2", action="store_true", help="apply the guide's gfx950 correction (16 B/lane coalesced streaming reads)")
     ap.add_argument("--io", default=None, help="wire layout tag recorded in the summary (bench.py matches it)")
     ap.add_argument("--note", default="")
+    ap.add_argument("--plan", default=None, help="plan line to record (default: the one the profiled program prints; pass it when the program "
+                                                 "prints another kernel's plan, e.g. bench.py's headline plan while the e2e leg's packed kernel is profiled)")
     ap.add_argument("--skip-first", type=int, default=0, help="ignore the first N launches of the kernel (warm-up)")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
@@ -55,10 +57,12 @@ def main():
                 continue
             if a.alg_bytes is None and "algorithmic_bytes" in j:
                 a.alg_bytes = float(j["algorithmic_bytes"])
-            if "plan" in j:
+            if "plan" in j and a.plan is None:
                 summary["plan"] = j["plan"]
-            if "config" in j and isinstance(j["config"], dict) and "plan" in j["config"]:
+            if "config" in j and isinstance(j["config"], dict) and "plan" in j["config"] and a.plan is None:
                 summary["plan"] = j["config"]["plan"]
+    if a.plan is not None:
+        summary["plan"] = a.plan
     durs, disp = [], None
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -72,6 +76,7 @@ def main():
     durs = [x[1] for x in sorted(durs)][a.skip_first:]
     if durs:
         summary["kernel"] = disp["kernel"]
+        disp["lds_note"] = "rocprofv3's LDS_Block_Size is the STATIC allocation; these kernels use dynamic LDS only -- its size is the `lds=` field of the plan line"
         summary["dispatch"] = disp
         summary["kernel_trace"] = {"launches": len(durs), "avg_us": sum(durs) / len(durs) / 1e3, "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3}
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):

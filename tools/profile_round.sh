@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats + PMC summaries for every BASELINE configuration's kernel (tools/pmc_summary.py: stats pass and PMC
 # passes are separate runs), then the kernel timers of every configuration of tools/bench_configs.py.
 # Results go to profiles/<round-dir>/ AND are mirrored under gpurun_out/ (the only directory gpurun copies back).
-R=${1:-r03}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
+R=${1:-r04}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 tools/pmc_summary.py --out $P/wfa_lane_pmc_summary.json --kernel wfa_lane_kernel --pairs 4194304 --alg-bytes 905968812 --fetch-x2 --io compact \
    --note "Cross-check: 4194304 pairs x (224 B rows + 8 B request) = 973.1 MB read, x 8 B result = 33.6 MB written." \
@@ -14,7 +14,8 @@ python3 tools/pmc_summary.py --out $P/wfa_group_pmc_summary.json --kernel wfa_gr
 python3 tools/pmc_summary.py --out $P/dp_strip_pmc_summary.json --kernel dp_strip_kernel --pairs 256 \
    --note "cfg4: SWG l=10000 e=1% with CIGAR, 256 pairs, column-strip pipeline; table stores are 16 B per lane (WRITE_SIZE exact), mixed-width reads: FETCH_SIZE kept raw." \
    -- python3 tools/bench_configs.py swg_l10000_e1_cigar_n256 > $O/pmc_dps.log 2>&1; tail -1 $O/pmc_dps.log
-python3 tools/pmc_summary.py --out $P/wfa_lane_packed_pmc_summary.json --kernel wfa_lane_packed_kernel --pairs 4194304 --fetch-x2 \
+python3 tools/pmc_summary.py --out $P/wfa_lane_packed_pmc_summary.json --kernel wfa_lane_packed_kernel --pairs 4194304 --fetch-x2 --alg-bytes 905968812 \
+   --plan "wfa_lane_packed_kernel n=4194304 (the e2e leg's plan: aim_set_plan_describe of the packed batch; bench.py prints the headline ASCII kernel's plan)" \
    --note "the drop-in path's kernel on packed batches (bench.py e2e leg, score-only): 4194304 pairs x (2 x 28 B packed rows + 8 B request) read, x 8 B written." \
    -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_lanepk.log 2>&1; tail -1 $O/pmc_lanepk.log
 python3 tools/pmc_summary.py --out $P/wfa_group_tb_pmc_summary.json --kernel wfa_group_tb_kernel --pairs 65536 \
@@ -23,6 +24,15 @@ python3 tools/pmc_summary.py --out $P/wfa_group_tb_pmc_summary.json --kernel wfa
 python3 tools/pmc_summary.py --out $P/genasm_wave_pmc_summary.json --kernel genasm_wave_kernel --pairs 4096 \
    --note "cfg5: GenASM l=100000 e=10% with CIGAR, 4096 pairs = 16 wavefronts per CU, LONG variant (parity unpinned)." \
    -- python3 tools/bench_configs.py genasm_l100000_e10_cigar_n4096 > $O/pmc_genasm.log 2>&1; tail -1 $O/pmc_genasm.log
+python3 tools/pmc_summary.py --out $P/nw_reg_pmc_summary.json --kernel nw_reg_kernel --pairs 1048576 \
+   --note "NW l=100 e=1% score-only, 1 Mi pairs: the DP row in registers (dp_reg.hpp); per-lane 112-byte rows read as dwords: FETCH_SIZE kept raw." \
+   -- python3 tools/bench_configs.py nw_l100_e1_score > $O/pmc_nwreg.log 2>&1; tail -1 $O/pmc_nwreg.log
+python3 tools/pmc_summary.py --out $P/nw_reg_cigar_pmc_summary.json --kernel nw_reg_kernel --pairs 1048576 \
+   --note "NW l=100 e=1% with CIGAR, 1 Mi pairs: two direction bits per cell (8 dwords per row and lane) instead of an int16 table." \
+   -- python3 tools/bench_configs.py nw_l100_e1_cigar > $O/pmc_nwregc.log 2>&1; tail -1 $O/pmc_nwregc.log
+python3 tools/pmc_summary.py --out $P/wfa_group_long_pmc_summary.json --kernel wfa_group_kernel --pairs 8192 \
+   --note "WFA-adaptive l=10000 e=1% (MAX_SCORE 500, READ_SIZE 10112) score-only, 8192 pairs: wfa_group_kernel G=32 since round 4 (wfa_wave_kernel before)." \
+   -- python3 tools/bench_configs.py wfa_l10000_e1_score > $O/pmc_grouplong.log 2>&1; tail -1 $O/pmc_grouplong.log
 python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
 python3 -c "
 import sys, json
