@@ -383,42 +383,4 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 
 constexpr uint64_t kGaSlabBytes = (uint64_t)(kGaW + 1) * 64 * 8;   // one wavefront's slow-path columns in HBM scratch
 
-// The LONG variant pays one 64-level pass per pair (the last window) for 16 instead of 11 wavefronts per CU. Same box, kernel ms of the
-// standard variant at 8 / at 11 per CU / LONG at 16 (tools/ga_sweep.py, e = 10 %): l=100 2.12 / 1.86 / 4.83; l=300 3.60 / 3.19 / 3.16;
-// l=1000 6.07 / 5.46 / 4.48; l=2000 6.19 / 5.38 / 4.33; l=3000 4.69 / 4.31 / 3.24; l=5000 7.74 / 7.12 / 5.27 -- LONG from ~15 windows per pair up.
-inline bool genasm_long(const aim_params_t &p, const Knobs &kn)
-{
-    return kn.ga_long >= 0 ? kn.ga_long != 0 : p.read_size >= 640;
-}
-
-inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
-{
-    const bool lg = genasm_long(p, kn);
-    *block = kWave;
-    *lds = lg ? (size_t)(kGlCols * 16 + kGlPm) * 8 + 64 : (size_t)kGaCols * kGaSlots * 8 + 64;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(16, lds_workgroups_per_cu(*lds));   // (the standard variant's 13 KB: 11; capped at 8 until round 3)
-    if (kn.ga_per_cu > 0) per_cu = (uint32_t)std::min<size_t>((size_t)kn.ga_per_cu, lds_workgroups_per_cu(*lds));   // residency sweeps
-    uint32_t g = resident_grid(kn, per_cu);
-    const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
-    if (g > need) g = need < 8u ? 8u : need;
-    *grid = g;
-}
-
-// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_GENASM); every other includer sees the declaration only.
-#ifdef AIM_TU_GENASM
-void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
-{
-    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-    if (genasm_long(p, kn)) {
-        if (bt) hipLaunchKernelGGL((genasm_wave_kernel<true, true>), dim3(grid), dim3(kWave), lds, s, ka);
-        else hipLaunchKernelGGL((genasm_wave_kernel<false, true>), dim3(grid), dim3(kWave), lds, s, ka);
-    } else {
-        if (bt) hipLaunchKernelGGL((genasm_wave_kernel<true, false>), dim3(grid), dim3(kWave), lds, s, ka);
-        else hipLaunchKernelGGL((genasm_wave_kernel<false, false>), dim3(grid), dim3(kWave), lds, s, ka);
-    }
-}
-#else
-void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
-#endif
-
 }  // namespace aim
