@@ -30,7 +30,7 @@
 #include "dp_strip.hpp"
 #include "dp_reg.hpp"
 #include "batch_io.hpp"
-#include "genasm_dual.hpp"
+#include "genasm_wave.hpp"
 
 namespace {
 
@@ -126,7 +126,6 @@ aim::Knobs read_knobs()
     k.group_unit1 = env_int("AIM_GROUP_UNIT1", 0);
     k.ga_long = env_int("AIM_GA_LONG", -1);
     k.ga_per_cu = env_int("AIM_GA_PER_CU", 0);
-    k.ga_dual = env_int("AIM_GA_DUAL", 0);
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
     k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;

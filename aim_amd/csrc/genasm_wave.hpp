@@ -45,6 +45,10 @@ __device__ __forceinline__ uint64_t ga_shr1(uint64_t v, uint64_t fill)
     const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), ctrl, 0xf, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
 }
+// Lanes of the one wavefront hand values to each other through LDS (masks written by lane j are read by lane d, columns written by lanes
+// 0..15 are read by all 64). The hardware executes a wavefront's LDS instructions in order, but the COMPILER reasons per thread and may
+// move a load above a store to a different address of the same thread: this stops it (no instruction is emitted).
+__device__ __forceinline__ void ga_lds_order() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ uint64_t ga_readlane(uint64_t v, int src)   // src wave-uniform
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
@@ -106,6 +110,7 @@ __device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t m
         Rs[ga_slot(n + lane) + 16] = ONES;
         uint64_t cur = ONES << lane;                     // R_n[d]
         Rs[ga_slot(n) + lane] = cur;
+        ga_lds_order();
         const uint64_t lane0 = lane == 0 ? ONES : 0ull;
         const uint64_t endbit = 1ull << (m - 1);
         uint64_t *rp = Rs + ga_slot(n - 1 + lane) + lane;                // my R slot of my column at step 0
@@ -145,78 +150,106 @@ __device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t m
             if (hit) break;
         }
     }
+    ga_lds_order();
     return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
 }
-// LONG variant (long reads: thousands of windows per pair, almost none of them the last). A window that is not the last one commits
-// kGaCommit = 40 characters, so its traceback never reads a column above 41: the sweep still runs over all n columns but keeps only
-// columns 41 .. 0 -- [56 .. -15] with the 15 padding columns either side that the skew needs -- and the pattern masks move to an array
-// of their own: 72 x 16 x 8 B + 96 x 8 B = 9.8 KB instead of 13 KB per wavefront, i.e. 16 wavefronts per CU instead of 12 (4 096 pairs
-// of BASELINE config 5 are resident at once). The first n - 42 steps, while even level 0 is above column 41, store nothing.
-// The pair's LAST window needs every column: it takes the 64-level path (one window in ~2 500).
+// LONG variant (long reads: thousands of windows per pair, almost all of them REGULAR: m = n = 64 and not the pair's last).
+//
+// (1) A window that is not the last one commits kGaCommit = 40 characters, so its traceback never reads a column above 41: the sweep
+// still runs over all 64 columns but keeps only columns 41 .. 0 -- [56 .. -15] with the 15 padding columns either side that the skew
+// needs -- and the pattern masks move to an array of their own. The first 22 steps, while even level 0 is above column 41, store nothing.
+//
+// (2) BANDED bit-vectors (round 4). The fast path stops at 15 edits, and an alignment of the window with <= 15 edits never leaves the
+// diagonals |a - i| <= 15 (a = text column, i = pattern position; the window's walk starts at (0, 0) and every edit moves it one diagonal
+// and costs one level). Follow one bit of the recurrence: bit q (pattern position i = 63 - q) of R_a[d] reads bit q-1 of column a+1 (match,
+// substitution: the SAME diagonal), bit q-1 of R_a[d-1] and bit q of R_{a+1}[d-1] (one diagonal away, one level down). So a bit on diagonal k
+// of level l depends on diagonals k-j .. k+j of level l-j only, and what the hit test (diagonal 0, level d0 <= 15) and the traceback (a cell
+// on diagonal k with |k| <= d0 - d at level d, its neighbours on k +- 1 at level d-1) read is a function of diagonals -15 .. +15 -- 31 bits.
+// The sweep therefore keeps, per column a, ONE 32-bit word whose bit b is bit q = b + 48 - a of the full vector (diagonal b - 15): in these
+// coordinates the "<< 1" of the terms that come from column a+1 disappears (the band slides with the column), the pattern-only edit keeps
+// its "<< 1" and the text-only edit becomes ">> 1". Bits shifted in at either end are garbage that moves one bit inwards per level -- at
+// level l bits b < l and b > 31 - l -- and the bits read at level l are l .. 30 - l (shown above). Positions past the pattern's end (q < 0)
+// are in the band for columns > 48; they hold 0 ("matches") as in the full vector, where "<< 1" shifts them in. The words are kept
+// COMPLEMENTED (c = ~R, bit set = "aligns"): AND-of-ORs becomes OR-of-ANDs, which the ISA has three-operand forms for (v_and_or_b32,
+// v_lshl_or_b32), and lane 0's missing neighbour is the DPP's bound_ctrl zero instead of an extra OR:
+//     c_a[d] = (c_{a+1}[d] & ~PM_a)  |  c_{a+1}[d-1]  |  (c_a[d-1] << 1)  |  (c_{a+1}[d-1] >> 1)
+// 5 VALU per step (one DPP move, shift-or, shift, and-or, or) instead of 14 on 64-bit pairs, 4 B instead of 8 B per kept level:
+// 72 x 16 x 4 B + 96 x 4 B = 5.0 KB of LDS per wavefront. Results are bit-identical to the full-width sweep wherever anything reads them
+// (tests/test_genasm.py; the 64-level path below stays full-width and is what any window outside these conditions takes: irregular,
+// the pair's last, or more than 15 edits).
 constexpr int kGlTop = kGaCommit + 1;                                 // highest column the traceback of a non-final window reads
 constexpr int kGlCols = 15 + kGlTop + 1 + 15;                         // columns 56 .. -15
 constexpr int kGlPm = kGaW + 16 + 16;                                 // pattern masks of columns 79 .. -16
+constexpr int kGlDiag = 15;                                           // band bit of the main diagonal
+constexpr size_t kGlLdsBytes = (size_t)(kGlCols * 16 + kGlPm) * 4 + 64;
 __device__ __forceinline__ int gl_slot(int col) { return (kGlTop + 15 - col) * 16; }   // descending, like ga_slot
 __device__ __forceinline__ int gl_pm(int col) { return kGlCols * 16 + (kGaW + 15 - col); }
-__device__ __forceinline__ uint64_t ga_dc16_long(int n_, int m_, int lane, uint64_t mypm, uint64_t *Rs)
+// Band word of column `col` from the full 64-bit "equal" mask eq (bit q set <=> p[63 - q] == t[col]), complemented-PM form: bit b = eq bit
+// (b + 48 - col); positions past the pattern's end (q < 0) read as set.
+__device__ __forceinline__ uint32_t gl_band_eq(uint64_t eq, int col)
 {
-    constexpr uint64_t ONES = ~0ull;
-    const int n = __builtin_amdgcn_readfirstlane(n_), m = __builtin_amdgcn_readfirstlane(m_);
-    if (lane < n) Rs[gl_pm(lane)] = mypm;
+    const int s = 48 - col;                              // off(col)
+    const uint64_t dn = eq >> (s & 63), up = (eq << (-s & 63)) | ((1ull << (-s & 63)) - 1ull);
+    return (uint32_t)(s >= 0 ? dn : up);
+}
+// One regular window (m = n = 64): levels 0..15 in lanes 0..15. myeq: lane j holds the band "equal" word of text column j. Returns the
+// ballot of the first level whose column 0 reports an alignment (0: none within 15 edits).
+__device__ __forceinline__ uint64_t ga_dc16_band(int lane, uint32_t myeq, uint32_t *Rb)
+{
+    constexpr int N = kGaW;
+    Rb[gl_pm(lane)] = myeq;
     uint64_t hit = 0;
     if (lane < 16) {
-        Rs[gl_pm(n + lane)] = ONES;
-        uint64_t cur = ONES << lane;                     // R_n[d]
-        if (n <= kGlTop + 15) Rs[gl_slot(n) + lane] = cur;
-        const uint64_t lane0 = lane == 0 ? ONES : 0ull;
-        const uint64_t endbit = 1ull << (m - 1);
-        const int nA = n - 1 > kGlTop ? n - 1 - kGlTop : 0;               // steps before level 0 reaches column 41 (wave-uniform)
-        uint64_t *rp = Rs + gl_slot(n - 1 - nA + lane) + lane;           // my R slot of my column at step nA
-        const uint64_t *pp = Rs + gl_pm(n - 1 + lane);                   // my column's pattern mask at step 0
-        auto shr1 = [](uint64_t v) -> uint64_t {         // lane d-1's value; lane 0 receives 0 (bound_ctrl), OR-ed away below
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x111, 0xf, 0xf, true);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x111, 0xf, 0xf, true);
-            return ((uint64_t)hi << 32) | lo;
+        Rb[gl_pm(N + lane)] = 0u;                        // columns 64 .. 79: "nothing matches" keeps a level that has not started at its initial value
+        ga_lds_order();
+        // lane d starts on column 63 + d; "column 64 + d" before it is the initial ~0 << d, in that column's band coordinates (bit b <-> q = b - 16 - d)
+        uint32_t c = (uint32_t)~(~0ull << (16 + 2 * lane));                          // ~R_{64+d}[d]
+        constexpr int nA = N - 1 - kGlTop;               // steps before level 0 reaches column 41
+        uint32_t *rp = Rb + gl_slot(N - 1 - nA + lane) + lane;                       // my slot of my column at step nA
+        const uint32_t *pp = Rb + gl_pm(N - 1 + lane);                               // my column's mask at step 0
+        auto shr1 = [](uint32_t v) -> uint32_t {         // lane d-1's value; lane 0 receives 0 = "no level below me adds anything"
+            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
         };
-        // one step (ga_dc16); `st` false: above column 41, nothing is kept
-        auto step = [&](const uint64_t &nb_prev, uint64_t &nb_cur, const uint64_t &pm_now, uint64_t &pm_next, int k, auto st) {
-            pm_next = pp[k + 1];
-            nb_cur = shr1(cur);
-            const uint64_t t = (((nb_prev & nb_cur) << 1) & nb_prev) | lane0;
-            cur = ((cur << 1) | pm_now) & t;
-            if constexpr (decltype(st)::value) rp[k * 16] = cur;
+        // one step; the roles of the two neighbour registers and of the two mask registers alternate (no copies). `st` false: above column 41
+        auto step = [&](const uint32_t &cp, uint32_t &cc, const uint32_t &eq_now, uint32_t &eq_next, int k, auto st) {
+            eq_next = pp[k + 1];                         // next step's mask: off the dependent chain
+            cc = shr1(c);                                // ~R_a[d-1] (lane d-1 one step ago); cp = ~R_{a+1}[d-1] (two steps ago)
+            const uint32_t e = (cc << 1) | cp;           // pattern-only edit, substitution
+            c = ((c & eq_now) | e) | (cp >> 1);          // match; text-only edit
+            if constexpr (decltype(st)::value) rp[k * 16] = c;
         };
-        uint64_t nbA = shr1(cur), nbB, pmA = pp[0], pmB;
+        uint32_t nbA = lane ? (uint32_t)~(~0ull << (15 + 2 * lane)) : 0u, nbB, eqA = pp[0], eqB;   // nbA: ~R_{64+d}[d-1]
         int u = 0;
         for (; u + 2 <= nA; u += 2) {
-            step(nbA, nbB, pmA, pmB, 0, std::false_type{});
-            step(nbB, nbA, pmB, pmA, 1, std::false_type{});
+            step(nbA, nbB, eqA, eqB, 0, std::false_type{});
+            step(nbB, nbA, eqB, eqA, 1, std::false_type{});
             pp += 2;
         }
         if (u < nA) {
-            step(nbA, nbB, pmA, pmB, 0, std::false_type{});
-            nbA = nbB; pmA = pmB;
+            step(nbA, nbB, eqA, eqB, 0, std::false_type{});
+            nbA = nbB; eqA = eqB;
             pp += 1;
         }
-        for (u = nA; u + 2 <= n - 1; u += 2) {           // no level has reached column 0 yet
-            step(nbA, nbB, pmA, pmB, 0, std::true_type{});
-            step(nbB, nbA, pmB, pmA, 1, std::true_type{});
+        for (u = nA; u + 2 <= N - 1; u += 2) {           // no level has reached column 0 yet
+            step(nbA, nbB, eqA, eqB, 0, std::true_type{});
+            step(nbB, nbA, eqB, eqA, 1, std::true_type{});
             rp += 2 * 16;
             pp += 2;
         }
-        if (u < n - 1) {
-            step(nbA, nbB, pmA, pmB, 0, std::true_type{});
-            nbA = nbB; pmA = pmB;
+        if (u < N - 1) {
+            step(nbA, nbB, eqA, eqB, 0, std::true_type{});
+            nbA = nbB; eqA = eqB;
             rp += 16; pp += 1;
         }
-        for (u = n - 1; u < n + 15; ++u) {               // level u - (n-1) completes column 0 in this step
-            step(nbA, nbB, pmA, pmB, 0, std::true_type{});
-            nbA = nbB; pmA = pmB;
+        for (u = N - 1; u < N + 15; ++u) {               // level u - 63 completes column 0 in this step
+            step(nbA, nbB, eqA, eqB, 0, std::true_type{});
+            nbA = nbB; eqA = eqB;
             rp += 16; pp += 1;
-            hit = __ballot(lane == u - (n - 1) && !(cur & endbit));
+            hit = __ballot(lane == u - (N - 1) && ((c >> kGlDiag) & 1u));
             if (hit) break;
         }
     }
+    ga_lds_order();
     return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
 }
 #ifdef AIM_GA_STAMPS   // diagnostic builds only: s_memtime per phase of a window, summed per pair, dumped into the pair's ops row
@@ -235,6 +268,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
     // dependent column chain with); the rare slow path (a window needing 16..63 edits) writes [kGaW + 1][64] to this
     // wavefront's slab of HBM scratch instead.
     uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);
+    uint32_t *Rb = reinterpret_cast<uint32_t *>(smem);   // LONG: banded 32-bit words (ga_dc16_band)
     uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
@@ -277,7 +311,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             // traceback never looks further.
             uint64_t hit = 0;
             if (!LONG) hit = ga_dc16(n, m, lane, mypm, Rs);
-            else if (!last) hit = ga_dc16_long(n, m, lane, mypm, Rs);   // (the last window's traceback may read every column: 64-level path)
+            else if (!last && m == kGaW && n == kGaW) hit = ga_dc16_band(lane, gl_band_eq(~mypm, lane), Rb);   // (any other window: 64-level path)
             const bool slow = !hit;            // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
             if (slow) {
@@ -312,8 +346,8 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 // the same tests in the same order as the step-by-step walk (oracle/genasm_oracle.c), without a second fetch.
                 auto walk = [&](auto slow_tag) {
                     constexpr bool SLOW = decltype(slow_tag)::value;
-                    auto Rf = [&](int col, int lvl) -> uint64_t { return SLOW ? Rg[col * 64 + lvl] : Rs[(LONG ? gl_slot(col) : ga_slot(col)) + lvl]; };
-                    const int amax = (LONG && !SLOW) ? min(n - 1, kGaCommit) : n - 1;   // LONG: columns above 41 were not kept (lanes clamped there are outside the commit range)
+                    auto Rf = [&](int col, int lvl) -> uint64_t { return SLOW ? Rg[col * 64 + lvl] : Rs[ga_slot(col) + lvl]; };
+                    const int amax = n - 1;
                     for (;;) {
                         const int ai = ca + lane, bi = cb + lane;
                         const bool inr = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
@@ -342,7 +376,37 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                         --d; ++dist;
                     }
                 };
-                if (slow) walk(std::true_type{}); else walk(std::false_type{});
+                // The same walk over the banded words of a regular window (LONG): m = n = 64, not the last window, so the walk ends on the
+                // commit bound; every lane's cell lies on the walk's diagonal k = ca - cb, whose band bit is 15 + k in column a+1 (pattern
+                // position b+1), 16 + k for position b of the same column and 14 + k for position b+1 of column a. Words are complemented:
+                // bit set = clear(r, b).
+                auto walk_band = [&]() {
+                    for (;;) {
+                        const int ai = ca + lane, bi = cb + lane;
+                        const bool inr = ai < kGaCommit && bi < kGaCommit;
+                        const int aic = min(ai, kGaCommit), bic = min(bi, kGaW - 1);   // columns above 41 were not kept (lanes clamped there are outside the commit range)
+                        const int dm1 = d > 0 ? d - 1 : 0;
+                        const uint32_t rn_d = Rb[gl_slot(aic + 1) + d], rn_dm1 = Rb[gl_slot(aic + 1) + dm1], rc_dm1 = Rb[gl_slot(aic) + dm1];
+                        const int pch = __builtin_amdgcn_ds_bpermute(bic << 2, pfwd), tch = __builtin_amdgcn_ds_bpermute(min(aic, kGaW - 1) << 2, tfwd);
+                        const int kb = kGlDiag + ca - cb;                     // wave-uniform, 0 .. 30
+                        const bool cm = inr && pch == tch && ((rn_d >> (kb & 31)) & 1u);
+                        int code = 0;
+                        if (d > 0) code = ((rn_dm1 >> (kb & 31)) & 1u) ? 'X' : ((rc_dm1 >> ((kb - 1) & 31)) & 1u) ? 'D' : ((rn_dm1 >> ((kb + 1) & 31)) & 1u) ? 'I' : 0;
+                        const uint64_t bad = ~__ballot(cm);
+                        const int run = bad ? (int)__builtin_ctzll(bad) : 64;
+                        wn += run; ca += run; cb += run;
+                        if (ca >= kGaCommit || cb >= kGaCommit) break;
+                        const int op = __builtin_amdgcn_readlane(code, run);
+                        if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen (the recurrence guarantees one rule applies)
+                        put(op);
+                        ca += op != 'D';
+                        cb += op != 'I';
+                        --d; ++dist;
+                    }
+                };
+                if (slow) walk(std::true_type{});
+                else if constexpr (LONG) walk_band();
+                else walk(std::false_type{});
             }
             AIM_GASTAMP(4);   // traceback
             if (BT) {   // the window's ops leave as coalesced byte stores
@@ -382,5 +446,43 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 }
 
 constexpr uint64_t kGaSlabBytes = (uint64_t)(kGaW + 1) * 64 * 8;   // one wavefront's slow-path columns in HBM scratch
+
+// The LONG variant pays one 64-level pass per pair (the last window) for 16 instead of 11 wavefronts per CU. Same box, kernel ms of the
+// standard variant at 8 / at 11 per CU / LONG at 16 (tools/ga_sweep.py, e = 10 %): l=100 2.12 / 1.86 / 4.83; l=300 3.60 / 3.19 / 3.16;
+// l=1000 6.07 / 5.46 / 4.48; l=2000 6.19 / 5.38 / 4.33; l=3000 4.69 / 4.31 / 3.24; l=5000 7.74 / 7.12 / 5.27 -- LONG from ~15 windows per pair up.
+inline bool genasm_long(const aim_params_t &p, const Knobs &kn)
+{
+    return kn.ga_long >= 0 ? kn.ga_long != 0 : p.read_size >= 640;
+}
+
+inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
+{
+    const bool lg = genasm_long(p, kn);
+    *block = kWave;
+    *lds = lg ? kGlLdsBytes : (size_t)kGaCols * kGaSlots * 8 + 64;
+    uint32_t per_cu = (uint32_t)std::min<size_t>(lg ? 32 : 16, lds_workgroups_per_cu(*lds));   // (the standard variant's 13 KB: 11; capped at 8 until round 3)
+    if (kn.ga_per_cu > 0) per_cu = (uint32_t)std::min<size_t>((size_t)kn.ga_per_cu, lds_workgroups_per_cu(*lds));   // residency sweeps
+    uint32_t g = resident_grid(kn, per_cu);
+    const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
+    if (g > need) g = need < 8u ? 8u : need;
+    *grid = g;
+}
+
+// Kernels are instantiated in ONE translation unit (tu_*.hip defines AIM_TU_GENASM); every other includer sees the declaration only.
+#ifdef AIM_TU_GENASM
+void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE;
+    if (genasm_long(p, kn)) {
+        if (bt) hipLaunchKernelGGL((genasm_wave_kernel<true, true>), dim3(grid), dim3(kWave), lds, s, ka);
+        else hipLaunchKernelGGL((genasm_wave_kernel<false, true>), dim3(grid), dim3(kWave), lds, s, ka);
+    } else {
+        if (bt) hipLaunchKernelGGL((genasm_wave_kernel<true, false>), dim3(grid), dim3(kWave), lds, s, ka);
+        else hipLaunchKernelGGL((genasm_wave_kernel<false, false>), dim3(grid), dim3(kWave), lds, s, ka);
+    }
+}
+#else
+void genasm_launch(const aim_params_t &p, const Knobs &kn, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
 
 }  // namespace aim

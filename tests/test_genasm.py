@@ -188,6 +188,41 @@ def test_genasm_long_variant_matches_oracle(gpu, monkeypatch, l, err, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("poison", [None, "165", "255"])
+def test_genasm_banded_sweep_at_the_band_edge(gpu, monkeypatch, poison):
+    """Round 4: regular windows of the LONG variant keep 32-bit banded words (diagonals -15 .. +16) instead of 64-bit vectors. Error rates of
+    15-25 % put windows at 10-15 edits -- alignments that reach the band's edge -- and just beyond (the 64-level path); indel-only edits drift
+    to one side of the band. Also run with LDS poisoned at kernel entry: the sweep hands masks and columns between lanes through LDS, and a
+    result that depends on what LDS held before is a missing ordering (found by tools/fuzz_parity.py --focus genasm under
+    AIM_DEBUG_POISON_LDS)."""
+    from aim_amd import engine
+    from oracle import oracle
+    monkeypatch.setenv("AIM_GA_LONG", "1")
+    if poison: monkeypatch.setenv("AIM_DEBUG_POISON_LDS", poison)
+    for l, err, n, seed in ((1000, 0.2, 625, 11), (700, 0.25, 300, 12), (2000, 0.15, 200, 13)):
+        rs = ((int(l * (1 + err)) + 8 + 7) // 8) * 8
+        req, pat, txt = engine.gen_pairs(seed, 0, n, l, err, rs)
+        rng = np.random.RandomState(seed)
+        for i in range(0, n, 5):     # deletions only: the text is the pattern with ~err of its bases dropped (the walk drifts to one side)
+            pl = int(req["pattern_len"][i])
+            keep = rng.rand(pl) >= err
+            t = pat[i, :pl][keep]
+            txt[i, :] = 0
+            txt[i, : len(t)] = t
+            req["text_len"][i] = len(t)
+        params = engine.make_params("genasm", 0, rs, backtrace=True)
+        res, ops = engine.align(params, req, pat, txt)
+        ores, oops, worst = oracle.align_batch(oracle.params("genasm", 0, rs, backtrace=True), req["pattern_len"], req["text_len"], pat, txt, nthreads=16)
+        assert worst == 0
+        for f in ("score", "end_offset", "status"):
+            assert np.array_equal(res[f], ores[f]), f
+        for i in range(n):
+            e = int(res["end_offset"][i])
+            assert np.array_equal(ops[i, :e], oops[i, :e]), i
+        _check_alignment(req, pat, txt, res, ops)
+
+
+@pytest.mark.gpu
 def test_genasm_compact_cigar_beyond_65535_runs_reports_overflow(gpu, tmp_path):
     """aim_cigar_t.n_runs is 16 bits. A long pair whose alignment alternates M / X has more runs than that: the device-side
     run-length encoder must flag AIM_CIGAR_OVERFLOW (aim_set_wait: AIM_ENOMEM) instead of storing a truncated count -- and the host CLI
