@@ -177,13 +177,18 @@ __device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t m
 // 72 x 16 x 4 B + 96 x 4 B = 5.0 KB of LDS per wavefront. Results are bit-identical to the full-width sweep wherever anything reads them
 // (tests/test_genasm.py; the 64-level path below stays full-width and is what any window outside these conditions takes: irregular,
 // the pair's last, or more than 15 edits).
-constexpr int kGlTop = kGaCommit + 1;                                 // highest column the traceback of a non-final window reads
-constexpr int kGlCols = 15 + kGlTop + 1 + 15;                         // columns 56 .. -15
-constexpr int kGlPm = kGaW + 16 + 16;                                 // pattern masks of columns 79 .. -16
+//
+// (3) The sweep as a SCAN over columns (round 4). In band coordinates the match term has no shift, so one level is a bitwise linear recurrence
+// along the columns,   c_a = (c_{a+1} & eq_a) | g_a   with   g_a[d] = c_{a+1}[d-1] | (c_a[d-1] << 1) | (c_{a+1}[d-1] >> 1),
+// i.e. a composition of the maps x -> (x & e) | g, which is associative: (e1, g1) then (e2, g2) = (e1 & e2, (g1 & e2) | g2). Lane j owns column
+// 63 - j and a level is ONE inclusive scan over the wavefront -- 4 DPP row_shr steps, row_bcast:15, row_bcast:31 -- instead of a walk down the
+// columns; the products of the eq words that the steps need do not depend on the level and are computed once per window (6 registers), so a
+// level costs: the neighbour column's word of the level below (one DPP wave_shr), g (3), 6 x (DPP move + and-or), the initial column folded in
+// (1), one store of the 64 columns, the hit test on lane 63 -- ~25 instructions with all 64 lanes busy, against 7 x (63 + d) for the skewed
+// 16-lane sweep, and levels beyond the first hit are never computed. No masks in LDS, no padding columns: 16 levels x 64 columns x 4 B = 4 KB.
 constexpr int kGlDiag = 15;                                           // band bit of the main diagonal
-constexpr size_t kGlLdsBytes = (size_t)(kGlCols * 16 + kGlPm) * 4 + 64;
-__device__ __forceinline__ int gl_slot(int col) { return (kGlTop + 15 - col) * 16; }   // descending, like ga_slot
-__device__ __forceinline__ int gl_pm(int col) { return kGlCols * 16 + (kGaW + 15 - col); }
+constexpr size_t kGlLdsBytes = (size_t)16 * kGaW * 4 + 64;
+__device__ __forceinline__ int gl_word(int col, int lvl) { return lvl * kGaW + (kGaW - 1 - col); }   // lane j stores column 63 - j
 // Band word of column `col` from the full 64-bit "equal" mask eq (bit q set <=> p[63 - q] == t[col]), complemented-PM form: bit b = eq bit
 // (b + 48 - col); positions past the pattern's end (q < 0) read as set.
 __device__ __forceinline__ uint32_t gl_band_eq(uint64_t eq, int col)
@@ -192,65 +197,47 @@ __device__ __forceinline__ uint32_t gl_band_eq(uint64_t eq, int col)
     const uint64_t dn = eq >> (s & 63), up = (eq << (-s & 63)) | ((1ull << (-s & 63)) - 1ull);
     return (uint32_t)(s >= 0 ? dn : up);
 }
-// One regular window (m = n = 64): levels 0..15 in lanes 0..15. myeq: lane j holds the band "equal" word of text column j. Returns the
-// ballot of the first level whose column 0 reports an alignment (0: none within 15 edits).
-__device__ __forceinline__ uint64_t ga_dc16_band(int lane, uint32_t myeq, uint32_t *Rb)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t gl_dpp(uint32_t fill, uint32_t v)   // lanes without a source (or outside the row mask) receive `fill`
 {
-    constexpr int N = kGaW;
-    Rb[gl_pm(lane)] = myeq;
-    uint64_t hit = 0;
-    if (lane < 16) {
-        Rb[gl_pm(N + lane)] = 0u;                        // columns 64 .. 79: "nothing matches" keeps a level that has not started at its initial value
-        ga_lds_order();
-        // lane d starts on column 63 + d; "column 64 + d" before it is the initial ~0 << d, in that column's band coordinates (bit b <-> q = b - 16 - d)
-        uint32_t c = (uint32_t)~(~0ull << (16 + 2 * lane));                          // ~R_{64+d}[d]
-        constexpr int nA = N - 1 - kGlTop;               // steps before level 0 reaches column 41
-        uint32_t *rp = Rb + gl_slot(N - 1 - nA + lane) + lane;                       // my slot of my column at step nA
-        const uint32_t *pp = Rb + gl_pm(N - 1 + lane);                               // my column's mask at step 0
-        auto shr1 = [](uint32_t v) -> uint32_t {         // lane d-1's value; lane 0 receives 0 = "no level below me adds anything"
-            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-        };
-        // one step; the roles of the two neighbour registers and of the two mask registers alternate (no copies). `st` false: above column 41
-        auto step = [&](const uint32_t &cp, uint32_t &cc, const uint32_t &eq_now, uint32_t &eq_next, int k, auto st) {
-            eq_next = pp[k + 1];                         // next step's mask: off the dependent chain
-            cc = shr1(c);                                // ~R_a[d-1] (lane d-1 one step ago); cp = ~R_{a+1}[d-1] (two steps ago)
-            const uint32_t e = (cc << 1) | cp;           // pattern-only edit, substitution
-            c = ((c & eq_now) | e) | (cp >> 1);          // match; text-only edit
-            if constexpr (decltype(st)::value) rp[k * 16] = c;
-        };
-        uint32_t nbA = lane ? (uint32_t)~(~0ull << (15 + 2 * lane)) : 0u, nbB, eqA = pp[0], eqB;   // nbA: ~R_{64+d}[d-1]
-        int u = 0;
-        for (; u + 2 <= nA; u += 2) {
-            step(nbA, nbB, eqA, eqB, 0, std::false_type{});
-            step(nbB, nbA, eqB, eqA, 1, std::false_type{});
-            pp += 2;
-        }
-        if (u < nA) {
-            step(nbA, nbB, eqA, eqB, 0, std::false_type{});
-            nbA = nbB; eqA = eqB;
-            pp += 1;
-        }
-        for (u = nA; u + 2 <= N - 1; u += 2) {           // no level has reached column 0 yet
-            step(nbA, nbB, eqA, eqB, 0, std::true_type{});
-            step(nbB, nbA, eqB, eqA, 1, std::true_type{});
-            rp += 2 * 16;
-            pp += 2;
-        }
-        if (u < N - 1) {
-            step(nbA, nbB, eqA, eqB, 0, std::true_type{});
-            nbA = nbB; eqA = eqB;
-            rp += 16; pp += 1;
-        }
-        for (u = N - 1; u < N + 15; ++u) {               // level u - 63 completes column 0 in this step
-            step(nbA, nbB, eqA, eqB, 0, std::true_type{});
-            nbA = nbB; eqA = eqB;
-            rp += 16; pp += 1;
-            hit = __ballot(lane == u - (N - 1) && ((c >> kGlDiag) & 1u));
-            if (hit) break;
-        }
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROWS, 0xf, false);
+}
+// One regular window (m = n = 64): eqcol = band "equal" word of text column `lane`. Returns the first level (0..15) whose column 0 reports an
+// alignment, -1 if none does; levels 0 .. that one are in Rb[gl_word(col, level)].
+__device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, uint32_t *Rb)
+{
+    constexpr uint32_t ONES = ~0u;
+    // lane j works on column 63 - j: the recurrence runs towards higher lanes, the direction DPP scans go
+    uint32_t e = (uint32_t)__builtin_amdgcn_ds_bpermute((kGaW - 1 - lane) << 2, (int)eqcol);
+    // inclusive AND-scan of eq; ek[k] = the product over this lane's segment BEFORE step k (what step k of the g-scan multiplies with)
+    uint32_t ek[6];
+    ek[0] = e; e &= gl_dpp<0x111, 0xf>(ONES, e);         // row_shr:1
+    ek[1] = e; e &= gl_dpp<0x112, 0xf>(ONES, e);         // row_shr:2
+    ek[2] = e; e &= gl_dpp<0x114, 0xf>(ONES, e);         // row_shr:4
+    ek[3] = e; e &= gl_dpp<0x118, 0xf>(ONES, e);         // row_shr:8
+    ek[4] = e; e &= gl_dpp<0x142, 0xa>(ONES, e);         // row_bcast:15 into rows 1 and 3
+    ek[5] = e; e &= gl_dpp<0x143, 0xc>(ONES, e);         // row_bcast:31 into rows 2 and 3
+    // level 0: c_a = c_64 & eq_63 & .. & eq_a, c_64[0] = ~(~0 << 0) in column 64's coordinates = the low 16 bits (positions past the pattern's end)
+    uint32_t c = e & 0xffffu;
+    Rb[lane] = c;
+    int d = 0;
+    for (;;) {
+        if ((__builtin_amdgcn_readlane((int)c, kGaW - 1) >> kGlDiag) & 1) break;       // column 0, pattern position 0
+        if (++d == 16) { d = -1; break; }
+        const uint32_t below = ~(ONES << (15 + d));      // c_64[d-1]
+        const uint32_t cp = gl_dpp<0x138, 0xf>(below, c);                               // wave_shr:1: c_{a+1}[d-1]; lane 0's neighbour is column 64
+        uint32_t g = ((c << 1) | cp) | (cp >> 1);        // pattern-only edit, substitution, text-only edit
+        g |= gl_dpp<0x111, 0xf>(0u, g) & ek[0];
+        g |= gl_dpp<0x112, 0xf>(0u, g) & ek[1];
+        g |= gl_dpp<0x114, 0xf>(0u, g) & ek[2];
+        g |= gl_dpp<0x118, 0xf>(0u, g) & ek[3];
+        g |= gl_dpp<0x142, 0xa>(0u, g) & ek[4];
+        g |= gl_dpp<0x143, 0xc>(0u, g) & ek[5];
+        c = (e & ~(ONES << (16 + d))) | g;               // the initial column c_64[d] through the whole product, then everything added on the way
+        Rb[d * kGaW + lane] = c;
     }
     ga_lds_order();
-    return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
+    return d;
 }
 #ifdef AIM_GA_STAMPS   // diagnostic builds only: s_memtime per phase of a window, summed per pair, dumped into the pair's ops row
 #define AIM_GASTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
@@ -268,7 +255,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
     // dependent column chain with); the rare slow path (a window needing 16..63 edits) writes [kGaW + 1][64] to this
     // wavefront's slab of HBM scratch instead.
     uint64_t *Rs = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *Rb = reinterpret_cast<uint32_t *>(smem);   // LONG: banded 32-bit words (ga_dc16_band)
+    uint32_t *Rb = reinterpret_cast<uint32_t *>(smem);   // LONG: banded 32-bit words (ga_dc16_scan)
     uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
@@ -311,7 +298,9 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             // traceback never looks further.
             uint64_t hit = 0;
             if (!LONG) hit = ga_dc16(n, m, lane, mypm, Rs);
-            else if (!last && m == kGaW && n == kGaW) hit = ga_dc16_band(lane, gl_band_eq(~mypm, lane), Rb);   // (any other window: 64-level path)
+            int dband = -1;
+            if (LONG && !last && m == kGaW && n == kGaW) dband = ga_dc16_scan(lane, gl_band_eq(~mypm, lane), Rb);   // (any other window: 64-level path)
+            if (dband >= 0) hit = 1ull << dband;
             const bool slow = !hit;            // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
             if (slow) {
@@ -386,7 +375,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                         const bool inr = ai < kGaCommit && bi < kGaCommit;
                         const int aic = min(ai, kGaCommit), bic = min(bi, kGaW - 1);   // columns above 41 were not kept (lanes clamped there are outside the commit range)
                         const int dm1 = d > 0 ? d - 1 : 0;
-                        const uint32_t rn_d = Rb[gl_slot(aic + 1) + d], rn_dm1 = Rb[gl_slot(aic + 1) + dm1], rc_dm1 = Rb[gl_slot(aic) + dm1];
+                        const uint32_t rn_d = Rb[gl_word(aic + 1, d)], rn_dm1 = Rb[gl_word(aic + 1, dm1)], rc_dm1 = Rb[gl_word(aic, dm1)];
                         const int pch = __builtin_amdgcn_ds_bpermute(bic << 2, pfwd), tch = __builtin_amdgcn_ds_bpermute(min(aic, kGaW - 1) << 2, tfwd);
                         const int kb = kGlDiag + ca - cb;                     // wave-uniform, 0 .. 30
                         const bool cm = inr && pch == tch && ((rn_d >> (kb & 31)) & 1u);

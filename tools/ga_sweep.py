@@ -18,8 +18,8 @@ def run(l, e, n):
         return best, s.plan_describe(0)
 
 
-for l, n in ((100, 1 << 18), (300, 1 << 17), (1000, 1 << 16), (2000, 1 << 15), (3000, 1 << 14), (5000, 1 << 14)):
-    for env in ({"AIM_GA_LONG": "0"}, {"AIM_GA_LONG": "0", "AIM_GA_PER_CU": "12"}, {"AIM_GA_LONG": "1"}, {"AIM_GA_LONG": "1", "AIM_GA_PER_CU": "12"}):
+for l, n in ((100, 1 << 18), (200, 1 << 17), (300, 1 << 17), (500, 1 << 16), (1000, 1 << 16), (2000, 1 << 15), (5000, 1 << 14), (10000, 1 << 13)):
+    for env in ({"AIM_GA_LONG": "0"}, {"AIM_GA_LONG": "1", "AIM_GA_PER_CU": "16"}, {"AIM_GA_LONG": "1", "AIM_GA_PER_CU": "24"}, {"AIM_GA_LONG": "1"}):
         for k in ("AIM_GA_LONG", "AIM_GA_PER_CU"): os.environ.pop(k, None)
         os.environ.update(env)
         ms_, plan = run(l, 0.10, n)
