@@ -203,8 +203,8 @@ __device__ __forceinline__ uint32_t gl_dpp(uint32_t fill, uint32_t v)   // lanes
     return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROWS, 0xf, false);
 }
 // One regular window (m = n = 64): eqcol = band "equal" word of text column `lane`. Returns the first level (0..15) whose column 0 reports an
-// alignment, -1 if none does; levels 0 .. that one are in Rb[gl_word(col, level)].
-__device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, uint32_t *Rb)
+// alignment, -1 if none does; levels 0 .. that one are in Rb[gl_word(col, level)] (lane j: column 63 - j).
+__device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, uint32_t *Rb, uint32_t &eq_own, uint32_t &c_own)
 {
     constexpr uint32_t ONES = ~0u;
     // lane j works on column 63 - j: the recurrence runs towards higher lanes, the direction DPP scans go
@@ -237,6 +237,8 @@ __device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, uint32_t *
         Rb[d * kGaW + lane] = c;
     }
     ga_lds_order();
+    eq_own = ek[0];                                      // for the traceback: this lane's column's eq word and its word of the hit level
+    c_own = c;
     return d;
 }
 #ifdef AIM_GA_STAMPS   // diagnostic builds only: s_memtime per phase of a window, summed per pair, dumped into the pair's ops row
@@ -299,7 +301,8 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             uint64_t hit = 0;
             if (!LONG) hit = ga_dc16(n, m, lane, mypm, Rs);
             int dband = -1;
-            if (LONG && !last && m == kGaW && n == kGaW) dband = ga_dc16_scan(lane, gl_band_eq(~mypm, lane), Rb);   // (any other window: 64-level path)
+            uint32_t eq_own = 0, c_own = 0;
+            if (LONG && !last && m == kGaW && n == kGaW) dband = ga_dc16_scan(lane, gl_band_eq(~mypm, lane), Rb, eq_own, c_own);   // (any other window: 64-level path)
             if (dband >= 0) hit = 1ull << dband;
             const bool slow = !hit;            // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
@@ -366,35 +369,39 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                     }
                 };
                 // The same walk over the banded words of a regular window (LONG): m = n = 64, not the last window, so the walk ends on the
-                // commit bound; every lane's cell lies on the walk's diagonal k = ca - cb, whose band bit is 15 + k in column a+1 (pattern
-                // position b+1), 16 + k for position b of the same column and 14 + k for position b+1 of column a. Words are complemented:
-                // bit set = clear(r, b).
-                auto walk_band = [&]() {
+                // commit bound. The lanes stay with their COLUMNS (lane j: column 63 - j, as in the sweep). Every cell of a run of matches lies
+                // on the walk's diagonal k = ca - cb, whose band bit is kb = 15 + k in every column, and "p[b] == t[a] and ok(a+1, b+1, d)" is
+                // bit kb of (c_{a+1}[d] & eq_a) -- the recurrence's own match term: one DPP shift of the level's words, one AND, one ballot,
+                // and the run is the string of set bits from column ca on (a count of leading ones). The edit after the run is decided by
+                // three bits of level d-1 at the one cell where the run stopped: two v_readlane of that level's words, the rest scalar.
+                // Words are complemented: bit set = clear(r, b). One LDS read per edit (the next level's words), nothing per match.
+                auto walk_cols = [&]() {
+                    uint32_t wd = c_own;                                      // c_a[d] of my column
+                    int kb = kGlDiag;                                         // wave-uniform, 0 .. 30
                     for (;;) {
-                        const int ai = ca + lane, bi = cb + lane;
-                        const bool inr = ai < kGaCommit && bi < kGaCommit;
-                        const int aic = min(ai, kGaCommit), bic = min(bi, kGaW - 1);   // columns above 41 were not kept (lanes clamped there are outside the commit range)
-                        const int dm1 = d > 0 ? d - 1 : 0;
-                        const uint32_t rn_d = Rb[gl_word(aic + 1, d)], rn_dm1 = Rb[gl_word(aic + 1, dm1)], rc_dm1 = Rb[gl_word(aic, dm1)];
-                        const int pch = __builtin_amdgcn_ds_bpermute(bic << 2, pfwd), tch = __builtin_amdgcn_ds_bpermute(min(aic, kGaW - 1) << 2, tfwd);
-                        const int kb = kGlDiag + ca - cb;                     // wave-uniform, 0 .. 30
-                        const bool cm = inr && pch == tch && ((rn_d >> (kb & 31)) & 1u);
-                        int code = 0;
-                        if (d > 0) code = ((rn_dm1 >> (kb & 31)) & 1u) ? 'X' : ((rc_dm1 >> ((kb - 1) & 31)) & 1u) ? 'D' : ((rn_dm1 >> ((kb + 1) & 31)) & 1u) ? 'I' : 0;
-                        const uint64_t bad = ~__ballot(cm);
-                        const int run = bad ? (int)__builtin_ctzll(bad) : 64;
+                        const uint32_t wn1 = gl_dpp<0x138, 0xf>(0u, wd);      // wave_shr:1: c_{a+1}[d] (column 64 is never asked for: a < 40)
+                        const uint64_t mm = __ballot(((wn1 & eq_own) >> kb) & 1u);
+                        const uint64_t sh = ~(mm << ca);                      // bit 63 = column ca, then ca + 1, ...: clear = the run goes on
+                        int run = sh ? (int)__builtin_clzll(sh) : 64;
+                        run = min(run, kGaCommit - max(ca, cb));              // cells with a < 40 and b < 40
                         wn += run; ca += run; cb += run;
                         if (ca >= kGaCommit || cb >= kGaCommit) break;
-                        const int op = __builtin_amdgcn_readlane(code, run);
-                        if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen (the recurrence guarantees one rule applies)
+                        if (d == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }    // cannot happen (the recurrence guarantees one rule applies)
+                        const uint32_t wl = Rb[(d - 1) * kGaW + lane];        // c_a[d-1] of my column
+                        const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)wl, kGaW - 2 - ca);   // column ca + 1
+                        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)wl, kGaW - 1 - ca);   // column ca
+                        const int op = ((s1 >> kb) & 1u) ? 'X' : ((s0 >> ((kb - 1) & 31)) & 1u) ? 'D' : ((s1 >> ((kb + 1) & 31)) & 1u) ? 'I' : 0;
+                        if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen
                         put(op);
                         ca += op != 'D';
                         cb += op != 'I';
+                        kb = kGlDiag + ca - cb;
                         --d; ++dist;
+                        wd = wl;
                     }
                 };
                 if (slow) walk(std::true_type{});
-                else if constexpr (LONG) walk_band();
+                else if constexpr (LONG) walk_cols();
                 else walk(std::false_type{});
             }
             AIM_GASTAMP(4);   // traceback
