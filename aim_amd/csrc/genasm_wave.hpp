@@ -153,13 +153,10 @@ __device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t m
     ga_lds_order();
     return __builtin_amdgcn_readfirstlane((uint32_t)hit) | ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(hit >> 32)) << 32);
 }
-// LONG variant (long reads: thousands of windows per pair, almost all of them REGULAR: m = n = 64 and not the pair's last).
+// LONG variant (long reads: thousands of windows per pair, almost all of them REGULAR: m = n = 64 and not the pair's last). Regular windows
+// take the path below; every other window -- irregular, the pair's last, or more than 15 edits -- takes the full-width 64-level path.
 //
-// (1) A window that is not the last one commits kGaCommit = 40 characters, so its traceback never reads a column above 41: the sweep
-// still runs over all 64 columns but keeps only columns 41 .. 0 -- [56 .. -15] with the 15 padding columns either side that the skew
-// needs -- and the pattern masks move to an array of their own. The first 22 steps, while even level 0 is above column 41, store nothing.
-//
-// (2) BANDED bit-vectors (round 4). The fast path stops at 15 edits, and an alignment of the window with <= 15 edits never leaves the
+// (1) BANDED bit-vectors (round 4). The fast path stops at 15 edits, and an alignment of the window with <= 15 edits never leaves the
 // diagonals |a - i| <= 15 (a = text column, i = pattern position; the window's walk starts at (0, 0) and every edit moves it one diagonal
 // and costs one level). Follow one bit of the recurrence: bit q (pattern position i = 63 - q) of R_a[d] reads bit q-1 of column a+1 (match,
 // substitution: the SAME diagonal), bit q-1 of R_a[d-1] and bit q of R_{a+1}[d-1] (one diagonal away, one level down). So a bit on diagonal k
@@ -171,14 +168,12 @@ __device__ __forceinline__ uint64_t ga_dc16(int n_, int m_, int lane, uint64_t m
 // level l bits b < l and b > 31 - l -- and the bits read at level l are l .. 30 - l (shown above). Positions past the pattern's end (q < 0)
 // are in the band for columns > 48; they hold 0 ("matches") as in the full vector, where "<< 1" shifts them in. The words are kept
 // COMPLEMENTED (c = ~R, bit set = "aligns"): AND-of-ORs becomes OR-of-ANDs, which the ISA has three-operand forms for (v_and_or_b32,
-// v_lshl_or_b32), and lane 0's missing neighbour is the DPP's bound_ctrl zero instead of an extra OR:
+// v_lshl_or_b32, v_or3_b32):
 //     c_a[d] = (c_{a+1}[d] & ~PM_a)  |  c_{a+1}[d-1]  |  (c_a[d-1] << 1)  |  (c_{a+1}[d-1] >> 1)
-// 5 VALU per step (one DPP move, shift-or, shift, and-or, or) instead of 14 on 64-bit pairs, 4 B instead of 8 B per kept level:
-// 72 x 16 x 4 B + 96 x 4 B = 5.0 KB of LDS per wavefront. Results are bit-identical to the full-width sweep wherever anything reads them
-// (tests/test_genasm.py; the 64-level path below stays full-width and is what any window outside these conditions takes: irregular,
-// the pair's last, or more than 15 edits).
+// Results are bit-identical to the full-width sweep wherever anything reads them (tests/test_genasm.py, tools/fuzz_parity.py --focus genasm).
+// First version: the round-3 skewed 16-lane sweep on these words, 5 instead of 14 VALU per step: 25.4 -> 13.9 ms per 4 096 pairs of 100 kb.
 //
-// (3) The sweep as a SCAN over columns (round 4). In band coordinates the match term has no shift, so one level is a bitwise linear recurrence
+// (2) The sweep as a SCAN over columns (round 4: 13.9 -> 9.1 ms). In band coordinates the match term has no shift, so one level is a bitwise linear recurrence
 // along the columns,   c_a = (c_{a+1} & eq_a) | g_a   with   g_a[d] = c_{a+1}[d-1] | (c_a[d-1] << 1) | (c_{a+1}[d-1] >> 1),
 // i.e. a composition of the maps x -> (x & e) | g, which is associative: (e1, g1) then (e2, g2) = (e1 & e2, (g1 & e2) | g2). Lane j owns column
 // 63 - j and a level is ONE inclusive scan over the wavefront -- 4 DPP row_shr steps, row_bcast:15, row_bcast:31 -- instead of a walk down the
@@ -235,6 +230,8 @@ __device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, uint32_t *
         g |= gl_dpp<0x143, 0xc>(0u, g) & ek[5];
         c = (e & ~(ONES << (16 + d))) | g;               // the initial column c_64[d] through the whole product, then everything added on the way
         Rb[d * kGaW + lane] = c;
+        // (written out as v_and_b32_dpp + v_or_b32 per step -- 18 instead of 29 instructions per level -- this loop is SLOWER: 8.4 against 7.95 ms
+        // per 4 096 pairs on the same box, profiles/r04/genasm_notes.txt. The compiler's v_mov / v_mov_dpp / v_and_or triplets stay.)
     }
     ga_lds_order();
     eq_own = ek[0];                                      // for the traceback: this lane's column's eq word and its word of the hit level
@@ -283,7 +280,8 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const bool last = (m == plen - pi) && (n == tlen - ti);
             // lane j: p[m-1-j] (reversed, for the pattern masks), p[j] and t[j] (forward, for the traceback)
             const int prev = lane < m ? (int)gP[pi + m - 1 - lane] : 0x100;     // 0x100 never equals a byte
-            const int pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
+            int pfwd = 0x200;                                               // (LONG: only the 64-level path reads it -- loaded there)
+            if (!LONG) pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
             const int tfwd = lane < n ? (int)gT[ti + lane] : 0x300;
             AIM_GASTAMP(0);   // window characters from HBM
             // lane j: PM of text column j -- bit i = 0 <=> p[m-1-i] == t[j] -- from one ballot per distinct character
@@ -307,6 +305,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const bool slow = !hit;            // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
             if (slow) {
+                if (LONG) pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
                 // SLOW PATH (a window that needs 16..63 edits): all 64 levels, columns to this wavefront's HBM slab
                 const uint64_t R = ga_dc<true>(n, lane, mypm, Rg);
                 hit = __ballot(!((R >> (m - 1)) & 1ull));
@@ -443,12 +442,13 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
 
 constexpr uint64_t kGaSlabBytes = (uint64_t)(kGaW + 1) * 64 * 8;   // one wavefront's slow-path columns in HBM scratch
 
-// The LONG variant pays one 64-level pass per pair (the last window) for 16 instead of 11 wavefronts per CU. Same box, kernel ms of the
-// standard variant at 8 / at 11 per CU / LONG at 16 (tools/ga_sweep.py, e = 10 %): l=100 2.12 / 1.86 / 4.83; l=300 3.60 / 3.19 / 3.16;
-// l=1000 6.07 / 5.46 / 4.48; l=2000 6.19 / 5.38 / 4.33; l=3000 4.69 / 4.31 / 3.24; l=5000 7.74 / 7.12 / 5.27 -- LONG from ~15 windows per pair up.
+// The LONG variant sends every window that is not regular (the pair's last one, and one or two before it) through the 64-level path and runs
+// the regular ones 2-3x faster. Same box, kernel ms standard / LONG (tools/ga_sweep.py, e = 10 %, profiles/r04/ga_sweep.txt): l=100 1.86 / 4.86;
+// l=200 2.11 / 1.93; l=300 3.24 / 2.53; l=500 2.76 / 1.45; l=1000 5.53 / 2.45; l=5000 7.15 / 2.43 -- LONG from READ_SIZE 224 (l = 200) up.
+// Residency: 24 wavefronts per CU beat 32 (l=10000, 8 192 pairs: 1.60 / 1.74 ms; 16: 1.95).
 inline bool genasm_long(const aim_params_t &p, const Knobs &kn)
 {
-    return kn.ga_long >= 0 ? kn.ga_long != 0 : p.read_size >= 640;
+    return kn.ga_long >= 0 ? kn.ga_long != 0 : p.read_size >= 224;
 }
 
 inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs, uint32_t *grid, uint32_t *block, size_t *lds)
@@ -456,7 +456,7 @@ inline void genasm_plan(const aim_params_t &p, const Knobs &kn, uint32_t n_pairs
     const bool lg = genasm_long(p, kn);
     *block = kWave;
     *lds = lg ? kGlLdsBytes : (size_t)kGaCols * kGaSlots * 8 + 64;
-    uint32_t per_cu = (uint32_t)std::min<size_t>(lg ? 32 : 16, lds_workgroups_per_cu(*lds));   // (the standard variant's 13 KB: 11; capped at 8 until round 3)
+    uint32_t per_cu = (uint32_t)std::min<size_t>(lg ? 24 : 16, lds_workgroups_per_cu(*lds));   // (the standard variant's 13 KB: 11; capped at 8 until round 3)
     if (kn.ga_per_cu > 0) per_cu = (uint32_t)std::min<size_t>((size_t)kn.ga_per_cu, lds_workgroups_per_cu(*lds));   // residency sweeps
     uint32_t g = resident_grid(kn, per_cu);
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;

@@ -55,7 +55,7 @@ def pmc_instructions(tag, pairs=None):
             valu = raw["SQ_INSTS_VALU"]["per_launch_mean"] / n
             allk = sum(raw[k]["per_launch_mean"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM",
                                                              "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH") if k in raw) / n
-            best = (valu, allk, os.path.relpath(f, ROOT))
+            best = (valu, allk, os.path.relpath(f, ROOT), d.get("derived", {}).get("valu_lane_use"))
         except Exception:
             continue
     return best
@@ -397,6 +397,10 @@ def main():
                 ach = rate * ins[0] * 64.0 / 1e12 if ins else None
                 roofline = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                             "frac": ach / VALU_PEAK_TLANEOPS if ins else None, "valu_instructions_per_pair": ins[0] if ins else None,
+                            # `frac` says how busy the SIMDs are issuing vector instructions; this says how many of the 64 lanes those instructions
+                            # had switched on (PMC: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)). Their product is the useful fraction.
+                            "useful_lane_frac": ins[3] if ins else None,
+                            "frac_useful": (ach / VALU_PEAK_TLANEOPS * ins[3]) if (ins and ins[3]) else None,
                             "instruction_source": ins[2] if ins else None, "traffic": None, "hbm_view": hbm,
                             "issue_view": {"achieved": rate * ins[1] / 1e9, "peak": ISSUE_PEAK_GINSTR, "unit": "G wavefront-instructions/s",
                                            "frac": rate * ins[1] / 1e9 / ISSUE_PEAK_GINSTR, "instructions_per_pair": ins[1]} if ins else None}

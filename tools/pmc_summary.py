@@ -18,6 +18,8 @@ PASSES = [
     ["WRITE_SIZE"],
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH"],
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"],
+    # lane use of the vector instructions: thread-cycles over instruction-cycles x 64 (rocprof's VALUUtilization)
+    ["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"],
 ]
 
 
@@ -123,6 +125,8 @@ def main():
         for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"):
             if k in raw:
                 summary["derived"][k.lower() + "_per_pair"] = raw[k]["per_launch_mean"] / a.pairs
+    if "SQ_THREAD_CYCLES_VALU" in raw and raw.get("SQ_ACTIVE_INST_VALU", {}).get("per_launch_mean"):
+        summary.setdefault("derived", {})["valu_lane_use"] = raw["SQ_THREAD_CYCLES_VALU"]["per_launch_mean"] / (raw["SQ_ACTIVE_INST_VALU"]["per_launch_mean"] * 64.0)
     json.dump(summary, open(a.out, "w"), indent=1)
     print(json.dumps({k: summary.get(k) for k in ("kernel", "kernel_trace", "hbm_traffic_bytes_per_launch", "algorithmic_GBps")}))
 
