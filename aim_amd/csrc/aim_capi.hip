@@ -124,7 +124,6 @@ aim::Knobs read_knobs()
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
     k.group_wlds = env_int("AIM_GROUP_WLDS", -1);
     k.group_unit1 = env_int("AIM_GROUP_UNIT1", 0);
-    k.ga_long = env_int("AIM_GA_LONG", -1);
     k.ga_per_cu = env_int("AIM_GA_PER_CU", 0);
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);

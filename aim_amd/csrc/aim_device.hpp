@@ -105,7 +105,6 @@ struct Knobs {
     int group_g = -1;             // AIM_GROUP_G         wfa_group: lanes per pair
     int group_per_cu = -1;        // AIM_GROUP_PER_CU    wfa_group: residency sweep
     int ga_per_cu = 0;            // AIM_GA_PER_CU       genasm: wavefronts per CU (residency sweeps; bounded by LDS)
-    int ga_long = -1;             // AIM_GA_LONG         genasm: 1 / 0 forces / forbids the LONG variant (compact column store, 16 wavefronts per CU)
     int group_unit1 = 0;          // AIM_GROUP_UNIT1     wfa_group: step through every score like the reference (A/B of GroupCfg::unit)
     int group_wlds = -1;          // AIM_GROUP_WLDS      wfa_group: entries per LDS ring row (power of two = narrow window, 0 = one home per diagonal)
     int poison_scratch = -1;      // AIM_DEBUG_POISON_SCRATCH  fill scratch with this byte at configure

@@ -71,7 +71,7 @@ def main():
             kw = dict(backtrace=rng.random() < 0.6, reduce=rng.random() < 0.7)
             params = engine.make_params("wfa", ms, rs, **kw)
             for k in list(os.environ):
-                if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
+                if k.startswith("AIM_") and k != "AIM_LIB" and not k.startswith("AIM_DEBUG_POISON"): os.environ.pop(k)
             req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
             for _ in range(rng.choice([0, 0, 1, 5])):
                 pat[rng.randrange(n), rng.randrange(max(1, l))] = ord(rng.choice("Nn*acgt"))
@@ -102,7 +102,7 @@ def main():
             ms = rng.randint(1, 60)
             params = engine.make_params(algo, ms, rs, backtrace=bt, **cost)
             for k in list(os.environ):
-                if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
+                if k.startswith("AIM_") and k != "AIM_LIB" and not k.startswith("AIM_DEBUG_POISON"): os.environ.pop(k)
             env = {}
             if rng.random() < 0.15: env["AIM_NO_NW_REG"] = "1"
             if rng.random() < 0.2: env["AIM_NW_REG_PER_CU"] = rng.choice(["1", "3", "16"])
@@ -168,7 +168,7 @@ def main():
         if a.focus == "fused":
             # packed rows in, {idx, score} or compact CIGAR out, through aim_set_submit / aim_set_wait; text against the oracle's
             for k in list(os.environ):
-                if k.startswith("AIM_") and k != "AIM_LIB": os.environ.pop(k)
+                if k.startswith("AIM_") and k != "AIM_LIB" and not k.startswith("AIM_DEBUG_POISON"): os.environ.pop(k)
             if rng.random() < 0.5:      # lane shapes
                 rs = rng.choice([80, 112, 136, 144, 160, 176]); l = rng.randint(1, rs - 12); ms = rng.randint(0, 10); cost = {}
                 e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10])

@@ -1,4 +1,4 @@
-"""GenASM: variant (AIM_GA_LONG) and residency (AIM_GA_PER_CU) against read length, kernel ms (best of 3), same box.
+"""GenASM: residency (AIM_GA_PER_CU) against read length, kernel ms (best of 3), same box.
     python tools/ga_sweep.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
@@ -19,8 +19,8 @@ def run(l, e, n):
 
 
 for l, n in ((100, 1 << 18), (200, 1 << 17), (300, 1 << 17), (500, 1 << 16), (1000, 1 << 16), (2000, 1 << 15), (5000, 1 << 14), (10000, 1 << 13)):
-    for env in ({"AIM_GA_LONG": "0"}, {"AIM_GA_LONG": "1", "AIM_GA_PER_CU": "16"}, {"AIM_GA_LONG": "1", "AIM_GA_PER_CU": "24"}, {"AIM_GA_LONG": "1"}):
-        for k in ("AIM_GA_LONG", "AIM_GA_PER_CU"): os.environ.pop(k, None)
+    for env in ({}, {"AIM_GA_PER_CU": "16"}, {"AIM_GA_PER_CU": "32"}):
+        os.environ.pop("AIM_GA_PER_CU", None)
         os.environ.update(env)
         ms_, plan = run(l, 0.10, n)
-        print("l=%-5d n=%-7d %-42s %.3f ms  %.3g pairs/s | grid=%s lds=%s" % (l, n, env, ms_, n / ms_ * 1e3, plan.split("grid=")[1].split()[0], plan.split("lds=")[1].split()[0]), flush=True)
+        print("l=%-5d n=%-7d %-24s %.3f ms  %.3g pairs/s | grid=%s lds=%s" % (l, n, env, ms_, n / ms_ * 1e3, plan.split("grid=")[1].split()[0], plan.split("lds=")[1].split()[0]), flush=True)
