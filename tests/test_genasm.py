@@ -177,27 +177,24 @@ def test_genasm_windows_that_need_more_than_15_edits(gpu):
 @pytest.mark.parametrize("l,err,n", [(30, 0.1, 300), (64, 0.05, 300), (100, 0.1, 1000), (150, 0.3, 400), (300, 0.25, 300), (1000, 0.1, 300), (500, 0.6, 100),
                                      (5000, 0.02, 64), (3000, 0.15, 64)])
 def test_genasm_long_variant_matches_oracle(gpu, monkeypatch, l, err, n):
-    """The LONG variant (compact column store: columns above 41 are computed but not kept, the pair's last window takes the 64-level
-    path; the default from READ_SIZE 640 up, 16 wavefronts per CU) forced onto every shape, and the standard variant forced onto long
-    reads: short last windows, windows with m != n, windows beyond 15 edits -- same output as the oracle either way."""
-    monkeypatch.setenv("AIM_GA_LONG", "1")
+    """Short last windows, windows with m != n, windows beyond 15 edits, with and without ops -- same output as the oracle. (Until round 4 there
+    were two kernel variants and this test forced each onto the other's shapes with AIM_GA_LONG; the banded scan path now serves every window
+    and the variable is ignored.)"""
     _hip_vs_oracle(l, err, n, 300 + l, True)
     _hip_vs_oracle(l, err, min(n, 100), 400 + l, False)
-    monkeypatch.setenv("AIM_GA_LONG", "0")
     _hip_vs_oracle(l, err, min(n, 64), 500 + l, True)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("poison", [None, "165", "255"])
 def test_genasm_banded_sweep_at_the_band_edge(gpu, monkeypatch, poison):
-    """Round 4: regular windows of the LONG variant keep 32-bit banded words (diagonals -15 .. +16) instead of 64-bit vectors. Error rates of
+    """Round 4: the fast path keeps 32-bit banded words (diagonals -15 .. +16) instead of 64-bit vectors. Error rates of
     15-25 % put windows at 10-15 edits -- alignments that reach the band's edge -- and just beyond (the 64-level path); indel-only edits drift
     to one side of the band. Also run with LDS poisoned at kernel entry: the sweep hands masks and columns between lanes through LDS, and a
     result that depends on what LDS held before is a missing ordering (found by tools/fuzz_parity.py --focus genasm under
     AIM_DEBUG_POISON_LDS)."""
     from aim_amd import engine
     from oracle import oracle
-    monkeypatch.setenv("AIM_GA_LONG", "1")
     if poison: monkeypatch.setenv("AIM_DEBUG_POISON_LDS", poison)
     for l, err, n, seed in ((1000, 0.2, 625, 11), (700, 0.25, 300, 12), (2000, 0.15, 200, 13)):
         rs = ((int(l * (1 + err)) + 8 + 7) // 8) * 8

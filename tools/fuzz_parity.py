@@ -143,10 +143,10 @@ def main():
                     tl = int(req["text_len"][i]); txt[i, :tl] = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(tl)), dtype=np.uint8)
                 elif r < 0.2:
                     pat[i, rng.randrange(l)] = ord(rng.choice("Nn*"))
-            os.environ.pop("AIM_GA_LONG", None)
-            ga = rng.choice(["", "", "0", "1"])               # default rule (LONG from READ_SIZE 640 up), or either variant forced onto any shape
-            if ga: os.environ["AIM_GA_LONG"] = ga
-            case = dict(algo="genasm", l=l, e=e, n=n, read_size=rs, backtrace=int(bt), kernel="genasm_wave_kernel", ga_long=ga)
+            os.environ.pop("AIM_GA_PER_CU", None)
+            ga = rng.choice(["", "", "1", "9", "32"])         # residency: the default, or another number of wavefronts per CU
+            if ga: os.environ["AIM_GA_PER_CU"] = ga
+            case = dict(algo="genasm", l=l, e=e, n=n, read_size=rs, backtrace=int(bt), kernel="genasm_wave_kernel", ga_per_cu=ga)
             try:
                 if params.flags & capi.FLAG_RES8:
                     res, _ = engine.align(params, req, pat, txt)

@@ -8,7 +8,7 @@ from oracle import oracle
 
 z = np.load(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/fuzz_genasm_fail.npz")
 req, pat, txt, rs = z["req"], z["pat"], z["txt"], int(z["rs"])
-if str(z["ga"]): os.environ["AIM_GA_LONG"] = str(z["ga"])
+if str(z["ga"]): os.environ["AIM_GA_PER_CU"] = str(z["ga"])
 n = len(req)
 params = engine.make_params("genasm", 0, rs, backtrace=True)
 res, ops = engine.align(params, req, pat, txt, check=False)
