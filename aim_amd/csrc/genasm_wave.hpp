@@ -60,47 +60,79 @@ constexpr int kGaCommit = 40;   // W - O
 // different address of the same thread: this stops it (no instruction is emitted).
 __device__ __forceinline__ void ga_lds_order() { asm volatile("" ::: "memory"); }
 
-// ---- full-width path (16 .. 63 edits): lanes = error levels, 64-bit vectors
-// lane L receives the value of lane L - 1 (DPP wave_shr:1); lane 0 receives `fill`
-__device__ __forceinline__ uint64_t ga_shr1(uint64_t v, uint64_t fill)
+// ---- full-width path (16 .. 63 edits): lanes = text columns like the fast path, full 64-bit complemented vectors (no band: an alignment with
+// up to 63 edits can sit anywhere). In full coordinates the match term keeps its shift, and one column is the map
+//     x -> (((x << 1) | 1) & EQ_a) | G_a,      G_a[d] = (C_{a+1}[d-1] << 1) | C_{a+1}[d-1] | (C_a[d-1] << 1) | 1   (d >= 1; G_a[0] = 0)
+// (C = ~R; "~(X << 1) = (~X << 1) | 1"), a member of the family x -> ((x << k) & A) | B, which is closed under composition:
+//     (k1, A1, B1) then (k2, A2, B2)  =  (k1 + k2, (A1 << k2) & A2, ((B1 << k2) & A2) | B2).
+// So a level is again ONE inclusive scan over the wavefront; the shift of a step is the length of the lane's own segment at that step -- 1, 2,
+// 4, 8 for the row_shr steps, (lane & 15) + 1 and (lane & 31) + 1 for the two row broadcasts -- and the A parts do not depend on the level
+// (computed once per window). C_a[d] = ((C_n[d] << (j + 1)) & A_j) | B_j for lane j = column n-1-j, C_n[d] = the d lowest bits. Levels are
+// computed until the first one whose column 0 has bit m-1 set (random sequences: ~30 of 64) and leave as one coalesced 512-B store each into
+// this wavefront's HBM slab ([level][lane]); the walk reads a level's row back with one coalesced load per edit.
+// Round 2-4's version (lanes = error levels, skewed sweep, n + 63 steps whatever the hit level, the walk gathering three slab columns per
+// iteration) needed 54 k cycles per window against 5 k on the fast path: a pair that loses the diagonal -- 1 in ~4 000 at l = 100 000, e = 10 %,
+// every later window random against random -- kept ONE wavefront busy for 45 ms next to a batch that takes 8 (profiles/NOTES.md R4.6).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint64_t gw_dpp(uint64_t fill, uint64_t v)   // lanes without a source (or outside the row mask) receive `fill`
 {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)fill, (int)(uint32_t)v, CTRL, ROWS, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(fill >> 32), (int)(uint32_t)(v >> 32), CTRL, ROWS, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t ga_readlane(uint64_t v, int src)   // src wave-uniform
+__device__ __forceinline__ uint64_t gw_readlane(uint64_t v, int src)   // src wave-uniform
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
 }
-// GenASM-DC of one window, SKEWED: level d of column a needs level d-1 of the SAME column, so a column-by-column sweep would be a 64-deep
-// chain per column. Instead lane d works on column n-1-(u-d) at step u: everything it needs from lane d-1 is then that lane's value after
-// step u-1 (R_a[d-1]) and after step u-2 (R_{a+1}[d-1]) -- ONE DPP shift by one lane per step and a remembered copy, n + 63 steps. The
-// pattern masks travel the same way: lane j first holds PM of text column j, lane 0 picks column n-1-u with a v_readlane, and the masks
-// shift one lane per step. Column a of level d is stored at cols[a * 64 + d] (column n = the initial ~0 << d included). Returns R_0[lane].
-__device__ __forceinline__ uint64_t ga_dc64(int n_, int lane, uint64_t mypm, uint64_t *cols)
+__device__ __forceinline__ uint64_t gw_bpermute(int byte_addr, uint64_t v)
 {
-    const int n = __builtin_amdgcn_readfirstlane(n_);   // wave-uniform by construction; said so for the v_readlane index below
-    constexpr uint64_t ONES = ~0ull;
-    uint64_t cur = ONES << lane;                         // R_n[d]
-    cols[n * 64 + lane] = cur;
-    uint64_t nb_prev = ga_shr1(cur, ONES);               // lane d-1 two steps ago
-    uint64_t pmv = ONES;
-    for (int u = 0; u < n + 63; ++u) {
-        const int c0 = n - 1 - u;                        // lane 0's column at this step
-        pmv = ga_shr1(pmv, ga_readlane(mypm, c0 < 0 ? 0 : c0));
-        const uint64_t nb_cur = ga_shr1(cur, ONES);      // lane d-1 one step ago: R_a[d-1]
-        const int col = c0 + lane;                       // my column
-        uint64_t y = (cur << 1) | pmv;                   // match
-        if (lane > 0) y &= (nb_prev << 1) & nb_prev & (nb_cur << 1);      // substitution, text-only edit, pattern-only edit
-        nb_prev = nb_cur;
-        if (col >= 0 && col < n) {
-            cur = y;
-            cols[col * 64 + lane] = y;
-        }
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(byte_addr, (int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// One window, all 64 levels if need be: eqcol = full "equal" mask of text column `lane` (bit q set <=> p[m-1-q] == t[lane]). Lane j works on
+// column n-1-j. Returns the first level whose column 0 reports an alignment (bit m-1), -1 if none of the 64 does; levels 0 .. that one are in
+// slab[level * 64 + lane].
+__device__ __forceinline__ int ga_dc64_scan(int lane, uint64_t eqcol, int n, int m, uint64_t *slab, uint64_t &eq_own, uint64_t &c_own)
+{
+    uint64_t e = gw_bpermute(max(n - 1 - lane, 0) << 2, eqcol);
+    if (lane >= n) e = 0;                                // beyond column 0: these lanes only receive
+    const int i16 = lane & 15, row = lane >> 4;
+    const int k4 = i16 + 1, k5 = (lane & 31) + 1;        // a lane's own segment at the two broadcast steps
+    // the A parts: ak[s] = this lane's own segment's A BEFORE step s; afull = the whole prefix's
+    uint64_t ak[6], A = e;
+    ak[0] = A; { const uint64_t t = (gw_dpp<0x111, 0xf>(0, A) << 1) & A; A = i16 >= 1 ? t : A; }
+    ak[1] = A; { const uint64_t t = (gw_dpp<0x112, 0xf>(0, A) << 2) & A; A = i16 >= 2 ? t : A; }
+    ak[2] = A; { const uint64_t t = (gw_dpp<0x114, 0xf>(0, A) << 4) & A; A = i16 >= 4 ? t : A; }
+    ak[3] = A; { const uint64_t t = (gw_dpp<0x118, 0xf>(0, A) << 8) & A; A = i16 >= 8 ? t : A; }
+    ak[4] = A; { const uint64_t t = (gw_dpp<0x142, 0xa>(0, A) << k4) & A; A = (row & 1) ? t : A; }
+    ak[5] = A; { const uint64_t t = (gw_dpp<0x143, 0xc>(0, A) << k5) & A; A = (row & 2) ? t : A; }
+    auto scan = [&](uint64_t B) -> uint64_t {            // lanes without a source receive 0: nothing is added
+        B |= (gw_dpp<0x111, 0xf>(0, B) << 1) & ak[0];
+        B |= (gw_dpp<0x112, 0xf>(0, B) << 2) & ak[1];
+        B |= (gw_dpp<0x114, 0xf>(0, B) << 4) & ak[2];
+        B |= (gw_dpp<0x118, 0xf>(0, B) << 8) & ak[3];
+        B |= (gw_dpp<0x142, 0xa>(0, B) << k4) & ak[4];
+        B |= (gw_dpp<0x143, 0xc>(0, B) << k5) & ak[5];
+        return B;
+    };
+    uint64_t c = scan(e & 1ull);                         // level 0: C_n[0] = 0, G = 0
+    slab[lane] = c;
+    int d = 0;
+    for (;;) {
+        if (__builtin_amdgcn_readlane((int)(uint32_t)(c >> (m - 1)), n - 1) & 1) break;   // column 0, pattern position 0
+        if (++d == 64) { d = -1; break; }
+        const uint64_t cp = gw_dpp<0x138, 0xf>((1ull << (d - 1)) - 1ull, c);              // wave_shr:1: C_{a+1}[d-1]; lane 0's neighbour is column n
+        const uint64_t B = scan((cp << 1) | cp | (c << 1) | 1ull);
+        const uint64_t x = lane == 63 ? 0ull : ((1ull << d) - 1ull) << (lane + 1);       // the initial column C_n[d] through the whole prefix
+        c = (x & A) | B;
+        slab[d * 64 + lane] = c;
     }
-    return cur;
+    eq_own = e;
+    c_own = c;
+    return d;
 }
 
 // ---- fast path (<= 15 edits): lanes = text columns, banded complemented 32-bit words
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
     uint32_t *Rb = reinterpret_cast<uint32_t *>(smem);   // fast path: [16 levels][64 lanes] banded words
-    uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);   // full-width path: [n + 1 columns][64 levels]
+    uint64_t *Rg = reinterpret_cast<uint64_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);   // full-width path: [64 levels][64 lanes]
     const int lane = threadIdx.x;
     const int rs = a.p.read_size;
     constexpr uint64_t ONES = ~0ull;
@@ -191,6 +223,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
         char *ops = BT ? a.ops + (uint64_t)pair * 2 * rs : nullptr;
         const int cap = 2 * rs;
         int pi = 0, ti = 0, nops = 0, dist = 0, status = AIM_PAIR_OK;   // wave-uniform
+        bool wide_prev = false;
 #ifdef AIM_GA_STAMPS
         unsigned long long gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(glast) :: "memory");
@@ -217,19 +250,18 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             // computation; if the window aligns within 15 edits the traceback never looks further.
             const bool regular = m == kGaW && n == kGaW && !last;   // 2 499 of the 2 500 windows of a 100-kb pair: the fast path is compiled twice, once with these as constants
             uint32_t eq_own = 0, c_own = 0;
-            int d = regular ? ga_dc16_scan<true>(lane, gl_band_eq(~mypm, lane, kGaW), kGaW, 16, Rb, eq_own, c_own)
-                            : ga_dc16_scan<false>(lane, gl_band_eq(~mypm, lane, m), n, 16 + n - m, Rb, eq_own, c_own);
+            int d = -1;
+            if (!wide_prev) d = regular ? ga_dc16_scan<true>(lane, gl_band_eq(~mypm, lane, kGaW), kGaW, 16, Rb, eq_own, c_own)
+                                        : ga_dc16_scan<false>(lane, gl_band_eq(~mypm, lane, m), n, 16 + n - m, Rb, eq_own, c_own);
             const bool slow = d < 0;           // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
-            int pfwd = 0x200;                  // p[j] forward: only the full-width path reads it
+            uint64_t weq = 0, wc = 0;
             if (slow) {
-                // FULL-WIDTH PATH (a window that needs 16..63 edits): all 64 levels, columns to this wavefront's HBM slab
-                pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
-                const uint64_t R = ga_dc64(n, lane, mypm, Rg);
-                const uint64_t hit = __ballot(!((R >> (m - 1)) & 1ull));
+                // FULL-WIDTH PATH (a window that needs 16..63 edits): up to 64 levels of 64-bit words, rows to this wavefront's HBM slab
+                d = ga_dc64_scan(lane, ~mypm, n, m, Rg, weq, wc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront reads its own slab back below
-                d = hit ? (int)__builtin_ctzll(hit) : -1;          // smallest level whose bit m-1 is clear in column 0
             }
+            wide_prev = slow && (d < 0 || d > 15);   // a pair that has lost the diagonal stays lost: its next window goes straight to the full-width path
             AIM_GASTAMP(3);   // DC, 64 levels (rare)
             int ca = 0, cb = 0, wn = 0;           // consumed text / pattern characters, ops of this window (uniform)
             // GenASM-TB. The window's ops live in two registers (lane i: ops i and 64 + i), pre-set to 'M': a run of matches costs
@@ -242,42 +274,52 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             };
             if (d < 0) {   // [spec] no alignment of this window within 63 edits: diagonal steps
                 const int steps = min(min(m, n), kGaCommit);
+                const int pfwd = lane < m ? (int)gP[pi + lane] : 0x200;
                 const bool x = lane < steps && pfwd != tfwd;
                 opsA = x ? 'X' : opsA;
                 dist += __builtin_popcountll(__ballot(x));
                 ca = cb = wn = steps;
             } else if (slow) {
-                // Full-width walk, one slab round trip per iteration. Lane i looks at the cell the sequential walk would reach after i
-                // matches, (ca+i, cb+i): the characters (ds_bpermute of the window registers), R_{a+1}[d] for the match test, and
-                // R_{a+1}[d-1], R_a[d-1] for the edit it would take if the run of matches ended on it. The run is the leading
-                // lanes whose match test holds ('M' never changes d); the edit is then read from the first lane where it fails --
-                // the same tests in the same order as the step-by-step walk (oracle/genasm_oracle.c), without a second fetch.
+                // Full-width walk: walk_cols (below) in full coordinates. The cells of a run of matches, (ca + i, cb + i), sit on different bits
+                // of their columns' words: lane of column a tests bit q = m-2-b of C_{a+1}[d] (ok(a+1, b+1, d); past the pattern's end: true) and
+                // bit q+1 of EQ_a (p[b] == t[a]), b = cb + a - ca. One coalesced 512-B load of the level below per edit.
+                uint64_t wd = wc;                                         // C_a[d] of my column
+                const int a_l = n - 1 - lane;                             // my column
                 for (;;) {
-                    const int ai = ca + lane, bi = cb + lane;
-                    const bool inr = bi < m && ai < n && (last || (ai < kGaCommit && bi < kGaCommit));
-                    const int aic = min(ai, n - 1), bic = min(bi, kGaW - 1);
-                    const int dm1 = d > 0 ? d - 1 : 0;
-                    const uint64_t rn_d = Rg[(aic + 1) * 64 + d], rn_dm1 = Rg[(aic + 1) * 64 + dm1], rc_dm1 = Rg[aic * 64 + dm1];
-                    const int pch = __builtin_amdgcn_ds_bpermute(bic << 2, pfwd), tch = __builtin_amdgcn_ds_bpermute(aic << 2, tfwd);
-                    // clear(r, b) := b >= m || bit (m-1-b) of r is 0
-                    const int q1 = m - 2 - bi, q0 = m - 1 - bi;          // bit indices for b = bi + 1 and b = bi
-                    auto clr = [&](uint64_t r, int q) -> bool { return q < 0 || !((r >> (q & 63)) & 1ull); };
-                    const bool cm = inr && pch == tch && clr(rn_d, q1);
-                    int code = 0;                                         // the edit this cell would take
-                    if (d > 0) code = clr(rn_dm1, q1) ? 'X' : clr(rc_dm1, q1) ? 'D' : clr(rn_dm1, q0) ? 'I' : 0;
-                    const uint64_t bad = ~__ballot(cm);
-                    const int run = bad ? (int)__builtin_ctzll(bad) : 64;
+                    if (ca == n) {   // the window's text is used up: pattern-only edits to the end of the pattern (to the commit bound if this is not the last window)
+                        const int k = last ? m - cb : (ca >= kGaCommit ? 0 : max(min(m, kGaCommit) - cb, 0));
+                        opsA = (lane >= wn && lane < wn + k) ? 'D' : opsA;
+                        opsB = (lane + 64 >= wn && lane + 64 < wn + k) ? 'D' : opsB;
+                        wn += k; cb += k; d -= k; dist += k;
+                        break;
+                    }
+                    const uint64_t wn1 = gw_dpp<0x138, 0xf>((1ull << d) - 1ull, wd);      // wave_shr:1: C_{a+1}[d]; lane 0's neighbour is column n
+                    const int q = m - 2 - cb - (a_l - ca);
+                    const bool okb = q < 0 || ((wn1 >> (q & 63)) & 1ull);
+                    const bool eqb = (weq >> ((q + 1) & 63)) & 1ull;
+                    const uint64_t mm = __ballot(okb && eqb);
+                    const uint64_t sh = ~(mm << (kGaW - n + ca));         // bit 63 = column ca, then ca + 1, ...: clear = the run goes on
+                    int run = sh ? (int)__builtin_clzll(sh) : 64;
+                    int lim = min(n - ca, m - cb);                        // cells inside the window ...
+                    if (!last) lim = min(lim, kGaCommit - max(ca, cb));   // ... and with a < 40 and b < 40
+                    run = min(run, lim);
                     wn += run; ca += run; cb += run;
                     if (cb == m) break;
                     if (!last && (ca >= kGaCommit || cb >= kGaCommit)) break;
-                    if (ca == n) { put('D'); ++cb; --d; ++dist; continue; }
-                    // here lane `run` is inside the window and its match test failed: its edit is the walk's next step
-                    const int op = __builtin_amdgcn_readlane(code, run);
-                    if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen (the recurrence guarantees one rule applies)
+                    if (ca == n) continue;
+                    if (d == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }    // cannot happen (the recurrence guarantees one rule applies)
+                    const uint64_t wl = Rg[(d - 1) * 64 + lane];          // C_a[d-1] of my column
+                    const uint64_t s1 = ca + 1 == n ? (1ull << (d - 1)) - 1ull : gw_readlane(wl, max(n - 2 - ca, 0));   // column ca + 1
+                    const uint64_t s0 = gw_readlane(wl, n - 1 - ca);                                                  // column ca
+                    const int q1 = m - 2 - cb, q0 = m - 1 - cb;           // bits of pattern positions cb + 1 and cb
+                    auto okq = [&](uint64_t w, int q_) -> bool { return q_ < 0 || ((w >> (q_ & 63)) & 1ull); };
+                    const int op = okq(s1, q1) ? 'X' : okq(s0, q1) ? 'D' : okq(s1, q0) ? 'I' : 0;
+                    if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen
                     put(op);
                     ca += op != 'D';
                     cb += op != 'I';
                     --d; ++dist;
+                    wd = wl;
                 }
             } else {
                 // walk_cols: the same walk over the banded words, the lanes still bound to their COLUMNS (lane j: column n-1-j, as in the sweep).

@@ -49,6 +49,11 @@ CONFIGS = {
     "genasm_l100000_e10_cigar": dict(algo="genasm", l=100000, e=0.10, n=1024, kw=dict(backtrace=True)),
     "genasm_l100000_e10_score": dict(algo="genasm", l=100000, e=0.10, n=1024, kw=dict()),
     "genasm_l100000_e10_cigar_n4096": dict(algo="genasm", l=100000, e=0.10, n=4096, kw=dict(backtrace=True)),
+    "genasm_l100000_e10_cigar_n6144": dict(algo="genasm", l=100000, e=0.10, n=6144, kw=dict(backtrace=True)),
+    "genasm_l100000_e10_cigar_n4864": dict(algo="genasm", l=100000, e=0.10, n=4864, kw=dict(backtrace=True)),
+    "genasm_l100000_e10_cigar_n5120": dict(algo="genasm", l=100000, e=0.10, n=5120, kw=dict(backtrace=True)),
+    "genasm_l100000_e10_score_n8192": dict(algo="genasm", l=100000, e=0.10, n=8192, kw=dict()),
+    "genasm_l100000_e10_cigar_n8192": dict(algo="genasm", l=100000, e=0.10, n=8192, kw=dict(backtrace=True)),
     "genasm_l10000_e10_cigar": dict(algo="genasm", l=10000, e=0.10, n=8192, kw=dict(backtrace=True)),
     "genasm_l100_e10_cigar": dict(algo="genasm", l=100, e=0.10, n=1 << 18, kw=dict(backtrace=True)),
 }
