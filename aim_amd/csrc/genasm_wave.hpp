@@ -73,6 +73,16 @@ __device__ __forceinline__ void ga_lds_order() { asm volatile("" ::: "memory"); 
 // Round 2-4's version (lanes = error levels, skewed sweep, n + 63 steps whatever the hit level, the walk gathering three slab columns per
 // iteration) needed 54 k cycles per window against 5 k on the fast path: a pair that loses the diagonal -- 1 in ~4 000 at l = 100 000, e = 10 %,
 // every later window random against random -- kept ONE wavefront busy for 45 ms next to a batch that takes 8 (profiles/NOTES.md R4.6).
+template <int CTRL>
+__device__ __forceinline__ uint32_t gl_dppz(uint32_t v)   // all four rows, lanes without a source receive 0 (bound_ctrl: no fill register to set up)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ uint64_t gw_dppz(uint64_t v)
+{
+    return ((uint64_t)gl_dppz<CTRL>((uint32_t)(v >> 32)) << 32) | gl_dppz<CTRL>((uint32_t)v);
+}
 template <int CTRL, int ROWS>
 __device__ __forceinline__ uint64_t gw_dpp(uint64_t fill, uint64_t v)   // lanes without a source (or outside the row mask) receive `fill`
 {
@@ -95,8 +105,10 @@ __device__ __forceinline__ uint64_t gw_bpermute(int byte_addr, uint64_t v)
 // One window, all 64 levels if need be: eqcol = full "equal" mask of text column `lane` (bit q set <=> p[m-1-q] == t[lane]). Lane j works on
 // column n-1-j. Returns the first level whose column 0 reports an alignment (bit m-1), -1 if none of the 64 does; levels 0 .. that one are in
 // slab[level * 64 + lane].
-__device__ __forceinline__ int ga_dc64_scan(int lane, uint64_t eqcol, int n, int m, uint64_t *slab, uint64_t &eq_own, uint64_t &c_own)
+template <bool REG>   // REG: m = n = 64 as constants
+__device__ __forceinline__ int ga_dc64_scan(int lane, uint64_t eqcol, int n_, int m_, uint64_t *slab, uint64_t &eq_own, uint64_t &c_own)
 {
+    const int n = REG ? kGaW : n_, m = REG ? kGaW : m_;
     uint64_t e = gw_bpermute(max(n - 1 - lane, 0) << 2, eqcol);
     if (lane >= n) e = 0;                                // beyond column 0: these lanes only receive
     const int i16 = lane & 15, row = lane >> 4;
@@ -110,10 +122,10 @@ __device__ __forceinline__ int ga_dc64_scan(int lane, uint64_t eqcol, int n, int
     ak[4] = A; { const uint64_t t = (gw_dpp<0x142, 0xa>(0, A) << k4) & A; A = (row & 1) ? t : A; }
     ak[5] = A; { const uint64_t t = (gw_dpp<0x143, 0xc>(0, A) << k5) & A; A = (row & 2) ? t : A; }
     auto scan = [&](uint64_t B) -> uint64_t {            // lanes without a source receive 0: nothing is added
-        B |= (gw_dpp<0x111, 0xf>(0, B) << 1) & ak[0];
-        B |= (gw_dpp<0x112, 0xf>(0, B) << 2) & ak[1];
-        B |= (gw_dpp<0x114, 0xf>(0, B) << 4) & ak[2];
-        B |= (gw_dpp<0x118, 0xf>(0, B) << 8) & ak[3];
+        B |= (gw_dppz<0x111>(B) << 1) & ak[0];
+        B |= (gw_dppz<0x112>(B) << 2) & ak[1];
+        B |= (gw_dppz<0x114>(B) << 4) & ak[2];
+        B |= (gw_dppz<0x118>(B) << 8) & ak[3];
         B |= (gw_dpp<0x142, 0xa>(0, B) << k4) & ak[4];
         B |= (gw_dpp<0x143, 0xc>(0, B) << k5) & ak[5];
         return B;
@@ -180,10 +192,10 @@ __device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, int n_, in
         if (++d == 16) { d = -1; break; }
         const uint32_t cp = gl_dpp<0x138, 0xf>(gl_lowmask(nm + d - 1), c);              // wave_shr:1: c_{a+1}[d-1]; lane 0's neighbour is column n
         uint32_t g = ((c << 1) | cp) | (cp >> 1);        // pattern-only edit, substitution, text-only edit
-        g |= gl_dpp<0x111, 0xf>(0u, g) & ek[0];
-        g |= gl_dpp<0x112, 0xf>(0u, g) & ek[1];
-        g |= gl_dpp<0x114, 0xf>(0u, g) & ek[2];
-        g |= gl_dpp<0x118, 0xf>(0u, g) & ek[3];
+        g |= gl_dppz<0x111>(g) & ek[0];
+        g |= gl_dppz<0x112>(g) & ek[1];
+        g |= gl_dppz<0x114>(g) & ek[2];
+        g |= gl_dppz<0x118>(g) & ek[3];
         g |= gl_dpp<0x142, 0xa>(0u, g) & ek[4];
         g |= gl_dpp<0x143, 0xc>(0u, g) & ek[5];
         c = (e & gl_lowmask(nm + d)) | g;                // the initial column c_n[d] through the whole product, then everything added on the way
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             uint64_t weq = 0, wc = 0;
             if (slow) {
                 // FULL-WIDTH PATH (a window that needs 16..63 edits): up to 64 levels of 64-bit words, rows to this wavefront's HBM slab
-                d = ga_dc64_scan(lane, ~mypm, n, m, Rg, weq, wc);
+                d = regular ? ga_dc64_scan<true>(lane, ~mypm, kGaW, kGaW, Rg, weq, wc) : ga_dc64_scan<false>(lane, ~mypm, n, m, Rg, weq, wc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront reads its own slab back below
             }
             wide_prev = slow && (d < 0 || d > 15);   // a pair that has lost the diagonal stays lost: its next window goes straight to the full-width path
@@ -283,44 +295,55 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 // Full-width walk: walk_cols (below) in full coordinates. The cells of a run of matches, (ca + i, cb + i), sit on different bits
                 // of their columns' words: lane of column a tests bit q = m-2-b of C_{a+1}[d] (ok(a+1, b+1, d); past the pattern's end: true) and
                 // bit q+1 of EQ_a (p[b] == t[a]), b = cb + a - ca. One coalesced 512-B load of the level below per edit.
-                uint64_t wd = wc;                                         // C_a[d] of my column
-                const int a_l = n - 1 - lane;                             // my column
-                for (;;) {
-                    if (ca == n) {   // the window's text is used up: pattern-only edits to the end of the pattern (to the commit bound if this is not the last window)
-                        const int k = last ? m - cb : (ca >= kGaCommit ? 0 : max(min(m, kGaCommit) - cb, 0));
-                        opsA = (lane >= wn && lane < wn + k) ? 'D' : opsA;
-                        opsB = (lane + 64 >= wn && lane + 64 < wn + k) ? 'D' : opsB;
-                        wn += k; cb += k; d -= k; dist += k;
-                        break;
+                auto walk_wide = [&](auto reg_tag) {
+                    constexpr bool REG = decltype(reg_tag)::value;   // a regular window (m = n = 64, not the last): what a pair that lost the diagonal is made of
+                    const int N = REG ? kGaW : n, M = REG ? kGaW : m;
+                    const bool LAST = REG ? false : last;
+                    uint64_t wd = wc;                                         // C_a[d] of my column
+                    const int a_l = N - 1 - lane;                             // my column
+                    // every edit moves exactly one level down: the rows of the next four levels are asked for ahead of their use (a slab round trip is ~600 cycles,
+                    // an iteration ~150)
+                    auto row = [&](int lvl) -> uint64_t { return Rg[max(lvl, 0) * 64 + lane]; };
+                    uint64_t w1 = row(d - 1), w2 = row(d - 2), w3 = row(d - 3), w4 = row(d - 4);
+                    for (;;) {
+                        if (!REG && ca == N) {   // the window's text is used up: pattern-only edits to the end of the pattern (to the commit bound if this is not the last window)
+                            const int k = LAST ? M - cb : (ca >= kGaCommit ? 0 : max(min(M, kGaCommit) - cb, 0));
+                            opsA = (lane >= wn && lane < wn + k) ? 'D' : opsA;
+                            opsB = (lane + 64 >= wn && lane + 64 < wn + k) ? 'D' : opsB;
+                            wn += k; cb += k; d -= k; dist += k;
+                            break;
+                        }
+                        const uint64_t wn1 = gw_dpp<0x138, 0xf>((1ull << d) - 1ull, wd);      // wave_shr:1: C_{a+1}[d]; lane 0's neighbour is column n
+                        const int q = M - 2 - cb - (a_l - ca);
+                        const bool okb = (!REG && q < 0) || ((wn1 >> (q & 63)) & 1ull);   // (a regular window's cells have b < 40: q >= 22)
+                        const bool eqb = (weq >> ((q + 1) & 63)) & 1ull;
+                        const uint64_t mm = __ballot(okb && eqb);
+                        const uint64_t sh = ~(mm << (kGaW - N + ca));         // bit 63 = column ca, then ca + 1, ...: clear = the run goes on
+                        int run = sh ? (int)__builtin_clzll(sh) : 64;
+                        int lim = kGaCommit - max(ca, cb);                    // cells with a < 40 and b < 40 ...
+                        if (!REG) { lim = min(N - ca, M - cb); if (!LAST) lim = min(lim, kGaCommit - max(ca, cb)); }   // ... or inside the window, whichever ends first
+                        run = min(run, lim);
+                        wn += run; ca += run; cb += run;
+                        if (!REG && cb == M) break;
+                        if (!LAST && (ca >= kGaCommit || cb >= kGaCommit)) break;
+                        if (!REG && ca == N) continue;
+                        if (d == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }    // cannot happen (the recurrence guarantees one rule applies)
+                        const uint64_t wl = w1;                               // C_a[d-1] of my column
+                        w1 = w2; w2 = w3; w3 = w4; w4 = row(d - 5);
+                        const uint64_t s1 = (!REG && ca + 1 == N) ? (1ull << (d - 1)) - 1ull : gw_readlane(wl, REG ? N - 2 - ca : max(N - 2 - ca, 0));   // column ca + 1
+                        const uint64_t s0 = gw_readlane(wl, N - 1 - ca);                                                  // column ca
+                        const int q1 = M - 2 - cb, q0 = M - 1 - cb;           // bits of pattern positions cb + 1 and cb
+                        auto okq = [&](uint64_t w, int q_) -> bool { return (!REG && q_ < 0) || ((w >> (q_ & 63)) & 1ull); };
+                        const int op = okq(s1, q1) ? 'X' : okq(s0, q1) ? 'D' : okq(s1, q0) ? 'I' : 0;
+                        if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen
+                        put(op);
+                        ca += op != 'D';
+                        cb += op != 'I';
+                        --d; ++dist;
+                        wd = wl;
                     }
-                    const uint64_t wn1 = gw_dpp<0x138, 0xf>((1ull << d) - 1ull, wd);      // wave_shr:1: C_{a+1}[d]; lane 0's neighbour is column n
-                    const int q = m - 2 - cb - (a_l - ca);
-                    const bool okb = q < 0 || ((wn1 >> (q & 63)) & 1ull);
-                    const bool eqb = (weq >> ((q + 1) & 63)) & 1ull;
-                    const uint64_t mm = __ballot(okb && eqb);
-                    const uint64_t sh = ~(mm << (kGaW - n + ca));         // bit 63 = column ca, then ca + 1, ...: clear = the run goes on
-                    int run = sh ? (int)__builtin_clzll(sh) : 64;
-                    int lim = min(n - ca, m - cb);                        // cells inside the window ...
-                    if (!last) lim = min(lim, kGaCommit - max(ca, cb));   // ... and with a < 40 and b < 40
-                    run = min(run, lim);
-                    wn += run; ca += run; cb += run;
-                    if (cb == m) break;
-                    if (!last && (ca >= kGaCommit || cb >= kGaCommit)) break;
-                    if (ca == n) continue;
-                    if (d == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }    // cannot happen (the recurrence guarantees one rule applies)
-                    const uint64_t wl = Rg[(d - 1) * 64 + lane];          // C_a[d-1] of my column
-                    const uint64_t s1 = ca + 1 == n ? (1ull << (d - 1)) - 1ull : gw_readlane(wl, max(n - 2 - ca, 0));   // column ca + 1
-                    const uint64_t s0 = gw_readlane(wl, n - 1 - ca);                                                  // column ca
-                    const int q1 = m - 2 - cb, q0 = m - 1 - cb;           // bits of pattern positions cb + 1 and cb
-                    auto okq = [&](uint64_t w, int q_) -> bool { return q_ < 0 || ((w >> (q_ & 63)) & 1ull); };
-                    const int op = okq(s1, q1) ? 'X' : okq(s0, q1) ? 'D' : okq(s1, q0) ? 'I' : 0;
-                    if (op == 0) { status = AIM_PAIR_WFA_NO_LINK; break; }   // cannot happen
-                    put(op);
-                    ca += op != 'D';
-                    cb += op != 'I';
-                    --d; ++dist;
-                    wd = wl;
-                }
+                };
+                if (regular) walk_wide(std::true_type{}); else walk_wide(std::false_type{});
             } else {
                 // walk_cols: the same walk over the banded words, the lanes still bound to their COLUMNS (lane j: column n-1-j, as in the sweep).
                 // Every cell of a run of matches lies on the walk's diagonal k = ca - cb, whose band bit is kb = 15 + k in every column, and
