@@ -13,8 +13,8 @@
 // Almost every window aligns within 15 edits (at e = 10 % a 64-character window carries ~6). Those windows take the FAST PATH
 // (rounds 3-4): banded 32-bit words, the lanes are the window's text COLUMNS and an error level is one scan over the wavefront;
 // the traceback keeps the lanes on their columns. A window that needs 16 .. 63 edits, or none at all [spec], takes the FULL-WIDTH
-// PATH of round 2: lanes = the 64 error levels, 64-bit vectors, a skewed sweep with one DPP wave_shr per column, the columns in a
-// per-wavefront slab of HBM scratch.
+// PATH: the same mapping on full 64-bit vectors (the composition carries a shift), rows of levels in a per-wavefront slab of HBM
+// scratch. (Until round 4 it was round 2's design: lanes = error levels, a skewed sweep with one DPP wave_shr per column.)
 //
 // FAST PATH.
 // (1) BANDED bit-vectors. The fast path stops at 15 edits, and an alignment of the window with <= 15 edits never leaves the

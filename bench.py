@@ -342,6 +342,17 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(int(v[0]))
 
+    # GenASM, long reads: a pair whose windowed traceback loses the diagonal has every later window random against random (the full-width
+    # path) and keeps ONE wavefront busy several times longer than the batch takes (profiles/NOTES.md R4.6). Say whether this
+    # rank's batch holds one: its score is ~half its length instead of ~the error rate.
+    tail = None
+    if algo == "genasm":
+        sc = res_host["score"].astype(np.int64)
+        med = float(np.median(sc)) if len(sc) else 0.0
+        lost = np.nonzero(sc > 2 * med + 64)[0]
+        tail = {"pairs_that_lost_the_diagonal": int(len(lost)), "first": [int(i) for i in lost[:4]], "median_score": med,
+                "note": "synthetic l=100000 e=10%: ~1 pair in 4000; a batch with one takes ~27 ms instead of ~8 (tools/ga_tail.py)"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
@@ -427,6 +438,7 @@ def main():
             "gather_ms": gather_ms,
             "gather": gather,
             "verified_vs_oracle": verified,
+            "tail": tail,
         }
         print(json.dumps(line), flush=True)
     if dist_on:

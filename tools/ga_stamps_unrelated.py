@@ -14,8 +14,8 @@ for i in range(n):
 res, ops = engine.align(params, req, pat, txt)
 st = np.ascontiguousarray(ops[:, :64]).view(np.uint64).astype(np.float64)
 windows = L / 40.0
-names = ["window chars (HBM)", "pattern masks", "DC 16 levels", "DC 64 levels", "traceback", "ops stores"]
+names = ["window chars (HBM)", "pattern masks", "DC fast path (<= 15 edits)", "DC full-width path", "traceback", "ops stores"]
 tot = st[:, :6].sum(axis=1).mean()
 print("unrelated texts: ticks per pair %.0f, per window (~%d windows) %.0f; mean score %.0f" % (tot, windows, tot / windows, res["score"].mean()))
 for i, nm in enumerate(names):
-    print("%-20s %8.0f ticks/window %5.1f%%" % (nm, st[:, i].mean() / windows, 100 * st[:, i].mean() / tot))
+    print("%-28s %8.0f ticks/window %5.1f%%" % (nm, st[:, i].mean() / windows, 100 * st[:, i].mean() / tot))
