@@ -40,3 +40,8 @@ for l in open('$P/all_configs_kernel_timers.jsonl'):
     d=json.loads(l); print('%-32s %-18s %10.4g pairs/s %8.1f GCUPS %8.1f GB/s' % (d['config'], d['kernel'], d['pairs_per_s'], d['gcups'], d['algorithmic_GBps']))
 "
 cp -r $P $O/
+# the bench lines of the final code (one JSON line each; bench.py reads the PMC summaries written above)
+python3 bench.py > $P/bench_default.json 2> $O/bench_default.err
+python3 bench.py --backtrace --pairs 1048576 > $P/bench_cigar.json 2> $O/bench_cigar.err
+for c in cfg3 cfg4 cfg5; do python3 bench.py --config $c --steps 3 --warmup 1 > $P/bench_$c.json 2> $O/bench_$c.err; done
+cp -r $P $O/
