@@ -185,6 +185,7 @@ __device__ __forceinline__ int ga_dc16_scan(int lane, uint32_t eqcol, int n_, in
     ek[4] = e; e &= gl_dpp<0x142, 0xa>(ONES, e);         // row_bcast:15 into rows 1 and 3
     ek[5] = e; e &= gl_dpp<0x143, 0xc>(ONES, e);         // row_bcast:31 into rows 2 and 3
     uint32_t c = e & gl_lowmask(nm);                     // level 0: c_a = c_n[0] & eq_{n-1} & .. & eq_a
+    ga_lds_order();                                      // (the previous window's walk has read its rows: no store of this window moves above those loads)
     Rb[lane] = c;
     int d = 0;
     for (;;) {
