@@ -460,9 +460,15 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 // ---- table (BT): 16-byte stores where the lane's cells are all inside the row (off the critical path: after the posts)
                 if (BT && nvalid > 0) {
                     const size_t trow = (size_t)h * S + 7 + v0;
+                    if constexpr (K % 8 == 0) {
 #pragma unroll
-                    for (int q = 0; q < K / 8; ++q)
-                        *reinterpret_cast<uint4 *>(&TM[trow + 8 * q]) = make_uint4(dps_bits(Mp[4 * q]), dps_bits(Mp[4 * q + 1]), dps_bits(Mp[4 * q + 2]), dps_bits(Mp[4 * q + 3]));
+                        for (int q = 0; q < K / 8; ++q)
+                            *reinterpret_cast<uint4 *>(&TM[trow + 8 * q]) = make_uint4(dps_bits(Mp[4 * q]), dps_bits(Mp[4 * q + 1]), dps_bits(Mp[4 * q + 2]), dps_bits(Mp[4 * q + 3]));
+                    } else {   // K = 20: a lane's cells start on an 8-byte boundary only
+#pragma unroll
+                        for (int q = 0; q < K / 4; ++q)
+                            *reinterpret_cast<uint2 *>(&TM[trow + 4 * q]) = make_uint2(dps_bits(Mp[2 * q]), dps_bits(Mp[2 * q + 1]));
+                    }
                     if (SWG) {   // two bits per cell instead of the I and D planes: M != D, M != I (unsigned min with 1 of the xor)
                         uint32_t fw[2] = {0u, 0u};
 #pragma unroll
@@ -579,9 +585,10 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Shapes: K cells per lane (16 / 24 / 32) x nw wavefronts covering READ_SIZE columns. A row costs every wavefront a fixed
+// Shapes: K cells per lane (16 / 20 / 24 / 32) x nw wavefronts covering READ_SIZE columns. A row costs every wavefront a fixed
 // overhead (scan, mailboxes, boundary cell) plus K cells, and the CU's four SIMDs each take ceil(nw / 4) of the wavefronts:
-// the shape with the cheapest BUSIEST SIMD wins (config 4, READ_SIZE 10 112: 16 x 10 -> 3 wavefronts on two SIMDs; 24 x 7 -> 2).
+// the shape with the cheapest BUSIEST SIMD wins (config 4, READ_SIZE 10 112: 16 x 10 -> 3 wavefronts on two SIMDs; 24 x 7 -> 2 on three of
+// them and 1 on the fourth; round 4: 20 x 8 -> 2 on each).
 // AIM_STRIP_K forces K for experiments.
 struct StripShape { int k, nw, nwmax; };
 inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *sh, uint32_t n_pairs = 0)
@@ -589,7 +596,7 @@ inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *s
     const int rs = p.read_size;
     int best_k = 0, best_nw = 0;
     long best_cost = 0;
-    for (int k : {16, 24, 32}) {
+    for (int k : {16, 20, 24, 32}) {
         if (kn.strip_k > 0 && kn.strip_k != k) continue;
         const int nw = (rs + kWave * k - 1) / (kWave * k);
         if (nw > (k == 16 ? 12 : 8)) continue;
@@ -630,7 +637,7 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     // resident workgroups per CU: LDS, and the wavefronts the instantiation's register budget admits (64 * NWMAX threads per CU-quarter...)
     // (registers: K = 16: NW 82-114, SWG 117, SWG with CIGAR 160 VGPRs; K = 32: 130-240)
     const bool heavy = swg && (p.flags & AIM_FLAG_BACKTRACE);
-    const uint32_t waves_per_cu = sh.k >= 24 ? 8u : (heavy ? 12u : 16u);
+    const uint32_t waves_per_cu = sh.k >= 20 ? 8u : (heavy ? 12u : 16u);
     const uint32_t per_cu = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(waves_per_cu / (uint32_t)nw, (uint64_t)lds_workgroups_per_cu(*lds)));
     uint32_t g = resident_grid(kn, per_cu);
     const uint32_t need = ((n_pairs + 7u) / 8u) * 8u;
@@ -661,6 +668,7 @@ void dp_strip_launch(const aim_params_t &p, int k, uint32_t grid, uint32_t block
     do {                                                                                             \
         if (sh.k == 32) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 32, 8>));                             \
         else if (sh.k == 24) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 24, 8>));                        \
+        else if (sh.k == 20) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 20, 8>));                        \
         else if (sh.nwmax == 4) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 16, 4>));                     \
         else if (sh.nwmax == 8) AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 16, 8>));                     \
         else AIM_STRIP((dp_strip_kernel<ALGOV, BTV, 16, 12>));                                       \

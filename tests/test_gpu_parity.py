@@ -393,7 +393,7 @@ def test_fast_path_handles_non_acgt_bytes_itself(gpu, sample_bytes, err_bytes):
 
 
 # ------------------------------------------------------------------ long-read NW/SWG kernels (dp_strip: column-strip pipeline; dp_wave: row scan)
-DP_KERNELS = [dict(), dict(AIM_DPW_LEGACY="1"), dict(AIM_STRIP_K="32")]
+DP_KERNELS = [dict(), dict(AIM_DPW_LEGACY="1"), dict(AIM_STRIP_K="32"), dict(AIM_STRIP_K="20")]
 
 
 def _dp_kernel_name(env, params):

@@ -238,7 +238,7 @@ def main():
         if algo == "wfa" and r < 0.25: env["AIM_GROUP_G"] = rng.choice(["1", "2", "4", "8", "16", "64"])
         if algo == "wfa" and 0.25 <= r < 0.35: env["AIM_FORCE_WAVE"] = "1"
         if algo != "wfa" and r < 0.25: env["AIM_DPW_NW"] = rng.choice(["1", "2", "4"])
-        if algo != "wfa" and 0.25 <= r < 0.4: env["AIM_STRIP_K"] = rng.choice(["16", "24", "32"])
+        if algo != "wfa" and 0.25 <= r < 0.4: env["AIM_STRIP_K"] = rng.choice(["16", "20", "24", "32"])
         if algo != "wfa" and 0.7 <= r < 0.75: env["AIM_DPW_LEGACY"] = "1"
         if algo != "wfa" and 0.4 <= r < 0.5: env["AIM_FORCE_DPWAVE"] = "1"
         if algo != "wfa" and 0.5 <= r < 0.6: env["AIM_DPL_SEQ_LDS"] = "0"
