@@ -77,9 +77,12 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
     uint32_t ones = 0x00010001u;
     opaque(ones);
-    const dps2 gi2 = dps_splat(GAP_I), x2 = dps_splat(MISMATCH);
-    const short gd = (short)GAP_D;
-    (void)gd;
+    // TILTED coordinates (round 4): the registers hold T(h, v) = R(h, v) - GAP_I * h - GAP_D * v. The gap moves then cost nothing -- "up" is the old
+    // register itself, the chain along the row is a running minimum (two instructions per register instead of four) -- and the diagonal move
+    // carries the constant: mismatch - GAP_I - GAP_D or -GAP_I - GAP_D. All three candidates of a cell are shifted by the same amount, so every
+    // comparison (the minima, the direction bits and their tie order) is unchanged; the score is un-tilted once at the end. |T| <= GAP_I * tlen +
+    // GAP_D * plen < 8 000 (nw_reg_supported), INF = 16 000 stays out of reach.
+    const dps2 x2 = dps_splat(MISMATCH), c2 = dps_splat(-(GAP_I + GAP_D));
     // direction table: 8 dwords per row and lane (dword q: registers 8q .. 8q + 7, register k's two cells at bits 2k (low half) and
     // 16 + 2k (high half); bit 0 "not D", bit 1 "not I"); 4 dwords = one 16-byte unit, units lane-interleaved
     uint32_t *tbw = reinterpret_cast<uint32_t *>(tb);
@@ -161,10 +164,12 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
 #pragma unroll
         for (int j = 0; j < NPK; ++j) {
             const int v0 = 2 * j - s0, v1 = v0 + 1;
-            Mp[j] = (uint32_t)(v0 >= 0 ? v0 * GAP_D : kRegInf) | ((uint32_t)(v1 >= 0 ? v1 * GAP_D : kRegInf) << 16);
+            Mp[j] = (uint32_t)(v0 >= 0 ? 0 : kRegInf) | ((uint32_t)(v1 >= 0 ? 0 : kRegInf) << 16);   // (tilted: R(0, v) = v * GAP_D is 0)
         }
         // plen == tlen + 1: flat cell (0, W) IS cell (1, 0), and the column initialisation wrote 1 * GAP_I there after the row's (nw.c:116-128)
-        if (isW) Mp[NPK - 1] = (Mp[NPK - 1] & 0xffffu) | ((uint32_t)GAP_I << 16);
+        if (isW) Mp[NPK - 1] = (Mp[NPK - 1] & 0xffffu) | ((uint32_t)(uint16_t)(GAP_I - GAP_D * W) << 16);
+        // isW lanes: B(h) = raw cell (h - 1, W), presented as cell (h, 0): un-tilt at (h - 1, W), tilt at (h, 0) = + GAP_D * W - GAP_I
+        const uint32_t kW = (uint32_t)(uint16_t)(GAP_D * W - GAP_I);
         // isW lanes: where the boundary is injected (index s0 as an all-ones field of the window's registers)
         uint32_t inj[kRegWin];
 #pragma unroll
@@ -185,8 +190,8 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             constexpr int J0 = decltype(j0_tag)::value;
             const uint32_t tword = ldsT[((h - 1) >> 2) * kWave + lane];
             const uint32_t tch2 = ((tword >> (((h - 1) & 3) * 8)) & 0xffu) * 0x00010001u;
-            // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, which the recurrence delivers by itself)
-            const uint32_t binj = (h == 1 ? (uint32_t)GAP_I : (src[NPK - 1] >> 16)) * 0x00010001u;
+            // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, set above), re-tilted for (h, 0)
+            const uint32_t binj = (((src[NPK - 1] >> 16) + kW) & 0xffffu) * 0x00010001u;
             uint32_t rprev = (uint32_t)kRegInf << 16;         // the register left of this one: m[index - 1] in its HIGH half
             dps2 code[8];                                     // BACKTRACE: direction bits of the registers of the current group of eight
             uint32_t dirw[8];
@@ -198,29 +203,24 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
                 const uint32_t oldj = src[j];
                 const dps2 diag = dps_from(__builtin_amdgcn_alignbit(oldj, oldprev, 16));   // {R_{h-1}[2j - 1], R_{h-1}[2j]}
                 const dps2 f = dps_from(pk_ne01(pc[j], tch2, ones));
-                const dps2 sub = f * x2 + diag;
-                const dps2 ins = dps_from(oldj) + gi2;
+                const dps2 sub = (f * x2 + c2) + diag;
+                const dps2 ins = dps_from(oldj);                 // (tilted: the move from the row above costs nothing)
                 dps2 A = dps_min(sub, ins);
                 if (j < kRegWin) A = dps_from((binj & inj[j]) | (dps_bits(A) & ~inj[j]));
-                // the gap chain, two cells: lo = min(A.lo, m[index - 1] + GAP_D), hi = min(A.hi, lo + GAP_D), result packed {hi, lo}. SDWA by hand:
-                // the second minimum writes the HIGH half of the register that holds lo (dst_unused:UNUSED_PRESERVE) and the next register's
-                // first addition reads it from there -- as C the compiler keeps lo and hi in two registers and packs them with a v_perm.
+                // the gap chain, two cells (tilted: a running minimum): lo = min(A.lo, m[index - 1]), hi = min(A.hi, lo), result packed {hi, lo}. SDWA by
+                // hand: the second minimum writes the HIGH half of the register that holds lo (dst_unused:UNUSED_PRESERVE) and the next register's
+                // first minimum reads it from there -- as C the compiler keeps lo and hi in two registers and packs them with a v_perm.
                 uint32_t t1, res;   // (ONE asm statement: the compiler pads every asm statement with an s_nop)
                 if (!BT) {
-                    asm("v_add_u16_sdwa %1, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                        "v_min_i16 %0, %3, %1\n\t"
-                        "v_add_u16 %1, %0, %4\n\t"
-                        "v_min_i16_sdwa %0, %3, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
-                        : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)), "v"((uint32_t)(uint16_t)gd));
+                    asm("v_min_i16_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+                        "v_min_i16_sdwa %0, %2, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
+                        : "=&v"(res) : "v"(rprev), "v"(dps_bits(A)));
                 } else {
-                    // the same chain with both gap candidates kept, packed {m[2j] + GAP_D, m[2j - 1] + GAP_D} (t1), for the direction bits (a
-                    // write with dst_sel needs one wait state before the next instruction reads the register: s_nop)
-                    asm volatile("v_add_u16_sdwa %1, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                        "v_min_i16 %0, %3, %1\n\t"
-                        "v_add_u16_sdwa %1, %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:DWORD\n\t"
-                        "s_nop 0\n\t"
-                        "v_min_i16_sdwa %0, %3, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1"
-                        : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)), "v"((uint32_t)(uint16_t)gd));
+                    // the same chain with both gap candidates kept, packed {m[2j], m[2j - 1]} = the cells' left neighbours (t1), for the direction bits
+                    asm volatile("v_min_i16_sdwa %0, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+                        "v_alignbit_b32 %1, %0, %2, 16\n\t"
+                        "v_min_i16_sdwa %0, %3, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
+                        : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)));
                     const uint32_t sD = dps_bits(A - dps_from(t1)), sI = dps_bits(sub - ins);   // sign bits: chain lost strictly / insertion lost strictly
                     const uint32_t neD = (sD >> 15) & 0x00010001u;
                     uint32_t cj = ((sI >> 14) & 0x00020002u) | neD;
@@ -232,6 +232,11 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
                         dirw[j >> 3] = dps_bits((c67 * c16 + c45) * c256 + (c23 * c16 + c01));
 #pragma unroll
                         for (int k = 0; k < 8; ++k) code[k] = dps_splat(0);
+                        if ((j >> 3) == 3 && mine && h <= tlen) {   // the first four dwords leave as soon as they are complete (their registers are free for the rest of the row)
+                            typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                            aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]};
+                            __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0)));
+                        }
                     }
                 }
                 dst[j] = res;
@@ -239,11 +244,11 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
                 oldprev = oldj;
 
             }
-            if (h == tlen) score = (int)(dst[NPK - 1] >> 16); // R_tlen[plen]
+            if (h == tlen) score = (int)(int16_t)(dst[NPK - 1] >> 16) + GAP_I * tlen + GAP_D * plen;   // R_tlen[plen], un-tilted
             if (BT && mine && h <= tlen) {                     // the row's direction bits: two 16-byte stores per lane
                 typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]}, w1 = {dirw[4], dirw[5], dirw[6], dirw[7]};
-                __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0)));
+                aim_u32x4 w1 = {dirw[4], dirw[5], dirw[6], dirw[7]};
+                if (NPK <= 32) { aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]}; __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0))); }
                 __builtin_nontemporal_store(w1, reinterpret_cast<aim_u32x4 *>(&TBW(h, 4)));
             }
         };
