@@ -65,6 +65,11 @@ def test_bench_other_baseline_configs_run_through_the_same_harness(built):
         d = _last_json(r.stdout)
         assert d["verified_vs_oracle"] is True and d["value"] > 0 and d["roofline"]["bound"] == bound and cfg in d["config"]["workload"]
         assert d["cpu_baseline"]["value"] > 0
+        if cfg == "cfg5":    # round 4: lanes switched on next to SIMD time, and whether the batch holds a pair that lost the diagonal
+            assert d["tail"]["pairs_that_lost_the_diagonal"] == 0 and d["tail"]["median_score"] > 0
+            assert d["roofline"]["useful_lane_frac"] is None or 0 < d["roofline"]["useful_lane_frac"] <= 1
+        else:
+            assert d["tail"] is None
     env = dict(os.environ, AIM_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29732", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3", "--pairs", "2048", "--steps", "2",
