@@ -250,9 +250,17 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const int tfwd = lane < n ? (int)gT[ti + lane] : 0x300;
             AIM_GASTAMP(0);   // window characters from HBM
             // lane j: PM of text column j -- bit i = 0 <=> p[m-1-i] == t[j] -- from one ballot per DISTINCT character of the window (any
-            // byte values: the reference family compares raw bytes)
+            // byte values: the reference family compares raw bytes). The four bases first, straight-line (the data-dependent loop costs a scalar /
+            // vector round trip per character); whatever else the window holds goes through the loop, which then usually does not run.
             uint64_t mypm = ONES;
-            for (uint64_t rest = __ballot(lane < n); rest;) {
+            {
+                const uint64_t eA = __ballot(prev == 'A'), eC = __ballot(prev == 'C'), eG = __ballot(prev == 'G'), eT = __ballot(prev == 'T');
+                mypm = tfwd == 'A' ? ~eA : mypm;
+                mypm = tfwd == 'C' ? ~eC : mypm;
+                mypm = tfwd == 'G' ? ~eG : mypm;
+                mypm = tfwd == 'T' ? ~eT : mypm;
+            }
+            for (uint64_t rest = __ballot(lane < n && tfwd != 'A' && tfwd != 'C' && tfwd != 'G' && tfwd != 'T'); rest;) {
                 const int c = __builtin_amdgcn_readlane(tfwd, (int)__builtin_ctzll(rest));
                 const uint64_t pm = ~__ballot(prev == c);
                 if (tfwd == c) mypm = pm;
