@@ -176,7 +176,7 @@ def test_genasm_windows_that_need_more_than_15_edits(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("l,err,n", [(30, 0.1, 300), (64, 0.05, 300), (100, 0.1, 1000), (150, 0.3, 400), (300, 0.25, 300), (1000, 0.1, 300), (500, 0.6, 100),
                                      (5000, 0.02, 64), (3000, 0.15, 64)])
-def test_genasm_long_variant_matches_oracle(gpu, monkeypatch, l, err, n):
+def test_genasm_window_shapes_match_oracle(gpu, monkeypatch, l, err, n):
     """Short last windows, windows with m != n, windows beyond 15 edits, with and without ops -- same output as the oracle. (Until round 4 there
     were two kernel variants and this test forced each onto the other's shapes with AIM_GA_LONG; the banded scan path now serves every window
     and the variable is ignored.)"""

@@ -22,7 +22,7 @@ python3 tools/pmc_summary.py --out $P/wfa_group_tb_pmc_summary.json --kernel wfa
    --note "cfg3's traceback kernel (one pair per lane over the compact per-pair history regions)." \
    -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_grouptb.log 2>&1; tail -1 $O/pmc_grouptb.log
 python3 tools/pmc_summary.py --out $P/genasm_wave_pmc_summary.json --kernel genasm_wave_kernel --pairs 4096 \
-   --note "cfg5: GenASM l=100000 e=10% with CIGAR, 4096 pairs = 16 wavefronts per CU, LONG variant (parity unpinned)." \
+   --note "cfg5: GenASM l=100000 e=10% with CIGAR, 4096 pairs = 16 wavefronts per CU: banded words, one DPP scan per error level, column-bound walk (parity unpinned)." \
    -- python3 tools/bench_configs.py genasm_l100000_e10_cigar_n4096 > $O/pmc_genasm.log 2>&1; tail -1 $O/pmc_genasm.log
 python3 tools/pmc_summary.py --out $P/nw_reg_pmc_summary.json --kernel nw_reg_kernel --pairs 1048576 \
    --note "NW l=100 e=1% score-only, 1 Mi pairs: the DP row in registers (dp_reg.hpp); per-lane 112-byte rows read as dwords: FETCH_SIZE kept raw." \
