@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
         char *ops = BT ? a.ops + (uint64_t)pair * 2 * rs : nullptr;
         const int cap = 2 * rs;
         int pi = 0, ti = 0, nops = 0, dist = 0, status = AIM_PAIR_OK;   // wave-uniform
-        bool wide_prev = false;
+        int wide_run = 0;                                    // consecutive windows that needed more than 15 edits
 #ifdef AIM_GA_STAMPS
         unsigned long long gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, glast;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(glast) :: "memory");
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
             const bool regular = m == kGaW && n == kGaW && !last;   // 2 499 of the 2 500 windows of a 100-kb pair: the fast path is compiled twice, once with these as constants
             uint32_t eq_own = 0, c_own = 0;
             int d = -1;
-            if (!wide_prev) d = regular ? ga_dc16_scan<true>(lane, gl_band_eq(~mypm, lane, kGaW), kGaW, 16, Rb, eq_own, c_own)
+            if (wide_run < 3) d = regular ? ga_dc16_scan<true>(lane, gl_band_eq(~mypm, lane, kGaW), kGaW, 16, Rb, eq_own, c_own)
                                         : ga_dc16_scan<false>(lane, gl_band_eq(~mypm, lane, m), n, 16 + n - m, Rb, eq_own, c_own);
             const bool slow = d < 0;           // wave-uniform
             AIM_GASTAMP(2);   // DC, 16 levels
@@ -282,7 +282,9 @@ __global__ __launch_bounds__(64) void genasm_wave_kernel(KArgs a)
                 d = regular ? ga_dc64_scan<true>(lane, ~mypm, kGaW, kGaW, Rg, weq, wc) : ga_dc64_scan<false>(lane, ~mypm, n, m, Rg, weq, wc);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront reads its own slab back below
             }
-            wide_prev = slow && (d < 0 || d > 15);   // a pair that has lost the diagonal stays lost: its next window goes straight to the full-width path
+            // a pair that has lost the diagonal stays lost: after three wide windows in a row the next ones go straight to the full-width path, until one
+            // of them aligns within 15 edits again (reads with ~20 % errors alternate between the two paths: they keep trying the fast one first)
+            wide_run = (slow && (d < 0 || d > 15)) ? wide_run + 1 : 0;
             AIM_GASTAMP(3);   // DC, 64 levels (rare)
             int ca = 0, cb = 0, wn = 0;           // consumed text / pattern characters, ops of this window (uniform)
             // GenASM-TB. The window's ops live in two registers (lane i: ops i and 64 + i), pre-set to 'M': a run of matches costs

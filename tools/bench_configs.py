@@ -55,6 +55,8 @@ CONFIGS = {
     "genasm_l100000_e10_score_n8192": dict(algo="genasm", l=100000, e=0.10, n=8192, kw=dict()),
     "genasm_l100000_e10_cigar_n8192": dict(algo="genasm", l=100000, e=0.10, n=8192, kw=dict(backtrace=True)),
     "genasm_l10000_e10_cigar": dict(algo="genasm", l=10000, e=0.10, n=8192, kw=dict(backtrace=True)),
+    "genasm_l10000_e20_cigar": dict(algo="genasm", l=10000, e=0.20, n=8192, kw=dict(backtrace=True)),
+    "genasm_l10000_e30_cigar": dict(algo="genasm", l=10000, e=0.30, n=8192, kw=dict(backtrace=True)),
     "genasm_l100_e10_cigar": dict(algo="genasm", l=100, e=0.10, n=1 << 18, kw=dict(backtrace=True)),
 }
 
