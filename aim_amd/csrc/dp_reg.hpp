@@ -44,7 +44,10 @@ constexpr int kRegWin = 16;        // registers (32 indices) in which a row may 
 constexpr int kRegInf = 16000;     // the value left of a row's start
 
 // Shapes: NPK registers per row = 2 * NPK indices > READ_SIZE
-inline int nw_reg_npk(int read_size, bool bt = false) { return read_size <= 80 ? 42 : (read_size <= 112 ? 58 : (read_size <= 128 && !bt ? 66 : 0)); }   // (66: score-only -- with the direction bits it would not fit 256 VGPRs)
+// Registers of a row. The launchers' READ_SIZE rule (run-nw-pim-wram.py: ceil((l + l*e + 7) / 8) * 8) leaves pattern and text at READ_SIZE - 7 characters at
+// most: a row of 2 * NPK >= READ_SIZE - 6 indices holds every pair they produce; a longer pattern or text (legal: up to READ_SIZE) goes to the to-do list.
+// (Until late in round 4: 42 / 58 / 66 = READ_SIZE + 4 indices, 7-10 % of them never used.)
+inline int nw_reg_npk(int read_size, bool bt = false) { return read_size <= 80 ? 38 : (read_size <= 112 ? 54 : (read_size <= 128 && !bt ? 62 : 0)); }   // (62: score-only -- the direction table has 8 dwords per row)
 
 inline bool nw_reg_supported(const aim_params_t &p)
 {
@@ -57,7 +60,7 @@ inline bool nw_reg_supported(const aim_params_t &p)
 __host__ __device__ inline size_t nw_reg_lds_bytes(const aim_params_t &p)   // text image / ops staging + the pair queue (512 B)
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    const int npk = p.read_size <= 80 ? 42 : (p.read_size <= 112 ? 58 : 66);
+    const int npk = p.read_size <= 80 ? 38 : (p.read_size <= 112 ? 54 : 62);
     const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave;
     return ((bt && o > t) ? o : t) + 512;
 }
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             rc.pattern_len = rc.text_len = 0; rc.padding = 0; rc.idx = 0;
             if (act) rc = load_request(a, cand);
             // this kernel's pairs: no tail cells (plen <= tlen + 1) and a row start inside the window
-            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 && rc.pattern_len >= RSK - 2 * kRegWin;
+            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 && rc.pattern_len >= RSK - 2 * kRegWin &&
+                              rc.pattern_len <= RSK - 1 && rc.text_len <= 4 * NWD;   // ... and both sequences inside the row / the staged text image
             const unsigned long long rest = __ballot(act && !take), mask_below = (1ull << lane) - 1ull;
             if (rest) {   // everything else: the to-do list of nw_lane_kernel (one atomic per wavefront)
                 uint32_t base = 0;
@@ -335,9 +339,9 @@ void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs
         if (bt) hipLaunchKernelGGL((nw_reg_kernel<N, true>), dim3(grid), dim3(kWave), lds, s, ka);             \
         else hipLaunchKernelGGL((nw_reg_kernel<N, false>), dim3(grid), dim3(kWave), lds, s, ka);               \
     } while (0)
-    if (npk == 42) AIM_NWREG(42);
-    else if (npk == 58) AIM_NWREG(58);
-    else if (npk == 66 && !bt) hipLaunchKernelGGL((nw_reg_kernel<66, false>), dim3(grid), dim3(kWave), lds, s, ka);
+    if (npk == 38) AIM_NWREG(38);
+    else if (npk == 54) AIM_NWREG(54);
+    else if (npk == 62 && !bt) hipLaunchKernelGGL((nw_reg_kernel<62, false>), dim3(grid), dim3(kWave), lds, s, ka);
 #undef AIM_NWREG
 }
 #else
