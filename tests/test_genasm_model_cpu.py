@@ -156,3 +156,78 @@ def test_full_width_scan_equals_the_recurrence():
         for d in range(64):
             for a in range(n):
                 assert C[d][n - 1 - a] & mask == (~R[a][d]) & mask, (m, n, d, a)
+
+
+def walk_textbook(R, p, t, last, levels):
+    """GenASM-TB of one window over the full vectors, the oracle's rule order (oracle/genasm_oracle.c); None: no alignment within `levels`."""
+    m, n = len(p), len(t)
+    d = next((k for k in range(levels) if not (R[0][k] >> (m - 1)) & 1), None)
+    if d is None:
+        return None
+    ok = lambda r, b: b >= m or not (r >> (m - 1 - b)) & 1
+    a = b = 0
+    ops = []
+    while True:
+        if b == m or (not last and (a >= 40 or b >= 40)):
+            break
+        if a == n:
+            ops.append("D"); b += 1; d -= 1; continue
+        if p[b] == t[a] and ok(R[a + 1][d], b + 1):
+            ops.append("M"); a += 1; b += 1; continue
+        if d > 0 and ok(R[a + 1][d - 1], b + 1):
+            ops.append("X"); a += 1; b += 1; d -= 1; continue
+        if d > 0 and ok(R[a][d - 1], b + 1):
+            ops.append("D"); b += 1; d -= 1; continue
+        if d > 0 and ok(R[a + 1][d - 1], b):
+            ops.append("I"); a += 1; d -= 1; continue
+        raise AssertionError("no rule applies")
+    return "".join(ops), a, b
+
+
+def walk_banded(C, p, t, last):
+    """walk_any of genasm_wave.hpp over the banded words: the run of matches is bit kb = 15 + ca - cb of (c_{a+1}[d] & eq_a) in consecutive
+    columns; the edit after it is decided by bits kb, kb - 1, kb + 1 of level d - 1 at the one cell where the run stopped."""
+    m, n = len(p), len(t)
+    d = next((k for k in range(16) if (C[0][k] >> 15) & 1), None)
+    if d is None:
+        return None
+    ca = cb = 0
+    ops = []
+    while True:
+        if ca == n:
+            k = (m - cb) if last else (0 if ca >= 40 else max(min(m, 40) - cb, 0))
+            ops += ["D"] * k; cb += k; d -= k
+            break
+        kb = 15 + ca - cb
+        lim = min(n - ca, m - cb)
+        if not last:
+            lim = min(lim, 40 - max(ca, cb))
+        run = 0
+        while run < lim and (C[ca + run + 1][d] & band_eq(eq_mask(p, t[ca + run]), ca + run, m)) >> kb & 1:
+            run += 1
+        ops += ["M"] * run; ca += run; cb += run
+        if cb == m or (not last and (ca >= 40 or cb >= 40)):
+            break
+        if ca == n:
+            continue
+        assert d > 0
+        s1, s0 = C[ca + 1][d - 1], C[ca][d - 1]
+        op = "X" if (s1 >> kb) & 1 else "D" if (s0 >> ((kb - 1) & 31)) & 1 else "I" if (s1 >> ((kb + 1) & 31)) & 1 else None
+        assert op is not None
+        ops.append(op); ca += op != "D"; cb += op != "I"; d -= 1
+    return "".join(ops), ca, cb
+
+
+def test_banded_walk_equals_the_textbook_walk():
+    rng = random.Random(13)
+    seen_last = seen_irregular = 0
+    for _ in range(400):
+        p, t = random_window(rng)
+        last = rng.random() < 0.4
+        R, C = textbook(p, t, 16), banded(p, t)
+        want = walk_textbook(R, p, t, last, 16)
+        got = walk_banded(C, p, t, last)
+        assert want == got, (len(p), len(t), last, want, got)
+        if want is not None:
+            seen_last += last; seen_irregular += (len(p) != 64 or len(t) != 64)
+    assert seen_last > 20 and seen_irregular > 20
