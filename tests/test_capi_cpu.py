@@ -194,3 +194,34 @@ def test_plans_follow_the_device_compute_unit_count(built):
             assert k0 == k1 and g1 % 8 == 0
             exp = g0 * cus // 256
             assert g1 == exp or (k0.startswith("dp_") and exp - 64 <= g1 <= exp), (k0, cus, g0, g1)   # (table slabs: the 16-GB planning bound may trim a few workgroups)
+
+
+def test_round4_plan_shapes(built):
+    """The shapes round 4 chose, as plans (no device needed): the strip kernel's 20 cells per lane -- 8 wavefronts = two per SIMD on every SIMD for
+    READ_SIZE ~10 000 with about a pair per CU, one wavefront per pair at READ_SIZE 1 064 --, GenASM's single kernel at 24 wavefronts per CU
+    with 4 KB of LDS, NW on short reads with the row in registers up to READ_SIZE 128 (112 with CIGAR)."""
+    import ctypes as C
+    from aim_amd import capi, engine
+    lib = capi.load()
+
+    def plan(p, n):
+        buf = C.create_string_buffer(1024)
+        assert lib.aim_plan_describe(C.byref(p), n, buf, 1024) == 0
+        return buf.value.decode()
+    env = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("AIM_") and k != "AIM_LIB"}
+    try:
+        l = plan(engine.make_params("swg", 500, 10112, backtrace=True), 256)
+        assert "dp_strip_kernel" in l and "cells_per_lane=20" in l and "wavefronts_per_pair=8" in l and "block=512" in l
+        l = plan(engine.make_params("swg", 250, 1064, backtrace=True), 65536)
+        assert "cells_per_lane=20" in l and "wavefronts_per_pair=1" in l
+        l = plan(engine.make_params("swg", 150, 3064, backtrace=True), 1024)
+        assert "cells_per_lane=16" in l and "wavefronts_per_pair=3" in l
+        for rs, n, grid in ((110008, 4096, 4096), (110008, 1 << 20, 24 * 256), (120, 1 << 18, 24 * 256)):
+            l = plan(engine.make_params("genasm", 0, rs, backtrace=True), n)
+            assert l.startswith("genasm_wave_kernel") and "grid=%d " % grid in l and "lds=4160" in l, l
+        assert plan(engine.make_params("nw", 4, 128), 1 << 20).startswith("nw_reg_kernel")
+        assert plan(engine.make_params("nw", 4, 128, backtrace=True), 1 << 20).startswith("nw_lane_kernel")
+        assert plan(engine.make_params("nw", 4, 112, backtrace=True), 1 << 20).startswith("nw_reg_kernel")
+        assert plan(engine.make_params("nw", 4, 112, gap=60), 1 << 20).startswith("nw_lane_kernel")     # costs too large for INF = 16 000 to stay out of reach
+    finally:
+        os.environ.update(env)
