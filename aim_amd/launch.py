@@ -105,6 +105,10 @@ def host_command(cfg):
         cmd.append("--reduce")
     if cfg["swg_w16"]:
         cmd.append("--swg-w16")
+    if cfg["algo"] == "genasm":
+        # four batches in flight per device: a pair that loses the diagonal keeps one wavefront busy long after its batch is done, and the
+        # next batches run under that tail (16 384 pairs of 100 kb through the CLI: 1 / 2 / 4 slots = 1.3 / 2.1 / 4.3e5 pairs/s)
+        cmd += ["--slots", "4"]
     return cmd
 
 
