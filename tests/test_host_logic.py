@@ -84,6 +84,11 @@ def test_launch_dry_run_command(built, capsys):
     out = capsys.readouterr().out
     assert "-DMAX_SCORE=5 -DREAD_SIZE=112 -DMATCH=0 -DMISMATCH=3 -DGAP_O=4 -DGAP_E=1 -DREDUCE -DBACKTRACE" in out
     assert "--algo wfa --max-score 5 --read-size 112" in out and "--nr-dpus 4" in out and "--backtrace --reduce" in out
+    assert "--slots" not in out
+    # GenASM long reads: four batches in flight per device (a pair that loses the diagonal outlasts its batch)
+    assert launch.main(["genasm", "-i", "a", "-o", "b", "-l", "100000", "-e", "0.1", "-n", "64", "-b", "--dry-run"]) == 0
+    out = capsys.readouterr().out
+    assert "--algo genasm" in out and "--read-size 110008" in out and "--slots 4" in out
 
 
 def test_gen_dataset_cli_round_trips_through_the_parser(tmp_path, built):
