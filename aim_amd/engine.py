@@ -30,11 +30,15 @@ def launcher_sizes(algo, read_length, error, mismatch=3, gap_o=4, gap_e=1, gap=4
 
 
 def make_params(algo, max_score, read_size, match=0, mismatch=3, gap_o=4, gap_e=1, gap=4, backtrace=False,
-                reduce=False, swg_w16=False, req8=False, res8=False):
+                reduce=False, swg_w16=False, req8=False, res8=False, gap_i=None, gap_d=None):
+    """`gap` is the launchers' single NW gap cost (run-nw-pim-wram.py: -DGAP_I = -DGAP_D); `gap_i` / `gap_d` set the two macros of
+    nw.c:67-153 apart (NW/DPU-WRAM/common/common.h GAP_I, GAP_D)."""
     a = ALGO_BY_NAME[algo] if isinstance(algo, str) else algo
+    gap_i = gap if gap_i is None else gap_i
+    gap_d = gap if gap_d is None else gap_d
     flags = (FLAG_BACKTRACE if backtrace else 0) | (FLAG_REDUCE if reduce else 0) | (FLAG_SWG_W16 if swg_w16 else 0)
     flags |= (FLAG_REQ8 if req8 else 0) | (FLAG_RES8 if res8 else 0)
-    return Params(a, match, mismatch, gap_o, gap_e, gap, gap, max_score, read_size, flags)
+    return Params(a, match, mismatch, gap_o, gap_e, gap_i, gap_d, max_score, read_size, flags)
 
 
 def params_for(algo, read_length, error, **kw):

@@ -9,7 +9,7 @@
  * time through -D macros is passed at run time as optional flags after the
  * three positional arguments (aim_amd/launch.py emits them):
  *     --algo nw|swg|wfa  --max-score S  --read-size R  --match M --mismatch X
- *     --gap-o G --gap-e A --gap G  --backtrace  --reduce  --swg-w16
+ *     --gap-o G --gap-e A --gap G [--gap-i GI --gap-d GD]  --backtrace  --reduce  --swg-w16
  *     --nr-dpus D   logical partition count of the reference (host.c:191: the
  *                   file is consumed in D blocks of ROUND_UP_8(n/D) pairs; n is
  *                   not a cap) -- kept so the set of aligned pairs is identical
@@ -948,6 +948,8 @@ int main(int argc, char *argv[])
         else if (!strcmp(f, "--gap-o")) { p.gap_o = atoi(v); ++i; }
         else if (!strcmp(f, "--gap-e")) { p.gap_e = atoi(v); ++i; }
         else if (!strcmp(f, "--gap")) { p.gap_i = p.gap_d = atoi(v); ++i; }
+        else if (!strcmp(f, "--gap-i")) { p.gap_i = atoi(v); ++i; }   /* NW: -DGAP_I / -DGAP_D set apart (nw.c:67-153) */
+        else if (!strcmp(f, "--gap-d")) { p.gap_d = atoi(v); ++i; }
         else if (!strcmp(f, "--nr-dpus")) { nr_dpus = (uint32_t)atoi(v); ++i; }
         else if (!strcmp(f, "--gpus")) { gpus = (uint32_t)atoi(v); ++i; }
         else if (!strcmp(f, "--batch")) { batch = (uint32_t)atoi(v); ++i; }

@@ -42,8 +42,10 @@ def load():
 
 
 def params(algo, max_score, read_size, match=0, mismatch=3, gap_o=4, gap_e=1, gap=4, backtrace=False, reduce=False,
-           swg_cell_bytes=0):
-    return OrcParams(ALGO[algo], match, mismatch, gap_o, gap_e, gap, gap, max_score, read_size, int(backtrace),
+           swg_cell_bytes=0, gap_i=None, gap_d=None):
+    gap_i = gap if gap_i is None else gap_i
+    gap_d = gap if gap_d is None else gap_d
+    return OrcParams(ALGO[algo], match, mismatch, gap_o, gap_e, gap_i, gap_d, max_score, read_size, int(backtrace),
                      int(reduce), swg_cell_bytes)
 
 

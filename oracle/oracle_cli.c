@@ -38,7 +38,7 @@ int main(int argc, char **argv)
     long n = 0;
     int len = 0, nr_dpus = 1, threads = 1, ms_override = -1, rs_override = -1;
     double err = 0.0;
-    int m = 0, x = 3, g = 4, a = 1;
+    int m = 0, x = 3, g = 4, a = 1, gi = -1, gd = -1;
     for (int i = 2; i < argc; ++i) {
         const char *f = argv[i];
         const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
@@ -58,11 +58,13 @@ int main(int argc, char **argv)
         else if (!strcmp(f, "-t")) { threads = atoi(v); ++i; }
         else if (!strcmp(f, "--max-score")) { ms_override = atoi(v); ++i; }
         else if (!strcmp(f, "--read-size")) { rs_override = atoi(v); ++i; }
+        else if (!strcmp(f, "--gap-i")) { gi = atoi(v); ++i; }   /* NW: -DGAP_I / -DGAP_D set apart (nw.c:67-153) */
+        else if (!strcmp(f, "--gap-d")) { gd = atoi(v); ++i; }
         else if (!strcmp(f, "--swg-cell")) { p.swg_cell_bytes = atoi(v); ++i; }
         else { fprintf(stderr, "unknown flag %s\n", f); return 2; }
     }
     if (!in || !out || n <= 0 || len <= 0) { fprintf(stderr, "need -i -o -n -l -e\n"); return 2; }
-    p.match = m; p.mismatch = x; p.gap_o = g; p.gap_e = a; p.gap_i = g; p.gap_d = g;
+    p.match = m; p.mismatch = x; p.gap_o = g; p.gap_e = a; p.gap_i = gi >= 0 ? gi : g; p.gap_d = gd >= 0 ? gd : g;
     orc_launcher_sizes(p.algo, len, err, x, g, a, g, &p.max_score, &p.read_size);
     if (ms_override >= 0) p.max_score = ms_override;
     if (rs_override >= 0) p.read_size = rs_override;

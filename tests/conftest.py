@@ -64,9 +64,10 @@ def judge_cases():
     """The wider reference digests the judges recorded: 14 in round 1 (tests/golden/judge_r01_cases.json), 14 in round 2
     (judge_r02_cases.json: dynamic-bounds / READ_SIZE-80 lane shapes, l = 150, MAX_SCORE 10, MRAM-variant overflow) and 20 in
     round 3 (judge_r03_cases.json: score-unit loop 4/6/2 and 6/2/2, READ_SIZE 136 ... 184 with CIGAR, rows of 96, NW / SWG at
-    cfg4's real size). Rows where the reference aborts are in judge_abort_cases()."""
+    cfg4's real size) and 13 in round 4 (judge_r04_cases.json: NW with GAP_I != GAP_D, the READ_SIZE 80 / 128 register shapes,
+    WFA-adaptive at l = 10 000 / 4 000 / 2 000). Rows where the reference aborts are in judge_abort_cases()."""
     cases = []
-    for name in ("judge_r01_cases.json", "judge_r02_cases.json", "judge_r03_cases.json"):
+    for name in ("judge_r01_cases.json", "judge_r02_cases.json", "judge_r03_cases.json", "judge_r04_cases.json"):
         cases += [c for c in json.load(open(os.path.join(GOLDEN, name)))["cases"] if "abort" not in c]
     return cases
 
@@ -83,7 +84,7 @@ def judge_dataset_cases():
 
 
 def judge_costs(case):
-    return {k: case[k] for k in ("mismatch", "gap_o", "gap_e", "gap") if k in case}
+    return {k: case[k] for k in ("mismatch", "gap_o", "gap_e", "gap", "gap_i", "gap_d") if k in case}
 
 
 def judge_case_input(case):

@@ -30,7 +30,7 @@ def _oracle_params(oracle, params, algo):
     red = bool(params.flags & capi.FLAG_REDUCE)
     cellb = 2 if (params.flags & capi.FLAG_SWG_W16) else 0
     return oracle.params(algo, params.max_score, params.read_size, match=params.match, mismatch=params.mismatch,
-                         gap_o=params.gap_o, gap_e=params.gap_e, gap=params.gap_i, backtrace=bt, reduce=red,
+                         gap_o=params.gap_o, gap_e=params.gap_e, gap_i=params.gap_i, gap_d=params.gap_d, backtrace=bt, reduce=red,
                          swg_cell_bytes=cellb)
 
 
@@ -101,6 +101,7 @@ def _host_cli(case, inp, out, cwd, extra=()):
            "--algo", case["algo"], "--max-score", str(case["max_score"]), "--read-size", str(case["read_size"]),
            "--nr-dpus", str(case.get("nr_dpus", 1)), "--mismatch", str(c.get("mismatch", 3)), "--gap-o", str(c.get("gap_o", 4)),
            "--gap-e", str(c.get("gap_e", 1)), "--gap", str(c.get("gap", 4))]
+    cmd += sum(([f, str(c[k])] for f, k in (("--gap-i", "gap_i"), ("--gap-d", "gap_d")) if k in c), [])
     cmd += (["--backtrace"] if case["backtrace"] else []) + (["--reduce"] if case.get("reduce") else [])
     cmd += ["--swg-w16"] if case.get("swg_cell_bytes", 0) == 2 else []
     return subprocess.run(cmd + list(extra), capture_output=True, text=True, cwd=str(cwd))
@@ -1549,3 +1550,44 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
     monkeypatch.delenv("AIM_NO_NW_REG")
     res1, ops1 = engine.align(params, req, pat, txt)
     assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
+
+
+# ------------------------------------------------------------------ NW with GAP_I != GAP_D
+@pytest.mark.parametrize("gi,gd,mism", [(2, 7, 3), (7, 3, 5), (1, 6, 2)])
+@pytest.mark.parametrize("bt", [False, True])
+@pytest.mark.parametrize("kernel", ["nw_reg", "nw_lane", "dp_strip", "dp_wave"])
+def test_nw_asymmetric_gap_costs_on_every_nw_kernel(gpu, monkeypatch, kernel, bt, gi, gd, mism):
+    """nw.c:67-153 takes GAP_I (move along the pattern) and GAP_D (move along the text) as two macros; the launchers set them equal, the
+    ABI does not have to (aim_hip.h aim_params_t.gap_i / gap_d). nw_reg_kernel's tilted coordinates T = R - GAP_I*h - GAP_D*v are exactly
+    where the two stop being interchangeable: all four NW kernels against the oracle with the costs apart, all three length relations
+    (plen < / == / > tlen, incl. the aliased tails plen >= tlen + 2), score-only and with CIGAR."""
+    from aim_amd import engine
+    l, err, n = (100, 0.05, 4000) if kernel in ("nw_reg", "nw_lane") else (1000, 0.05, 160)
+    ms, rs = engine.launcher_sizes("nw", l, err)
+    if kernel == "nw_lane":
+        monkeypatch.setenv("AIM_NO_NW_REG", "1")
+    if kernel == "dp_wave":
+        monkeypatch.setenv("AIM_DPW_LEGACY", "1")
+    req, pat, txt = engine.gen_pairs(9100 + gi, 0, n, l, err, rs)
+    for i in range(3, n, 41):                                                  # more tails / short texts than the generator draws
+        req["text_len"][i] = max(1, int(req["text_len"][i]) - (i % 9))
+    for i in range(7, n, 53):
+        req["pattern_len"][i] = max(1, int(req["pattern_len"][i]) - (i % 11))
+    d = req["pattern_len"].astype(int) - req["text_len"].astype(int)
+    assert (d < 0).any() and (d == 0).any() and (d == 1).any() and (d >= 2).any()
+    params = engine.make_params("nw", ms, rs, backtrace=bt, mismatch=mism, gap_i=gi, gap_d=gd)
+    _compare("nw", params, req, pat, txt)
+    with engine.DeviceSet(1) as s:
+        s.configure(params, n)
+        s.push(0, req, pat, txt); s.launch(); s.pull(0)
+        assert s.plan_describe(0).startswith(kernel + "_kernel"), s.plan_describe(0)
+
+
+def test_host_cli_takes_gap_i_and_gap_d(gpu, tmp_path):
+    """judge r04 row 1 through the host CLI (--gap-i / --gap-d): the reference's output digest for GAP_I 2, GAP_D 7."""
+    case = [c for c in judge_cases() if c["name"] == "nw_asym_gi2_gd7_l100_e5_bt"][0]
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.write_bytes(judge_case_input(case))
+    r = _host_cli(case, inp, out, tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert md5(out.read_bytes()) == case["output_md5"]

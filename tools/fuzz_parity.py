@@ -20,7 +20,7 @@ def oracle_params(params, algo):
     red = bool(params.flags & capi.FLAG_REDUCE)
     cellb = 2 if (params.flags & capi.FLAG_SWG_W16) else 0
     return oracle.params(algo, params.max_score, params.read_size, match=params.match, mismatch=params.mismatch,
-                         gap_o=params.gap_o, gap_e=params.gap_e, gap=params.gap_i, backtrace=bt, reduce=red, swg_cell_bytes=cellb)
+                         gap_o=params.gap_o, gap_e=params.gap_e, gap_i=params.gap_i, gap_d=params.gap_d, backtrace=bt, reduce=red, swg_cell_bytes=cellb)
 
 
 def compare(algo, params, req, pat, txt, allow_nomem=False):
@@ -97,6 +97,8 @@ def main():
             e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10])
             if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
             cost = dict(mismatch=rng.randint(1, 9), gap=rng.choice([1, 2, 3, 4, 5, 9, 30, 60])) if (algo == "nw" and rng.random() < 0.5) else {}
+            if algo == "nw" and rng.random() < 0.4:                     # GAP_I != GAP_D (nw.c:67-153; nw_reg's tilt treats them separately)
+                cost = dict(mismatch=rng.randint(1, 9), gap_i=rng.choice([1, 2, 3, 4, 6, 7, 9, 30]), gap_d=rng.choice([1, 2, 3, 5, 6, 7, 9, 30]))
             n = rng.choice([1, 63, 64, 65, 1000, 4097, 9000])
             bt = rng.random() < 0.6
             ms = rng.randint(1, 60)
@@ -219,6 +221,8 @@ def main():
             else: cost = dict(mismatch=rng.randint(1, 9), gap=rng.randint(1, 9))
         try:
             ms, rs = engine.launcher_sizes(algo, l, e, **cost)
+            if algo == "nw" and cost and rng.random() < 0.5:        # GAP_I != GAP_D on the long-read NW kernels
+                cost = dict(mismatch=cost["mismatch"], gap_i=rng.randint(1, 9), gap_d=rng.randint(1, 9))
         except Exception:
             continue
         r0 = rng.random()
