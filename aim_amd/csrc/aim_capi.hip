@@ -118,6 +118,7 @@ aim::Knobs read_knobs()
     k.dpl_no_reg = env_int("AIM_DPL_NO_REG", 0);
     k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
     k.no_nw_reg = env_flag("AIM_NO_NW_REG");
+    k.no_swg_reg = env_flag("AIM_NO_SWG_REG");
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
@@ -395,7 +396,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         if (!kn.dpw_legacy && kn.dpw_nw < 0 && aim::dp_strip_supported(p, cell8, kn)) {
             // column-strip pipeline (dp_strip.hpp): previous row in registers, packed int16 arithmetic, mailboxes instead of barriers
             pl->kid = K_DP_STRIP;
-            return aim::dp_strip_plan(p, n_pairs, budget, kn, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total, &pl->strip_k)
+            return aim::dp_strip_plan(p, n_pairs, budget, kn, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total, &pl->strip_k, &pl->pool_cap)
                        ? AIM_OK
                        : fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
         }
@@ -437,6 +438,39 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         pl->scratch_total = (size_t)(per * std::max(g, fb.grid)) + pl->todo_bytes;
         return AIM_OK;
     }
+    // SWG short reads: the M and I rows in registers (dp_reg.hpp, round 5); tail pairs, outliers and pairs whose cells wrap reach swg_lane_kernel
+    // through the same to-do list. [table slabs of max(grid) wavefronts | to-do region]
+    if (p.algo == AIM_ALGO_SWG && !kn.no_swg_reg && !kn.force_dpwave && aim::swg_reg_supported(p)) {
+        Plan fb;
+        memset(&fb, 0, sizeof fb);
+        aim::Knobs kq = kn;
+        kq.dpl_seq_lds = 2;
+        kq.dpl_no_reg = 0;
+        if (!aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds))
+            return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+        const int npk = aim::swg_reg_npk(p.read_size);
+        const uint64_t slab = bt ? (uint64_t)aim::swg_reg_slab_bytes(npk, p.read_size) : 256;
+        uint32_t per_cu = 8u;   // two wavefronts per SIMD
+        if (kn.nw_reg_per_cu > 0) per_cu = (uint32_t)kn.nw_reg_per_cu;
+        pl->lds = aim::swg_reg_lds_bytes(p, npk);
+        per_cu = (uint32_t)std::min<size_t>(per_cu, aim::lds_workgroups_per_cu(pl->lds));
+        const uint32_t n_groups = (n_pairs + 63u) / 64u;
+        uint32_t g = aim::resident_grid(kn, per_cu);
+        const uint32_t need = ((n_groups + 7u) / 8u) * 8u;
+        if (g > need) g = need < 8u ? 8u : need;
+        const uint64_t per = std::max<uint64_t>((slab + 255) & ~255ull, fb.scratch_per_wg);
+        while (g > 8 && per * g > budget / 2) g -= 8;
+        if (per * std::max(g, fb.grid) > budget) return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+        pl->kid = K_DP_REG;
+        pl->grid = g;
+        pl->block = 64;
+        pl->scratch_per_wg = per;
+        pl->fb_grid = fb.grid;
+        pl->fb_lds = fb.lds;
+        pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
+        pl->scratch_total = (size_t)(per * std::max(g, fb.grid)) + pl->todo_bytes;
+        return AIM_OK;
+    }
     // NW / SWG short reads: one pair per lane, flat DP table in per-wave HBM scratch
     pl->kid = K_DP_LANE;
     return aim::dp_lane_plan(p, n_pairs, budget, kn, &pl->grid, &pl->block, &pl->lds, &pl->scratch_per_wg, &pl->scratch_total,
@@ -453,7 +487,7 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
     case K_WFA_LANE_PK: return "wfa_lane_packed_kernel";
     case K_WFA_GROUP: return "wfa_group_kernel";
     case K_DP_LANE: return p_is_nw(&p) ? "nw_lane_kernel" : "swg_lane_kernel";
-    case K_DP_REG: return "nw_reg_kernel";
+    case K_DP_REG: return p_is_nw(&p) ? "nw_reg_kernel" : "swg_reg_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
     case K_DP_STRIP: return "dp_strip_kernel";
     case K_GENASM: return "genasm_wave_kernel";
@@ -714,7 +748,8 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         uint32_t *todo_d = reinterpret_cast<uint32_t *>((char *)d_scratch + (pl.scratch_total - pl.todo_bytes));
         HIP_TRY(hipMemsetAsync(todo_d, 0, 64, stream));
         ka.todo = todo_d;
-        aim::nw_reg_launch(p, pl.grid, pl.lds, ka, stream);
+        if (p.algo == AIM_ALGO_SWG) aim::swg_reg_launch(p, pl.grid, pl.lds, ka, stream);
+        else aim::nw_reg_launch(p, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         aim::Knobs kq = kn;
         kq.dpl_seq_lds = 2;
@@ -727,6 +762,10 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_DP_STRIP:
+        if (p.algo == AIM_ALGO_SWG) {   // [slabs | lock words | pool tables of the literal path]: the locks are free at every launch
+            HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.grid * pl.scratch_per_wg, 0, 256, stream));
+            ka.pool_cap = pl.pool_cap;
+        }
         aim::dp_strip_launch(p, pl.strip_k, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_GENASM:

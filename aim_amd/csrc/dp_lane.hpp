@@ -315,7 +315,11 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
     const int GAP_O = a.p.gap_o, GAP_E = a.p.gap_e, MATCH = a.p.match, MISMATCH = a.p.mismatch;
     const int OE = GAP_O + GAP_E;
     const int MAX_SCORE = a.p.max_score;
-    const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
+    // to-do mode (a.todo set; SEQ != 1: every lane reads its own pair's rows from global memory -- the listed pairs are not consecutive):
+    // the pairs swg_reg_kernel (dp_reg.hpp) left over (tail cells, outliers, pairs whose int8 cells wrap)
+    const bool todo_mode = SEQ != 1 && a.todo != nullptr;
+    const uint32_t n_work = todo_mode ? a.todo[LANE_TODO_COUNT] : a.n_pairs;
+    const uint32_t n_groups = (n_work + kWave - 1) / kWave;
 #define RM(v) RMa[(v) * kWave + lane]
 #define RI(v) RIa[(v) * kWave + lane]
 
@@ -323,16 +327,17 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
         uint32_t grp;
         if (!xcd_unit(n_groups, it, &grp)) break;
         const uint32_t pair0 = grp * kWave;
-        const uint32_t pair = pair0 + lane;
-        const bool active = pair < a.n_pairs;
-        const int n_rows = min((uint32_t)kWave, a.n_pairs - pair0);
+        const bool active = pair0 + lane < n_work;
+        const uint32_t pair = todo_mode ? (active ? a.todo[LANE_TODO_LIST + pair0 + lane] : 0u) : pair0 + lane;
+        const int n_rows = min((uint32_t)kWave, n_work - pair0);
         __syncthreads();
-        if (SEQ_LDS || SEQ == 2) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
+        if ((SEQ_LDS || SEQ == 2) && !todo_mode) stage_rows_transposed(imgP, a.patterns + (uint64_t)pair0 * rs, rsw, n_rows, lane);   // SEQ == 2: into the row area, which is not live yet
         __syncthreads();
         dpl_u32x32 preg = {};
         if (SEQ == 2) {
+            const uint32_t *own = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
 #pragma unroll
-            for (int j = 0; j < 32; ++j) preg[j] = j < rsw ? imgP[j * kWave + lane] : 0u;
+            for (int j = 0; j < 32; ++j) preg[j] = j < rsw ? (todo_mode ? own[j] : imgP[j * kWave + lane]) : 0u;
             __syncthreads();                          // every lane holds its row before the row area is initialised
         }
         if (!active) continue;

@@ -328,6 +328,393 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
 // bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
 inline size_t nw_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * 8 * 4 * kWave; }   // 8 dwords of direction bits per row and lane
 
+
+// =====================================================================================================================================
+// swg_reg_kernel -- Smith-Waterman-Gotoh (global, affine gaps) on short reads with the M and I rows IN REGISTERS (round 5).
+//
+// Same values as swg_compute / swg_traceback (SWG/DPU-WRAM/dpu/swg.c:121-171, 45-119) for the pairs it takes; swg_lane_kernel (dp_lane.hpp: rows in
+// LDS, the reference's cell order literally) keeps the rest through the to-do list. One pair per lane, two cells per VGPR, rows LEFT-aligned: column
+// v (pattern character v - 1) at index v - 1, register j = indices 2j (low half), 2j + 1 (high half); the boundary cell (h, 0) lives in per-lane
+// scalars and enters a row as the "register left of register 0".
+//   * Cells are int8 (MAX_SCORE < 127, SWG/DPU-WRAM/common/common.h:71-86) or int16, and the reference wraps on every store (quirk S3). The
+//     registers hold value * SC in 16-bit fields, SC = 256 for int8 cells: v_pk_add_u16 / v_pk_mad_u16 then wrap exactly like the (int8_t) casts,
+//     v_pk_min_i16 orders like a signed int8 compare -- no sign-extension instruction anywhere. MAX_SCORE is the reference's +infinity (S2), literally.
+//   * The D layer is the in-row chain D[v] = min(M[v-1] + o + e, D[v-1] + e), M[v] = min(A[v], D[v]) with A = min(M_diag + cost, I). It runs in the
+//     shortened form D[v] = min(A[v-1] + o + e, D[v-1] + e) (four 16-bit SDWA steps per register), which equals the reference's whenever NO
+//     intermediate wraps (o >= 0: D[v-1] + o + e never beats D[v-1] + e). All costs are >= 0 (swg_reg_supported), so without a wrap every stored value is
+//     >= 0, and the first candidate the reference wraps also wraps here (A[v-1] >= M[v-1]) to a NEGATIVE value that wins its minimum and reaches the
+//     cell's M: the OR of all stored M fields has a sign bit set if and only if something may have wrapped. Such a pair's results are discarded and the
+//     pair goes to the to-do list (none of the synthetic l = 100 sets up to e = 5 % has one).
+//   * Quirk N1 / S1 (flat table, stride W = tlen + 1): plen <= tlen -- nothing aliased; plen > tlen -- cell (h, W) IS row h + 1's boundary cell {M, D}
+//     (and reads, as its cell "above", its own previous value: the stored row), row 1's boundary is the row initialisation's (it is written after the
+//     column's). The cells right of it (plen >= tlen + 2) read the CURRENT row's first cells and are overwritten by the next row before anything
+//     else reads them: only the LAST row's matter (they hold the score), so the rows run over the columns 1 .. W like those of a plen == tlen + 1 pair and
+//     the last row's tail cells W + 1 .. plen are computed once, after the loop, from the final row (at most kSwgTail of them; score-only -- with CIGAR such
+//     pairs stay on the to-do list). Cell (h, W) sits at a per-lane index: pairs with plen > tlen are queued separately and only THEIR wavefronts pick
+//     {M, D} out of the last kSwgWin registers after every row (two v_cndmask per register); the queues' remainders share a last, mixed batch.
+//   * BACKTRACE: FOUR BITS per cell, decided at fill time (every cell the walk compares with still holds the value the fill read, as in nw_reg_kernel):
+//     "M != D" (A < D), "M != I" (M_diag + cost < I), "D != M_left + o + e" (D < A_left + o + e: the gap was extended; needs o > 0) and
+//     "I != M_up + o + e" (I_up + e < M_up + o + e) -- the four tests of swg_traceback; 'M' / 'X' is the character comparison. The sign bytes of the four
+//     packed differences are gathered by two v_perm_b32 (selectors 8 .. 11 replicate a source's sign bits) and merged into a dword per FOUR registers with
+//     v_bfi: byte b of the dword = {low nibble: bit k = register k's "M != D" (b = 0, 1: low / high half) or "M != I" (b = 2, 3); high nibble: the two gap
+//     tests}. Without a wrap the walk always finds an operation (AIM_PAIR_SWG_NO_OP needs wrapped cells: those pairs are on the to-do list).
+constexpr int kSwgWin = 16;        // registers (32 indices) in which a row may END
+
+// Registers of a row: the launchers' READ_SIZE rule (run-swg-pim-wram.py: ceil((l + l*e + 7) / 8) * 8) leaves pattern and text at READ_SIZE - 7 characters at most, and
+// column v sits at index v - 1: 2 * NPK >= READ_SIZE - 7 indices hold every pair they produce (a longer pattern, legal up to READ_SIZE, goes to the to-do list).
+inline int swg_reg_npk(int read_size) { return read_size <= 48 ? 21 : read_size <= 64 ? 29 : read_size <= 80 ? 37 : read_size <= 96 ? 45 : read_size <= 112 ? 53 : read_size <= 128 ? 61 : 0; }
+constexpr int kSwgTail = 8;        // tail cells of the last row a pair may have beyond (tlen, W): plen <= tlen + 1 + kSwgTail (score-only)
+inline int swg_reg_cell_bytes(const aim_params_t &p) { return (p.flags & AIM_FLAG_SWG_W16) ? 2 : (p.max_score < 127 ? 1 : 2); }   // = swg_cell_bytes (dp_lane.hpp)
+
+inline bool swg_reg_supported(const aim_params_t &p)
+{
+    if (p.algo != AIM_ALGO_SWG || swg_reg_npk(p.read_size) == 0 || p.read_size < 40) return false;
+    if (p.match != 0 || p.mismatch < 1 || p.gap_o < 1 || p.gap_e < 1 || p.max_score < 0) return false;
+    const long oe = (long)p.gap_o + p.gap_e, cmax = std::max<long>(oe, p.mismatch);
+    if (swg_reg_cell_bytes(p) == 1) return cmax <= 127 && p.max_score <= 127;   // (two values <= 127: a wrapped sum is negative)
+    return std::max<long>(p.max_score, p.gap_o) + (p.read_size + 2L) * p.gap_e + 2 * cmax < 32000;   // int16 cells: nothing can wrap
+}
+
+__host__ __device__ inline int swg_reg_units(int npk) { return ((npk + 3) / 4 + 3) / 4; }   // 16-byte units of direction bits per row and lane
+__host__ __device__ inline size_t swg_reg_lds_bytes(const aim_params_t &p, int npk)   // text image / ops staging + the two pair queues (1 KB)
+{
+    const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave;
+    return ((bt && o > t) ? o : t) + 1024;
+}
+inline size_t swg_reg_slab_bytes(int npk, int read_size) { return (size_t)(read_size + 2) * swg_reg_units(npk) * 16 * kWave; }
+
+// the D chain of one register: Dprev / Aprev carry the left neighbour's D and A + o + e in their HIGH halves, aoe = {A.lo + oe, A.hi + oe}
+__device__ __forceinline__ uint32_t swg_chain(uint32_t Dprev, uint32_t Aprev, uint32_t aoe, uint32_t e2)
+{
+    uint32_t d, t;   // (ONE asm statement: the compiler pads every asm statement with an s_nop)
+    asm("v_add_u16_sdwa %0, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+        "v_min_i16_sdwa %0, %3, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0\n\t"
+        "v_add_u16_sdwa %1, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+        "v_min_i16_sdwa %0, %5, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0"
+        : "=&v"(d), "=&v"(t) : "v"(Dprev), "v"(Aprev), "v"(e2), "v"(aoe));
+    return d;
+}
+
+template <int NPK, bool BT, bool C8>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void swg_reg_kernel(KArgs a)   // (two wavefronts per SIMD: vector + accumulation registers <= 256)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
+    constexpr int RSK = 2 * NPK;          // indices (columns 1 .. RSK) of a row of registers
+    constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
+    constexpr int SC = C8 ? 256 : 1;
+    constexpr int NQ = (NPK + 3) / 4;     // dwords of direction bits per row and lane
+    constexpr int NU = (NQ + 3) / 4;      // ... in 16-byte units
+    constexpr int JW = NPK - kSwgWin;     // first register in which a row may end
+    const int lane = threadIdx.x;
+    const int rs = a.p.read_size, rsw = rs >> 2;
+    const int OE = a.p.gap_o + a.p.gap_e, GAP_E = a.p.gap_e, MISMATCH = a.p.mismatch, MAXS = a.p.max_score;
+    uint32_t *todo = const_cast<uint32_t *>(a.todo);                     // OUT: pairs left to swg_lane_kernel ({count @0, pair ids @16..})
+    uint32_t *tbw = BT ? reinterpret_cast<uint32_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
+#define TBW(h, q) tbw[((size_t)((h) * NU + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
+    const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
+    uint32_t ones = 0x00010001u;
+    opaque(ones);
+    const uint32_t x2 = (uint32_t)(uint16_t)(MISMATCH * SC) * 0x00010001u, oe2 = (uint32_t)(uint16_t)(OE * SC) * 0x00010001u;
+    uint32_t e2 = (uint32_t)(uint16_t)(GAP_E * SC) * 0x00010001u;
+    opaque(e2);                                                          // (the chain's SDWA operands are vector registers)
+    const uint32_t eH = (uint32_t)(uint16_t)(GAP_E * SC) << 16, oeH = (uint32_t)(uint16_t)(OE * SC) << 16, msH = (uint32_t)(uint16_t)(MAXS * SC) << 16;
+    auto add2 = [](uint32_t x, uint32_t y) __attribute__((always_inline)) { return dps_bits(dps_from(x) + dps_from(y)); };
+    auto sub2 = [](uint32_t x, uint32_t y) __attribute__((always_inline)) { return dps_bits(dps_from(x) - dps_from(y)); };
+    auto min2 = [](uint32_t x, uint32_t y) __attribute__((always_inline)) { return dps_bits(dps_min(dps_from(x), dps_from(y))); };
+
+    // Two LDS queues (pairs with plen <= tlen; pairs with plen == tlen + 1), filled from groups of 64 consecutive pairs; the row loop runs on 64
+    // queued pairs of ONE class at a time.
+    uint32_t *queue = reinterpret_cast<uint32_t *>(smem + swg_reg_lds_bytes(a.p, NPK) - 1024);   // 2 x 128 entries behind the text / ops area
+    uint32_t qn[2] = {0u, 0u}, it = 0;                       // wave-uniform
+    bool more = true;
+    const unsigned long long mask_below = (1ull << lane) - 1ull;
+
+    auto run = [&](auto isw_tag, uint32_t *q, uint32_t &qcount) __attribute__((always_inline)) {
+        constexpr bool ISW = decltype(isw_tag)::value;
+        const uint32_t ntake = qcount < (uint32_t)kWave ? qcount : (uint32_t)kWave;
+        const bool mine = (uint32_t)lane < ntake;
+        const uint32_t pair = mine ? q[lane] : 0u;
+        const uint32_t moved = (ntake + lane < qcount) ? q[ntake + lane] : 0u;   // the queue's remainder moves to its front (same-wave LDS traffic is ordered)
+        if (ntake + lane < qcount) q[lane] = moved;
+        qcount -= ntake;
+        aim_request_t rq;
+        rq.pattern_len = rq.text_len = 0; rq.padding = 0; rq.idx = 0;
+        if (mine) rq = load_request(a, pair);
+        const int plen = rq.pattern_len, tlen = rq.text_len;
+        const bool lw = ISW && plen > tlen;                   // this lane's pair has cell (h, W) = B(h + 1) (a mixed batch also holds plen <= tlen pairs)
+        const int pe = lw ? tlen + 1 : plen;                  // columns the rows run over: 1 .. pe
+        const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);   // (idle lanes: pair 0's rows, read and ignored)
+        const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
+        // the text row goes to LDS, transposed [dword][lane] (one conflict-free ds_read per ROW of the table), the pattern row into registers as
+        // 16-bit fields (character v - 1 at index v - 1: no shift)
+        uint32_t *ldsT = reinterpret_cast<uint32_t *>(smem);
+        uint32_t pc[NPK];
+        __syncthreads();                                      // (single wavefront: the previous batch's traceback is done with this area)
+#pragma unroll
+        for (int i = 0; i < NWD; ++i) {
+            const uint32_t pw = i < rsw ? gP[i] : 0u;
+            ldsT[i * kWave + lane] = i < rsw ? gT[i] : 0u;
+            if (2 * i < NPK) pc[2 * i] = __builtin_amdgcn_perm(0u, pw, 0x0c010c00u);           // bytes 0, 1 -> 16-bit fields (indices 4i, 4i + 1)
+            if (2 * i + 1 < NPK) pc[2 * i + 1] = __builtin_amdgcn_perm(0u, pw, 0x0c030c02u);   // bytes 2, 3
+        }
+        // row 0 (the "first column" loop of swg_compute, swg.c:131-136): M = D = o + v e (wrapped like the reference's store), I = MAX_SCORE; columns
+        // beyond plen hold 0 (never read by a cell of the pair). plen == tlen + 1: flat cell (0, W) IS the boundary cell (1, 0), and the row
+        // initialisation wrote {M = I = o + e} there AFTER the column's (swg.c:137-142).
+        uint32_t M[NPK], I[NPK];
+        uint32_t acc = 0u;                                    // OR of every stored M: a sign bit = something may have wrapped
+        {
+            uint32_t val = (uint32_t)(uint16_t)(a.p.gap_o * SC);
+#pragma unroll
+            for (int j = 0; j < NPK; ++j) {
+                uint32_t lo, hi;
+                val = (val + (uint32_t)(GAP_E * SC)) & 0xffffu;
+                lo = (2 * j + 1 <= pe) ? val : 0u;
+                val = (val + (uint32_t)(GAP_E * SC)) & 0xffffu;
+                hi = (2 * j + 2 <= pe) ? val : 0u;
+                uint32_t ilo = msH >> 16, ihi = msH >> 16;
+                if (ISW) {
+                    if (lw && 2 * j + 1 == pe) lo = ilo = oeH >> 16;
+                    if (lw && 2 * j + 2 == pe) hi = ihi = oeH >> 16;
+                }
+                M[j] = lo | (hi << 16);
+                I[j] = ilo | (ihi << 16);
+                acc |= M[j];
+            }
+        }
+        // the boundary cell of the current row, in HIGH halves: M (= I for the cells the row initialisation wrote), D
+        uint32_t MbH = oeH, DbH = msH, MbOldH = 0u;           // row 1: {o + e, MAX_SCORE}; M[0][0] = 0
+        const int jl = (pe - 1) >> 1;                         // the register of the row's last cell
+        const bool lhi = ((pe - 1) & 1) != 0;
+        // ISW: cell (h, W) is picked out of the last kSwgWin registers with v_bfi under per-register lane masks (a chain of `jl == j ? m : Ml` selects is
+        // recognised as a dynamic index into an array of the m values, which then lives in scratch)
+        // (the masks are made from ONE one-hot register, v_bfe_i32 per use: sixteen mask registers were sixteen registers too many)
+        uint32_t hot = (ISW && jl >= JW) ? 1u << (jl - JW) : 0u;
+        opaque(hot);
+        const int hmax = -wave_min_i32(mine ? -tlen : 0);
+        for (int h = 1; h <= hmax; ++h) {
+            if (h <= tlen) {                                  // (lanes whose table is complete keep their rows: the score is picked up after the loop)
+                const uint32_t tword = ldsT[((h - 1) >> 2) * kWave + lane];
+                const uint32_t tch2 = ((tword >> (((h - 1) & 3) * 8)) & 0xffu) * 0x00010001u;
+                acc |= MbH;
+                uint32_t Dprev = DbH, Aprev = MbH + oeH;      // left of register 0: the boundary cell (its M + o + e is the reference's own del_new)
+                uint32_t oldprev = MbOldH;                    // M[h-1][0] in the high half
+                uint32_t Ml = 0u, Dl = 0u;                    // ISW: {M, D} of the row's last cell
+                uint32_t dword = 0u;
+                typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+                aim_u32x4 unit = {0u, 0u, 0u, 0u};
+                uint32_t diag = __builtin_amdgcn_alignbit(M[0], oldprev, 16);           // {M[h-1][index - 1]} of register 0's cells
+#pragma unroll
+                for (int j = 0; j < NPK; ++j) {
+                    // everything that reads the OLD row's register j is taken first -- the next register's diagonal too -- so that the new value
+                    // can be written over it (in place: as a plain read-later the compiler kept a v_mov copy per register and row)
+                    uint32_t insn = add2(M[j], oe2);
+                    uint32_t dnext = j + 1 < NPK ? __builtin_amdgcn_alignbit(M[j + 1], M[j], 16) : 0u;
+                    opaque(insn);
+                    opaque(dnext);
+                    const uint32_t f = pk_ne01(pc[j], tch2, ones);
+                    const uint32_t mm = dps_bits(dps_from(f) * dps_from(x2) + dps_from(diag));   // m_match (MATCH = 0)
+                    const uint32_t inse = add2(I[j], e2);
+                    const uint32_t ins = min2(insn, inse);
+                    const uint32_t A = min2(mm, ins);
+                    const uint32_t aoe = add2(A, oe2);
+                    const uint32_t d = swg_chain(Dprev, Aprev, aoe, e2);
+                    uint32_t m = min2(A, d);
+                    opaque(m);   // (made HERE, inside the `h <= tlen` region: otherwise the compiler sinks the 53 minima behind the region's end -- legal, min(min(A, d), d) is what a
+                                 //  lane outside it needs -- and keeps every register's d alive until then: 256 VGPRs + 33 AGPRs = one wavefront per SIMD)
+                    if (BT) {
+                        const uint32_t aleft = __builtin_amdgcn_alignbit(aoe, Aprev, 16);       // {A + o + e} of both cells' left neighbours
+                        const uint32_t dA = sub2(A, d), dB = sub2(mm, ins), dC = sub2(d, aleft), dD = sub2(inse, insn);
+                        uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);               // bytes {A.lo, A.hi, B.lo, B.hi} sign -> 0x00 / 0xff
+                        uint32_t w2 = __builtin_amdgcn_perm(dD, dC, 0x0b0a0908u);
+                        opaque(w1);   // (the bits are made HERE: left to itself the compiler makes all registers' bits at the end of the row, with every
+                        opaque(w2);   //  register's candidates live until then)
+                        const uint32_t k1 = 0x01010101u << (j & 3), k2 = 0x10101010u << (j & 3);
+                        dword = (w1 & k1) | (dword & ~k1);
+                        dword = (w2 & k2) | (dword & ~k2);
+                        if ((j & 3) == 3 || j == NPK - 1) {
+                            unit[(j >> 2) & 3] = dword;
+                            dword = 0u;
+                            if (((j >> 2) & 3) == 3 || j == NPK - 1) {   // a 16-byte unit leaves as soon as it is complete
+                                __builtin_nontemporal_store(unit, reinterpret_cast<aim_u32x4 *>(&TBW(h, (j >> 2) & ~3)));
+                                unit = aim_u32x4{0u, 0u, 0u, 0u};
+                            }
+                        }
+                    }
+                    if (ISW && j >= JW) {
+                        const uint32_t wmk = (uint32_t)__builtin_amdgcn_sbfe((int)hot, j - JW, 1);   // all ones in the lanes whose cell (h, W) lies in register j
+                        Ml = (m & wmk) | (Ml & ~wmk);
+                        Dl = (d & wmk) | (Dl & ~wmk);
+                    }
+                    M[j] = m;
+                    I[j] = ins;
+                    acc |= m;
+                    Dprev = d;
+                    Aprev = aoe;
+                    diag = dnext;
+                }
+                MbOldH = MbH;
+                if (ISW) {                                    // plen > tlen: the next row's boundary cell is this row's cell (h, W); else o + (h + 1) e, wrapped, D stays MAX_SCORE
+                    MbH = lw ? (lhi ? (Ml & 0xffff0000u) : (Ml << 16)) : MbH + eH;
+                    DbH = lw ? (lhi ? (Dl & 0xffff0000u) : (Dl << 16)) : DbH;
+                } else {
+                    MbH += eH;
+                }
+            }
+        }
+        // M[tlen][pe]: a binary select tree over the last kSwgWin registers
+        uint32_t sreg;
+        {
+            uint32_t t[kSwgWin];
+#pragma unroll
+            for (int k = 0; k < kSwgWin; ++k) t[k] = M[JW + k];
+            const int d = jl - JW;
+#pragma unroll
+            for (int step = 1; step < kSwgWin; step <<= 1) {
+                const bool odd = (d & step) != 0;
+#pragma unroll
+                for (int k = 0; k + step < kSwgWin; k += 2 * step) t[k] = odd ? t[k + step] : t[k];
+            }
+            sreg = t[0];
+        }
+        int sc16 = (int)(int16_t)(lhi ? (sreg >> 16) : (sreg & 0xffffu));     // M[tlen][pe] * SC
+        if (ISW && !BT) {
+            // plen >= tlen + 2: the LAST row's tail cells v = W + c, c = 1 .. plen - W, one after the other (swg.c:151-162 with the flat indices resolved: the cell
+            // on the left is the previous tail cell, the cell "above" is cell (tlen, c) of this same row, the diagonal one cell (tlen, c - 1))
+            const int ntail = lw ? plen - pe : 0;
+            const int tmax = -wave_min_i32(mine ? -ntail : 0);
+            if (tmax > 0) {
+                // field idx (0 .. 7) of a row's first four registers: a binary select tree over VALUES (a chain of `idx == j ? arr[j] : r` is recognised as a
+                // dynamic index, and an array passed by reference has its address taken: either way the row would live in scratch)
+                static_assert(kSwgTail <= 8, "pick16 looks at four registers");
+                auto pick16 = [](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, int idx) __attribute__((always_inline)) {
+                    const int d = idx >> 1;
+                    const uint32_t r0 = (d & 1) ? a1 : a0, r1 = (d & 1) ? a3 : a2;
+                    const uint32_t r = (d & 2) ? r1 : r0;
+                    return (int)(int16_t)((idx & 1) ? (r >> 16) : (r & 0xffffu));
+                };
+                const uint32_t m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
+                const unsigned char *pb8 = reinterpret_cast<const unsigned char *>(gP), *tb8 = reinterpret_cast<const unsigned char *>(gT);
+                const int tch = mine && tlen >= 1 ? (int)tb8[tlen - 1] : 0;
+                int upM = (int)(int16_t)(MbH >> 16), upD = (int)(int16_t)(DbH >> 16);      // cell (tlen, W): picked up after the last row
+                const int OEs = OE * SC, Es = GAP_E * SC, Xs = MISMATCH * SC;
+                for (int c = 1; c <= tmax; ++c) {
+                    if (c <= ntail) {
+                        const int mU = pick16(m0, m1, m2, m3, c - 1), iU = pick16(i0, i1, i2, i3, c - 1);
+                        const int dg = c == 1 ? (int)(int16_t)(MbOldH >> 16) : pick16(m0, m1, m2, m3, c - 2);   // (c == 1: the last row's boundary cell)
+                        const int cD = min((int)(int16_t)(upM + OEs), (int)(int16_t)(upD + Es));
+                        const int cI = min((int)(int16_t)(mU + OEs), (int)(int16_t)(iU + Es));
+                        const int cM = min((int)(int16_t)(dg + (((int)pb8[pe + c - 1] == tch) ? 0 : Xs)), min(cI, cD));
+                        acc |= (uint32_t)cM & 0x8000u;
+                        upM = cM; upD = cD;
+                        sc16 = cM;
+                    }
+                }
+            }
+        }
+        const int score = C8 ? (sc16 >> 8) : sc16;
+        // pairs in which something may have wrapped: to the to-do list, results discarded
+        const bool bad = mine && (acc & 0x80008000u) != 0u;
+        const unsigned long long badm = __ballot(bad);
+        if (badm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(badm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (bad) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(badm & mask_below)] = pair;
+        }
+        int begin_offset = plen + tlen - 1;
+        const int end_offset = plen + tlen;
+        if (BT) {
+            // swg_traceback (swg.c:45-119) over the direction bits: one dependent load per step; 'X' / 'M' from the sequences. Ops staged in LDS (the
+            // text image is dead by now), copied out in 16-byte pieces.
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (mine && !bad) {
+                char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+                const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
+                unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem);
+#define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
+                int sentinel = end_offset - 1;
+                int h = tlen, v = plen;
+                int layer = 0;                                // 0: M, 1: I, 2: D
+                while (h > 0 && v > 0) {
+                    const int i = v - 1, j = i >> 1;
+                    const uint32_t word = TBW(h, j >> 2);
+                    const uint32_t bits = word >> (8 * (i & 1) + (j & 3));   // bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended
+                    if (layer == 2) { OPS(sentinel) = 'D'; --sentinel; if (!(bits & 0x10u)) layer = 0; --v; }
+                    else if (layer == 1) { OPS(sentinel) = 'I'; --sentinel; if (!(bits & 0x100000u)) layer = 0; --h; }
+                    else if (!(bits & 1u)) layer = 2;
+                    else if (!(bits & 0x10000u)) layer = 1;
+                    else { OPS(sentinel) = (pb[v - 1] != tbytes[h - 1]) ? 'X' : 'M'; --sentinel; --h; --v; }
+                }
+                while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+                while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
+                begin_offset = sentinel + 1;
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+                    uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                    for (int qq = begin_offset >> 4; qq <= (end_offset - 1) >> 4; ++qq) dst[qq] = src[qq * kWave + lane];
+                }
+#undef OPS
+            }
+        }
+        if (mine && !bad) {
+            aim_result_t res;
+            res.max_operations = plen + tlen;
+            res.begin_offset = begin_offset;
+            res.end_offset = end_offset;
+            res.score = score;
+            res.status = AIM_PAIR_OK;
+            res.idx = rq.idx;
+            store_result(a, pair, res);
+        }
+    };
+
+    for (;;) {
+        while (qn[0] < (uint32_t)kWave && qn[1] < (uint32_t)kWave && more) {
+            uint32_t grp;
+            more = xcd_unit(n_groups, it, &grp);
+            if (!more) break;
+            ++it;
+            const uint32_t cand = grp * kWave + lane;
+            const bool act = cand < a.n_pairs;
+            aim_request_t rc;
+            rc.pattern_len = rc.text_len = 0; rc.padding = 0; rc.idx = 0;
+            if (act) rc = load_request(a, cand);
+            // this kernel's pairs: at most kSwgTail tail cells in the last row (with CIGAR: none), the rows' end inside the window, both sequences inside the
+            // row / the staged text image
+            const int cpe = rc.pattern_len > rc.text_len ? rc.text_len + 1 : rc.pattern_len;
+            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 + (BT ? 0 : kSwgTail) && cpe >= RSK - 2 * kSwgWin + 1 &&
+                              rc.pattern_len <= RSK && rc.text_len <= 4 * NWD && rc.text_len <= rs;
+            const bool w = take && rc.pattern_len > rc.text_len;
+            const unsigned long long rest = __ballot(act && !take);
+            if (rest) {   // everything else: the to-do list of swg_lane_kernel (one atomic per wavefront)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(rest));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (act && !take) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(rest & mask_below)] = cand;
+            }
+            const unsigned long long t0 = __ballot(take && !w), t1 = __ballot(w);
+            if (take && !w) queue[qn[0] + (uint32_t)__builtin_popcountll(t0 & mask_below)] = cand;
+            if (w) queue[128 + qn[1] + (uint32_t)__builtin_popcountll(t1 & mask_below)] = cand;
+            qn[0] += (uint32_t)__builtin_popcountll(t0);
+            qn[1] += (uint32_t)__builtin_popcountll(t1);
+        }
+        bool second = qn[1] >= (uint32_t)kWave;
+        if (qn[0] < (uint32_t)kWave && !second) {   // no groups left, both queues below 64: their remainders share the last batches (the plen > tlen variant takes every lane's own class)
+            if (qn[0] + qn[1] == 0u) break;
+            if ((uint32_t)lane < qn[0]) queue[128 + qn[1] + lane] = queue[lane];
+            qn[1] += qn[0];
+            qn[0] = 0u;
+            second = true;
+        }
+        if (qn[0] >= (uint32_t)kWave) run(std::false_type{}, queue, qn[0]);    // (each variant is inlined once)
+        else if (second) run(std::true_type{}, queue + 128, qn[1]);
+    }
+#undef TBW
+}
+
 // Kernels are instantiated in ONE translation unit (tu_dp_reg.hip defines AIM_TU_DP_REG); every other includer sees the declaration only.
 #ifdef AIM_TU_DP_REG
 void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
@@ -346,6 +733,33 @@ void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs
 }
 #else
 void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
+#ifdef AIM_TU_SWG_REG
+void swg_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE, c8 = swg_reg_cell_bytes(p) == 1;
+    const int npk = swg_reg_npk(p.read_size);
+#define AIM_SWGREG2(N, B, C)                                                                                                              \
+    do {                                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&swg_reg_kernel<N, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((swg_reg_kernel<N, B, C>), dim3(grid), dim3(kWave), lds, s, ka);                                               \
+    } while (0)
+#define AIM_SWGREG(N)                                                                                          \
+    do {                                                                                                       \
+        if (bt) { if (c8) AIM_SWGREG2(N, true, true); else AIM_SWGREG2(N, true, false); }                      \
+        else { if (c8) AIM_SWGREG2(N, false, true); else AIM_SWGREG2(N, false, false); }                       \
+    } while (0)
+    if (npk == 21) AIM_SWGREG(21);
+    else if (npk == 29) AIM_SWGREG(29);
+    else if (npk == 37) AIM_SWGREG(37);
+    else if (npk == 45) AIM_SWGREG(45);
+    else if (npk == 53) AIM_SWGREG(53);
+    else if (npk == 61) AIM_SWGREG(61);
+#undef AIM_SWGREG
+#undef AIM_SWGREG2
+}
+#else
+void swg_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
 #endif
 
 }  // namespace aim

@@ -172,6 +172,82 @@ __device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, 
     begin_offset = sentinel + 1;
 }
 
+
+// swg_traceback (swg.c:45-119) over FOUR DIRECTION BITS per cell, decided at fill time (round 5) -- no value plane at all:
+// 0.5 - 0.8 instead of 2.25 bytes per cell (config 4 wrote 61.8 GB per 256 pairs, 52 GB of it the int16 M plane). The four tests of the reference's
+// walk at a cell are known when the cell is computed, because every cell the walk compares with still holds the value the fill read (the flat table's
+// aliasing only replaces boundary cells B(h + 1) = tail cell (h, W), and B(h + 1) is final before row h + 1 starts; dp_strip_exact_ok: nothing wraps, so
+// an operation is always found):
+//     bit "M != D"        A < D                      (layer M, first test)
+//     bit "M != I"        A < I                      (layer M, second test; then 'M' / 'X' is the character comparison, MISMATCH != MATCH)
+//     bit "I extended"    I_up + e < M_up + o + e    (layer I: I == M_up + o + e fails)
+//     bit "next D ext."   pre(v) < G(v)  <=>  D[v + 1] != M[v] + o + e  (layer D at cell v + 1; o > 0) -- kept at the cell on the LEFT of the one it belongs
+//                         to, because that is the lane that knows it (the prefix minimum up to v and G(v)); the walk looks one cell to the left.
+// Per row and lane NQS dwords (dword q: registers 4q .. 4q + 3; byte b of it: low nibble bit k = register 4q + k's "M != D" (b = 0, 1: low / high half) or
+// "M != I" (b = 2, 3), high nibble: "next D extended" / "I extended"), row h's words at FLW[(h * FS + lane) * NQS]; boundary cells (column 0) in BF[row]:
+// bits 0 - 3 the cell's own four tests (D extended = its OWN), bit 4 "D of column 1 extended".
+template <int K>
+__device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int plen, int tlen, int FS, const uint32_t *FLW, const unsigned char *BF,
+                                                      const unsigned char *ldsP, const unsigned char *ldsT, uint32_t *tile, char *ops, int lane, int &begin_offset)
+{
+    constexpr int KP = K / 2, NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;
+    constexpr int kTR = 32;                                       // rows of the window (the walk moves up one row per step at most)
+    const int rs = p.read_size, W = tlen + 1;
+    int sentinel = plen + tlen - 1;
+    int h = tlen, v = plen;
+    const int cap = 2 * rs;
+    auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
+    int tR = -1, tG0 = 0;
+    auto refill = [&](int R, int g) {                             // rows R .. R - kTR + 1, lane words g - 7 .. g (clamped at 0)
+        tR = R; tG0 = g >= 7 ? g - 7 : 0;
+#pragma unroll
+        for (int q = 0; q < kTR / 8; ++q) {
+            const int rr = 8 * q + (lane >> 3), r = R - rr, gg = tG0 + (lane & 7);
+            if (r >= 0 && gg < FS) {
+#pragma unroll
+                for (int d = 0; d < NQS; ++d) tile[(rr * 8 + (lane & 7)) * NQS + d] = FLW[((size_t)r * FS + gg) * NQS + d];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    auto cellbits = [&](int R, int C) -> uint32_t {               // regular cell (R, C), C >= 1: bit 0 M != D, bit 4 next D extended, bit 16 M != I, bit 20 I extended
+        const int g = (C - 1) / K;
+        if (!(tR >= 0 && R <= tR && R > tR - kTR && g >= tG0 && g < tG0 + 8)) refill(R, g);
+        const int t = (C - 1) - g * K, j = t >> 1;
+        return tile[((tR - R) * 8 + (g - tG0)) * NQS + (j >> 2)] >> (8 * (t & 1) + (j & 3));
+    };
+    // (R, C): the canonical position of flat index W h + v (rows of W cells); moves: D at - 1, I at - W, diagonal at - W - 1
+    int R = W ? (W * h + v) / W : 0, C = (W * h + v) - R * W;
+    int layer = 0;                                                // 0: M, 1: I, 2: D
+    while (h > 0 && v > 0) {
+        uint32_t nD, nI, xD, xI;
+        if (C >= 1) {
+            const uint32_t b = cellbits(R, C);
+            nD = b & 1u; nI = (b >> 16) & 1u; xI = (b >> 20) & 1u;
+            xD = 0u;
+            if (layer == 2) xD = C == 1 ? (((uint32_t)BF[R] >> 4) & 1u) : ((cellbits(R, C - 1) >> 4) & 1u);
+        } else {
+            const uint32_t b = BF[R];
+            nD = b & 1u; nI = (b >> 1) & 1u; xD = (b >> 2) & 1u; xI = (b >> 3) & 1u;
+        }
+        if (layer == 2) { put('D'); if (!xD) layer = 0; --v; if (C > 0) --C; else { --R; C = W - 1; } }
+        else if (layer == 1) { put('I'); if (!xI) layer = 0; --h; --R; }
+        else if (!nD) layer = 2;
+        else if (!nI) layer = 1;
+        else {   // diagonal move: the cell equals its diagonal + MATCH or + MISMATCH according to the characters IT was computed with -- canonical cell (R, C) was
+                 // last written as cell (R, C) of the table (C >= 1, R <= tlen) or as the tail cell (R - 1, W + C) (column 0; row tlen + 1)
+            const bool as_tail = C == 0 || R > tlen;
+            put(ldsP[as_tail ? W + C - 1 : C - 1] != ldsT[as_tail ? R - 2 : R - 1] ? 'X' : 'M');
+            --h; --v; --R; if (C > 0) --C; else { --R; C = W - 1; }
+        }
+    }
+    for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
+    if (h > 0) sentinel -= h;
+    for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
+    if (v > 0) sentinel -= v;
+    begin_offset = sentinel + 1;
+}
+
 // K: cells per lane; NWMAX: the most wavefronts a workgroup of this instantiation is launched with (its register budget:
 // 4 / 8 wavefronts 256 VGPRs, 12 -> 168, 16 -> 128)
 template <int ALGO, bool BT, int K, int NWMAX>
@@ -204,11 +280,17 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
     // inside the row, so that every lane stores 16-byte vectors (cells beyond the row are written and never read)
     const int S = dp_strip_stride(rs, K);
     const size_t plane = (size_t)S * (size_t)(rs + 3);
+    // NW: one int16 plane per workgroup (TM). SWG (round 5): the workgroup's slab holds FOUR DIRECTION BITS per cell -- FLW [row][FS lanes][NQS dwords] + the
+    // boundary cells' bytes BF [row] -- and no value plane; the three int16 planes the literal path needs (a pair with plen > 2 tlen: an outlier) come from a
+    // small POOL of tables behind the slabs, taken under a lock (strip_pool_acquire): 61 MB instead of 613 MB per resident pair at READ_SIZE 10 112.
+    constexpr int NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;       // dwords of direction bits per lane and row (a 12-byte word is stored as 16)
     int16_t *tb = reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
-    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;      // (I / D planes: the literal path only)
-    uint2 *FL = reinterpret_cast<uint2 *>(tb + plane);            // SWG row-strip path: the compact table's flag words, [row][FS]
-    unsigned char *BF = reinterpret_cast<unsigned char *>(tb + 2 * plane);   // ... and the boundary cells' flags, [row]
-    const int FS = rs / K + 2;                    // flag words per row: one per lane that can hold a column (8 FS <= 2 S: the words fit the I plane's place)
+    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;      // (SWG: re-pointed at a pool table on the literal path)
+    const int FS = rs / K + 2;                    // lanes per row that can hold a column
+    uint32_t *FLW = reinterpret_cast<uint32_t *>(tb);             // SWG strip path: direction bits
+    unsigned char *BF = reinterpret_cast<unsigned char *>(FLW + (size_t)(rs + 3) * FS * NQS);   // ... and the boundary cells' bytes, [row]
+    uint32_t *pool_locks = reinterpret_cast<uint32_t *>(a.scratch + (uint64_t)gridDim.x * a.scratch_per_wave);   // SWG: [64] lock words, then pool_cap tables of 3 planes
+    int16_t *pool_tables = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(pool_locks) + 256);
     const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
     const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
     const int GE = SWG ? E : GD;                 // step of the in-row chain
@@ -237,6 +319,21 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
         }
         const bool literal = !exact_ok || plen > 2 * tlen || (min(plen, W - 1) > nw * kWave * K);
 
+        int pool_slot = -1;
+        if (literal && SWG) {   // the three int16 planes of the literal path: a table of the pool (workgroups wait for a free one; holders always finish)
+            if (tid == 0) {
+                int got = -1;
+                while (got < 0) {
+                    for (uint32_t i = 0; i < a.pool_cap && got < 0; ++i)
+                        if (atomicCAS(&pool_locks[i], 0u, 1u) == 0u) got = (int)i;
+                    if (got < 0) __builtin_amdgcn_s_sleep(32);
+                }
+                tl[4] = got;
+            }
+            __syncthreads();
+            pool_slot = tl[4];
+            TM = pool_tables + (size_t)pool_slot * 3 * plane; TI = TM + plane; TD = TM + 2 * plane;
+        }
         if (literal) {
             if (tid == 0) { score = dp_literal_fill<SWG, false>(a.p, plen, tlen, gP, gT, TM, TI, TD); tl[3] = score; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SWG's ops prefill by all threads completes before the traceback patches it
@@ -277,16 +374,12 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 opaque(vmb);
                 vmask[j] = dps_from(vmb);
             }
-            if (BT) {
-                for (int v = tid; v <= Rr; v += NT) {
-                    const int m0 = SWG ? (v ? O + v * E : 0) : v * GD;
-                    TM[7 + v] = (int16_t)m0;
-                }
-                for (int h = 1 + tid; h <= tlen; h += NT) {   // row-init boundary cells flat[W*h]: M = I = o + h e, D = MAX_SCORE
-                    const size_t at = (size_t)h * S + 7;
-                    if (SWG) { TM[at] = (int16_t)(O + h * E); BF[h] = (unsigned char)((O + h * E) != MAXS ? 1 : 0); }
-                    else TM[at] = (int16_t)(h * GI);
-                }
+            if (BT && !SWG) {
+                for (int v = tid; v <= Rr; v += NT) TM[7 + v] = (int16_t)(v * GD);
+                for (int h = 1 + tid; h <= tlen; h += NT) TM[(size_t)h * S + 7] = (int16_t)(h * GI);   // row-init boundary cells flat[W*h]
+            }
+            if (BT && SWG) {   // row-init boundary cells {M = I = o + h e, D = MAX_SCORE}: the walk only ever asks whether column 1's D was extended from them
+                for (int h = 1 + tid; h <= tlen + 1; h += NT) BF[h] = (unsigned char)((O + h * E) + O <= MAXS ? 0 : 16);
             }
             // (the row-init stores above vs the tail owner's store to the same boundary cell below: write after write across
             // wavefronts through HBM -- made explicit exactly as in dp_wave.hpp: every store has completed before the barrier)
@@ -352,6 +445,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 // ---- pre-carry: I, A, G of this lane's K cells, two per instruction (nothing here depends on this row's carry or
                 // boundary cell: in a tailed pair it runs while the previous row's last strip is still finishing)
                 dps2 A[KP], Iv[KP], G[KP];
+                uint32_t fw[4] = {0u, 0u, 0u, 0u};                   // BT, SWG: the row's direction bits, assembled as the tests become known (layout: dp_traceback_swg_bits)
                 dps2 gmin = dps_splat(kInf16);
                 auto precarry = [&](auto MASKED) {
 #pragma unroll
@@ -363,7 +457,14 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         const dps2 f = dps_from(pk_ne01(pc16[j], tch2, ones));
                         const dps2 sub = f * costD + (diag + costM);
                         dps2 ins;
-                        if (SWG) ins = dps_min(Mp[j] + OEp, Ip[j] + Ep);
+                        if (SWG) {
+                            const dps2 insn = Mp[j] + OEp, inse = Ip[j] + Ep;
+                            ins = dps_min(insn, inse);
+                            if (BT) {   // "I extended": I_up + e < M_up + o + e (sign byte of the saturating difference -> bytes 2, 3, high nibble)
+                                const uint32_t sI = __builtin_amdgcn_perm(0u, dps_bits(__builtin_elementwise_sub_sat(inse, insn)), 0x09080c0cu);
+                                fw[j >> 2] |= sI & (0x10100000u << (j & 3));
+                            }
+                        }
                         else ins = Mp[j] + GIp;
                         Iv[j] = ins;
                         A[j] = dps_min(sub, ins);
@@ -423,6 +524,10 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     dps2 s_; s_.x = kInf16; s_.y = G[j].x;
                     const dps2 prej = dps_min(c, s_);                      // {pre(2j), pre(2j+1)}
                     c = dps_splat(min((int)prej.y, (int)G[j].y));
+                    if (BT && SWG) {   // "the next cell's D was extended": pre(v) < G(v) (-> bytes 0, 1, high nibble)
+                        const uint32_t sD = __builtin_amdgcn_perm(0u, dps_bits(__builtin_elementwise_sub_sat(prej, G[j])), 0x0c0c0908u);
+                        fw[j >> 2] |= sD & (0x00001010u << (j & 3));
+                    }
                     Do[j] = prej + cD[j];
                     Mp[j] = dps_min(A[j], Do[j]);
                     if (SWG) Ip[j] = Iv[j];
@@ -450,15 +555,27 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         bs[0] = cM; bs[1] = cI; bs[2] = cDd;
                         bs[3] = h + 1;                                     // (same-wavefront LDS writes complete in order)
                         if (BT) {
-                            const size_t tdst = (size_t)(h + 1) * S + 7;   // canonical home of flat[W*h + W]
-                            TM[tdst] = (int16_t)cM;
-                            if (SWG) BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0));
+                            if (SWG) BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0) | (upD + E < upM + OE ? 4 : 0) | (BI + E < BM + OE ? 8 : 0) |
+                                                                 (cM + O <= cDd ? 0 : 16));
+                            else TM[(size_t)(h + 1) * S + 7] = (int16_t)cM;   // canonical home of flat[W*h + W]
                         }
                     }
                 }
                 AIM_SSTAMP(5);   // tail cell / picks
                 // ---- table (BT): 16-byte stores where the lane's cells are all inside the row (off the critical path: after the posts)
-                if (BT && nvalid > 0) {
+                if (BT && SWG && nvalid > 0) {   // four direction bits per cell: the sign bytes of four saturating differences, gathered by v_perm_b32 (selectors
+                                                 // 8 .. 11 replicate a source's sign bits) and merged per four registers; the two gap tests are in fw already
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) {
+                        const uint32_t dA = dps_bits(__builtin_elementwise_sub_sat(A[j], Do[j])), dB = dps_bits(__builtin_elementwise_sub_sat(A[j], Iv[j]));
+                        const uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);
+                        fw[j >> 2] |= w1 & (0x01010101u << (j & 3));
+                    }
+                    uint32_t *dst = FLW + ((size_t)h * FS + wv * kWave + lane) * NQS;
+                    if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+                    else *reinterpret_cast<uint2 *>(dst) = make_uint2(fw[0], fw[1]);
+                }
+                if (BT && !SWG && nvalid > 0) {
                     const size_t trow = (size_t)h * S + 7 + v0;
                     if constexpr (K % 8 == 0) {
 #pragma unroll
@@ -468,16 +585,6 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
 #pragma unroll
                         for (int q = 0; q < K / 4; ++q)
                             *reinterpret_cast<uint2 *>(&TM[trow + 4 * q]) = make_uint2(dps_bits(Mp[2 * q]), dps_bits(Mp[2 * q + 1]));
-                    }
-                    if (SWG) {   // two bits per cell instead of the I and D planes: M != D, M != I (unsigned min with 1 of the xor)
-                        uint32_t fw[2] = {0u, 0u};
-#pragma unroll
-                        for (int j = 0; j < KP; ++j) {
-                            const uint32_t nd = pk_ne01(dps_bits(Mp[j]), dps_bits(Do[j]), ones);
-                            const uint32_t ni = pk_ne01(dps_bits(Mp[j]), dps_bits(Iv[j]), ones);
-                            fw[j >> 3] |= (nd | (ni << 1)) << (2 * (j & 7));
-                        }
-                        FL[(size_t)h * FS + wv * kWave + lane] = make_uint2(fw[0], fw[1]);
                     }
                 }
             }
@@ -506,8 +613,11 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     const int bM = BM, bI = BI;   // every wavefront read B(tlen) at the start of the last row
                     int upM = tl[0], upD = tl[1];
                     int lastM = 0;
-                    int tw_g = -1;                    // flag word being assembled for the tail cells
-                    uint32_t tw_x = 0u, tw_y = 0u;
+                    int tw_g = -1;                    // lane word (direction bits) being assembled for the tail cells
+                    uint32_t tw[4] = {0u, 0u, 0u, 0u};
+                    auto tw_flush = [&]() {
+                        if (tw_g >= 0 && lane == 0) for (int d = 0; d < NQS; ++d) FLW[((size_t)(h + 1) * FS + tw_g) * NQS + d] = tw[d];
+                    };
                     const size_t tdst = (size_t)(h + 1) * S + 7;
                     for (int v = W; v <= plen; ++v) {
                         int leftM, leftI, diagM;
@@ -527,27 +637,28 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                             cI = cDd = 0;
                             cM = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(leftM + GI, upM + GD));
                         }
-                        if (BT) {
-                            if (lane == 0) TM[tdst + (v - W)] = (int16_t)cM;
-                            if (SWG) {   // the flags of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array)
-                                const uint32_t ne = (cM != cDd ? 1u : 0u) | (cM != cI ? 2u : 0u);
-                                const int C = v - W;
-                                if (C == 0) { if (lane == 0) BF[h + 1] = (unsigned char)ne; }
-                                else {
-                                    const int g = (C - 1) / K, t = (C - 1) - g * K, j = t >> 1;
-                                    if (g != tw_g) {
-                                        if (tw_g >= 0 && lane == 0) FL[(size_t)(h + 1) * FS + tw_g] = make_uint2(tw_x, tw_y);
-                                        tw_g = g; tw_x = tw_y = 0u;
-                                    }
-                                    const uint32_t bits = ne << (((t & 1) ? 16 : 0) + 2 * (j & 7));
-                                    if (j < 8) tw_x |= bits; else tw_y |= bits;
+                        if (BT && !SWG) { if (lane == 0) TM[tdst + (v - W)] = (int16_t)cM; }
+                        if (BT && SWG) {   // the direction bits of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array)
+                            const uint32_t nD = cM != cDd ? 1u : 0u, nI = cM != cI ? 1u : 0u, xD = upD + E < upM + OE ? 1u : 0u, xI = leftI + E < leftM + OE ? 1u : 0u;
+                            const int C = v - W;
+                            if (C == 0) { if (lane == 0) BF[h + 1] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | (cM + O <= cDd ? 0u : 16u)); }
+                            else {
+                                if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left (column 1's: BF bit 4, set with column 0)
+                                    const int t = (C - 2) - tw_g * K, j = t >> 1;
+                                    tw[j >> 2] |= xD << (8 * (t & 1) + 4 + (j & 3));
                                 }
+                                const int g = (C - 1) / K, t = (C - 1) - g * K, j = t >> 1;
+                                if (g != tw_g) {
+                                    tw_flush();
+                                    tw_g = g; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
+                                }
+                                tw[j >> 2] |= (nD << (8 * (t & 1) + (j & 3))) | (nI << (8 * (2 + (t & 1)) + (j & 3))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & 3)));
                             }
                         }
                         upM = cM; upD = cDd;
                         lastM = cM;
                     }
-                    if (BT && SWG && tw_g >= 0 && lane == 0) FL[(size_t)(h + 1) * FS + tw_g] = make_uint2(tw_x, tw_y);
+                    if (BT && SWG) tw_flush();
                     if (lane == 0) tl[3] = lastM;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -561,8 +672,13 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
         }
 
         if (BT && wv == 0) {
-            if (SWG && !literal) dp_traceback_swg_compact<K>(a.p, plen, tlen, S, FS, TM, FL, BF, rowM, ops, lane, begin_offset, status);
+            if (SWG && !literal) dp_traceback_swg_bits<K>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), ops, lane, begin_offset);
             else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
+        }
+        if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)
+            __syncthreads();
+            if (tid == 0) atomicExch(&pool_locks[pool_slot], 0u);
+            TM = tb; TI = tb + plane; TD = tb + 2 * plane;
         }
 #ifdef AIM_STRIP_STAMPS
         __syncthreads();         // the traceback is done with the ops row: the stamps go there (the CIGAR of a diagnostic build is void)
@@ -618,7 +734,7 @@ inline bool dp_strip_supported(const aim_params_t &p, bool cell8, const Knobs &k
 }
 
 inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budget, const Knobs &kn, uint32_t *grid, uint32_t *block, size_t *lds,
-                          uint64_t *scratch_per_wg, size_t *scratch_total, int *k_out)
+                          uint64_t *scratch_per_wg, size_t *scratch_total, int *k_out, uint32_t *pool_tables)
 {
     const uint64_t rs = (uint64_t)p.read_size;
     const bool swg = p.algo == AIM_ALGO_SWG;
@@ -626,8 +742,14 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     if (!dp_strip_shape(p, kn, &sh, n_pairs)) return false;
     *k_out = sh.k;
     const uint64_t S = (uint64_t)dp_strip_stride((int)rs, sh.k);
-    uint64_t per = (swg ? 3 : 1) * S * (rs + 3) * 2;              // int16 planes: the traceback's table; score-only launches touch it on the literal path only
+    // NW: one int16 plane per workgroup. SWG (round 5): four direction bits per cell (NQS dwords per lane and row) + one byte per row, and a POOL of
+    // three-plane tables for the literal path behind the slabs (dp_strip_pool_bytes); score-only launches touch neither.
+    const uint64_t nq = (uint64_t)((sh.k / 2 + 3) / 4), nqs = nq == 3 ? 4 : nq, fs = rs / (uint64_t)sh.k + 2;
+    uint64_t per = swg ? (rs + 3) * fs * nqs * 4 + (rs + 3) + 64 : S * (rs + 3) * 2;
+    if (swg && !(p.flags & AIM_FLAG_BACKTRACE)) per = 256;
     per = (per + 255) & ~255ull;
+    const uint64_t table = swg ? 3 * S * (rs + 3) * 2 : 0;         // one pool table
+    if (swg) { if (budget < 256 + table + per) return false; budget -= 256 + table; }   // (at least one table; more as the budget allows, dp_strip_pool_tables)
     const int nw = sh.nw;
     *block = (uint32_t)(kWave * nw);
     const uint64_t seqcap = (rs + 79) & ~15ull, rowcap = (rs + 47) & ~7ull;
@@ -647,6 +769,12 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     *grid = g;
     *scratch_per_wg = per;
     *scratch_total = (size_t)(per * g);
+    if (swg) {   // [slabs | 256 B of lock words | pool tables]: up to 8 tables where the budget admits them
+        uint64_t tables = 1;
+        while (tables < 8 && tables < g && per * g + 256 + (tables + 1) * table <= budget + table) ++tables;
+        *pool_tables = (uint32_t)tables;
+        *scratch_total += (size_t)(256 + tables * table);
+    } else *pool_tables = 0;
     return true;
 }
 

@@ -37,7 +37,7 @@ def test_kernels_are_compiled_for_gfx950(built):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "gfx950" in out
     blob = open(capi.LIB_PATH, "rb").read()
-    for k in (b"wfa_lane_kernel", b"wfa_wave_kernel", b"nw_lane_kernel", b"swg_lane_kernel", b"nw_reg_kernel", b"genasm_wave_kernel"):
+    for k in (b"wfa_lane_kernel", b"wfa_wave_kernel", b"nw_lane_kernel", b"swg_lane_kernel", b"nw_reg_kernel", b"swg_reg_kernel", b"genasm_wave_kernel"):
         assert k in blob
 
 
@@ -94,7 +94,10 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_reg_kernel"                           # round 4: rows in registers up to READ_SIZE 128 (112 with CIGAR)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 120, backtrace=True))) == b"nw_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 136))) == b"nw_lane_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_reg_kernel"                          # round 5: M and I rows in registers up to READ_SIZE 128
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 112, backtrace=True))) == b"swg_reg_kernel"       # (int16 cells too)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 136))) == b"swg_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112, match=-1))) == b"swg_lane_kernel"              # (negative costs: cells may be negative without a wrap)
 
 
 def _plan_line(params, n, env):

@@ -624,7 +624,7 @@ def test_dp_lane_all_length_relations(gpu):
     for algo, ms, kw in (("nw", 40, dict(backtrace=True)), ("nw", 40, dict()), ("swg", 40, dict(backtrace=True)),
                          ("swg", 200, dict(backtrace=True)), ("swg", 40, dict())):
         params = engine.make_params(algo, ms, 112, **kw)
-        assert capi.load().aim_kernel_name(C.byref(params)) in (b"nw_reg_kernel", b"nw_lane_kernel", b"swg_lane_kernel")   # (nw_reg: nearly all of these pairs take its to-do list to nw_lane_kernel)
+        assert capi.load().aim_kernel_name(C.byref(params)) in (b"nw_reg_kernel", b"nw_lane_kernel", b"swg_reg_kernel", b"swg_lane_kernel")   # (nw_reg: nearly all of these pairs take its to-do list to nw_lane_kernel)
         _compare(algo, params, req, pat, txt, threads=4)
 
 
@@ -1591,3 +1591,62 @@ def test_host_cli_takes_gap_i_and_gap_d(gpu, tmp_path):
     r = _host_cli(case, inp, out, tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
     assert md5(out.read_bytes()) == case["output_md5"]
+
+
+# ------------------------------------------------------------------ swg_reg_kernel
+@pytest.mark.parametrize("l,err", [(100, 0.01), (100, 0.05), (100, 0.10), (70, 0.02), (60, 0.10), (90, 0.03), (104, 0.0), (40, 0.05), (54, 0.02)])
+@pytest.mark.parametrize("bt", [False, True])
+def test_swg_rows_in_registers_kernel(gpu, monkeypatch, l, err, bt):
+    """swg_reg_kernel (dp_reg.hpp: M and I rows in registers, left-aligned, value * 256 in 16-bit fields for int8 cells) against the oracle: both
+    length relations it takes (plen <= tlen, plen == tlen + 1: the aliased boundary cell {M, D}), the pairs it hands to swg_lane_kernel (plen >= tlen + 2,
+    short outliers, pairs whose int8 cells wrap), every READ_SIZE class (48 ... 128), int8 and int16 cells, other penalties, and equality with the
+    LDS-row kernel alone (AIM_NO_SWG_REG=1)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes("swg", l, max(err, 0.01))
+    n = 6000
+    req, pat, txt = engine.gen_pairs(8000 + l, 0, n, l, err, rs)
+    for i in range(0, n, 97):                                                  # outliers: a few short pairs, a few long tails, unrelated texts
+        req["pattern_len"][i] = max(1, l // 3)
+    for i in range(5, n, 131):
+        req["text_len"][i] = max(1, int(req["text_len"][i]) - 7)
+    rng = np.random.default_rng(l)
+    for i in range(11, n, 61):                                                 # unrelated sequences: cells reach MAX_SCORE + min(h, v) e (quirk S2) and int8 cells wrap
+        txt[i, :int(req["text_len"][i])] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(req["text_len"][i]))
+    for cost, kw in ((dict(), dict()), (dict(mismatch=2, gap_o=5, gap_e=1), dict()), (dict(mismatch=7, gap_o=3, gap_e=2), dict()),
+                     (dict(), dict(swg_w16=True)), (dict(mismatch=5, gap_o=2, gap_e=3), dict(swg_w16=True))):
+        params = engine.make_params("swg", ms, rs, backtrace=bt, **cost, **kw)
+        res, ops, _ = _compare("swg", params, req, pat, txt)
+        with engine.DeviceSet(1) as s:
+            s.configure(params, n)
+            s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
+            assert s.plan_describe(0).startswith("swg_reg_kernel"), s.plan_describe(0)
+            fb = s.fallback_pairs(0)
+            tails = int((req["pattern_len"] > req["text_len"] + (1 if bt else 9)).sum())   # with CIGAR: plen >= tlen + 2; score-only: more than 8 tail cells in the last row
+            assert tails <= fb, (fb, tails)
+            if not cost and not kw and err <= 0.05 and l >= 60:
+                assert fb <= tails + n // 20, (fb, tails)                       # default costs: the to-do list is the tail pairs + the outliers + the unrelated pairs
+    monkeypatch.setenv("AIM_NO_SWG_REG", "1")
+    params = engine.make_params("swg", ms, rs, backtrace=bt)
+    res2, ops2 = engine.align(params, req, pat, txt, check=False)
+    monkeypatch.delenv("AIM_NO_SWG_REG")
+    res1, ops1 = engine.align(params, req, pat, txt, check=False)
+    assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
+
+
+def test_swg_register_kernel_sends_wrapping_pairs_to_the_literal_kernel(gpu):
+    """int8 cells (MAX_SCORE 25, l = 100): unrelated sequences drive cells past 127 (S2 + S3); the register kernel must notice (sign of the OR of
+    every stored M) and leave exactly such pairs to swg_lane_kernel -- bit-exact either way, incl. AIM_PAIR_SWG_NO_OP where the oracle has it."""
+    from aim_amd import capi, engine
+    rng = np.random.default_rng(5)
+    n = 2000
+    req, pat, txt = engine.gen_pairs(31, 0, n, 100, 0.05, 112)
+    for i in range(0, n, 2):
+        txt[i, :int(req["text_len"][i])] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(req["text_len"][i]))
+    for bt in (False, True):
+        params = engine.make_params("swg", 25, 112, backtrace=bt)
+        _compare("swg", params, req, pat, txt)
+        with engine.DeviceSet(1) as s:
+            s.configure(params, n)
+            s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
+            assert s.plan_describe(0).startswith("swg_reg_kernel")
+            assert n // 4 <= s.fallback_pairs(0) <= n // 2 + n // 5           # the unrelated half (those that wrap) and the related pairs whose cells pass 127 far from the diagonal -- not everything

@@ -38,6 +38,11 @@ CONFIGS = {
     "nw_l70_e2_score": dict(algo="nw", l=70, e=0.02, n=1 << 20, kw=dict()),
     "swg_l100_e1_cigar": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "swg_l100_e1_score": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict()),
+    "swg_l100_e2_score": dict(algo="swg", l=100, e=0.02, n=1 << 20, kw=dict()),
+    "swg_l100_e5_score": dict(algo="swg", l=100, e=0.05, n=1 << 20, kw=dict()),
+    "swg_l100_e5_cigar": dict(algo="swg", l=100, e=0.05, n=1 << 20, kw=dict(backtrace=True)),
+    "swg_l100_e10_score": dict(algo="swg", l=100, e=0.10, n=1 << 20, kw=dict()),
+    "swg_l70_e2_score": dict(algo="swg", l=70, e=0.02, n=1 << 20, kw=dict()),
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict(backtrace=True)),
@@ -76,6 +81,7 @@ def run(name, cfg, reps=3):
             best = k if best is None else min(best, k)
         res, ops = s.pull(0)
         plan = s.plan_describe(0)
+        todo = s.fallback_pairs(0)
     cells = float((req["pattern_len"].astype(np.int64) * req["text_len"]).sum())
     alg = float(req["pattern_len"].sum() + req["text_len"].sum() + 16 * cfg["n"])
     if ops is not None:
@@ -84,7 +90,7 @@ def run(name, cfg, reps=3):
                       "pairs": cfg["n"], "max_score": ms, "read_size": rs, "kernel_ms": best,
                       "pairs_per_s": cfg["n"] / (best * 1e-3), "gcups": cells / (best * 1e-3) / 1e9,
                       "algorithmic_GBps": alg / (best * 1e-3) / 1e9, "algorithmic_bytes": alg, "mean_score": float(res["score"].mean()),
-                      "plan": plan}), flush=True)
+                      "todo_pairs": todo, "plan": plan}), flush=True)
 
 
 if __name__ == "__main__":

@@ -99,18 +99,29 @@ def main():
             cost = dict(mismatch=rng.randint(1, 9), gap=rng.choice([1, 2, 3, 4, 5, 9, 30, 60])) if (algo == "nw" and rng.random() < 0.5) else {}
             if algo == "nw" and rng.random() < 0.4:                     # GAP_I != GAP_D (nw.c:67-153; nw_reg's tilt treats them separately)
                 cost = dict(mismatch=rng.randint(1, 9), gap_i=rng.choice([1, 2, 3, 4, 6, 7, 9, 30]), gap_d=rng.choice([1, 2, 3, 5, 6, 7, 9, 30]))
+            if algo == "swg" and rng.random() < 0.5:                   # swg_reg_kernel on both sides of swg_reg_supported(): other costs, int16 cells, MAX_SCORE as the pseudo-infinity
+                cost = dict(mismatch=rng.randint(1, 9), gap_o=rng.choice([1, 2, 4, 6, 9, 40]), gap_e=rng.choice([1, 1, 2, 3, 5]))
+                if rng.random() < 0.1: cost["match"] = rng.choice([-2, -1, 0])
             n = rng.choice([1, 63, 64, 65, 1000, 4097, 9000])
             bt = rng.random() < 0.6
             ms = rng.randint(1, 60)
+            if algo == "swg":
+                ms = rng.choice([0, 1, 5, 10, 25, 50, 100, 126, 127, 200, 2000])
+                if rng.random() < 0.3: cost["swg_w16"] = True
             params = engine.make_params(algo, ms, rs, backtrace=bt, **cost)
             for k in list(os.environ):
                 if k.startswith("AIM_") and k != "AIM_LIB" and not k.startswith("AIM_DEBUG_POISON"): os.environ.pop(k)
             env = {}
             if rng.random() < 0.15: env["AIM_NO_NW_REG"] = "1"
+            if rng.random() < 0.1: env["AIM_NO_SWG_REG"] = "1"
             if rng.random() < 0.2: env["AIM_NW_REG_PER_CU"] = rng.choice(["1", "3", "16"])
             if rng.random() < 0.2: env["AIM_DPL_PER_CU"] = rng.choice(["1", "3", "12"])
             os.environ.update(env)
             req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
+            if algo == "swg" and n > 8 and rng.random() < 0.4:          # unrelated texts: cells climb to MAX_SCORE + min(h, v) e, int8 cells wrap, the walk may find no operation
+                for i in range(0, n, rng.choice([2, 7, 50])):
+                    k = int(req["text_len"][i])
+                    txt[i, :k] = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(k)), dtype=np.uint8)
             for _ in range(rng.choice([0, 3, 40])):                     # outliers: shorter patterns / texts (contents stay what they were)
                 i = rng.randrange(n)
                 if rng.random() < 0.5: req["pattern_len"][i] = rng.randint(0, int(req["pattern_len"][i]))
