@@ -119,6 +119,7 @@ aim::Knobs read_knobs()
     k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
     k.no_nw_reg = env_flag("AIM_NO_NW_REG");
     k.no_swg_reg = env_flag("AIM_NO_SWG_REG");
+    k.dbg_flags = env_int("AIM_DEBUG_FLAGS", 0);
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
@@ -609,6 +610,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     ka.slot_w = pl.slot_w;
     ka.todo = nullptr;
     ka.dbg_poison_lds = kn.poison_lds >= 0 ? (0x100u | (uint32_t)(kn.poison_lds & 0xff)) : 0u;
+    ka.dbg_flags = (uint32_t)kn.dbg_flags;
     ka.dbg_lds_bytes = (uint32_t)pl.lds;
     ka.packedP = fio ? fio->packedP : nullptr;
     ka.packedT = fio ? fio->packedT : nullptr;

@@ -31,6 +31,7 @@ struct KArgs {
     const uint32_t *todo; // nullptr: units are pairs 0..n_pairs-1; else {count @0, pair ids @16..} written by wfa_lane
     uint32_t dbg_poison_lds;    // debugging aid (AIM_DEBUG_POISON_LDS): 0 = off, else 0x100 | byte every workgroup fills its
     uint32_t dbg_lds_bytes;     // dynamic LDS with at kernel entry (results must not depend on it)
+    uint32_t dbg_flags;         // diagnostic runs only (AIM_DEBUG_FLAGS; results are WRONG with any bit set): 1 = dp_strip skips the traceback walk
     // Fused batch I/O (round 3; aim_hip.h "pipelined batches"): kernels that can, consume the packed image of a batch
     // directly and emit the compact CIGAR themselves -- no unpack pass, no ops rows, no run-length pass.
     const uint32_t *packedP;    // [n][ceil(read_size/16)] dwords, 2 bits per base, or nullptr (ASCII rows in patterns / texts)
@@ -100,6 +101,7 @@ struct Knobs {
     int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: where the pattern row lives -- 0 global memory, 1 LDS image, 2 registers (READ_SIZE <= 124); unset: the measured default
     int dpl_per_cu = -1;          // AIM_DPL_PER_CU      dp_lane: residency sweep
     bool no_nw_reg = false;       // AIM_NO_NW_REG=1     NW short reads: nw_lane_kernel only (rows in LDS), no nw_reg_kernel (row in registers) in front
+    int dbg_flags = 0;            // AIM_DEBUG_FLAGS     diagnostic timing runs (KArgs::dbg_flags)
     bool no_swg_reg = false;      // AIM_NO_SWG_REG=1    SWG short reads: swg_lane_kernel only, no swg_reg_kernel (rows in registers) in front
     int nw_reg_per_cu = -1;       // AIM_NW_REG_PER_CU   nw_reg: residency sweep
     int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs

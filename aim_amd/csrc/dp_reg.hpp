@@ -493,9 +493,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         uint32_t hot = (ISW && jl >= JW) ? 1u << (jl - JW) : 0u;
         opaque(hot);
         const int hmax = -wave_min_i32(mine ? -tlen : 0);
+        // registers the rows run over: the last four are skipped when no lane's columns reach them (score-only; a wave-uniform test per register: a column
+        // never reads a higher index, so stale values there harm nobody). l = 100 at READ_SIZE 112: 50 of 53.
+        const int njrun = BT ? NPK : -wave_min_i32(mine ? -((pe + 1) >> 1) : 0);
+        uint32_t tword = 0u;
         for (int h = 1; h <= hmax; ++h) {
+            if (((h - 1) & 3) == 0) tword = ldsT[((h - 1) >> 2) * kWave + lane];   // one text dword per four rows
             if (h <= tlen) {                                  // (lanes whose table is complete keep their rows: the score is picked up after the loop)
-                const uint32_t tword = ldsT[((h - 1) >> 2) * kWave + lane];
                 const uint32_t tch2 = ((tword >> (((h - 1) & 3) * 8)) & 0xffu) * 0x00010001u;
                 acc |= MbH;
                 uint32_t Dprev = DbH, Aprev = MbH + oeH;      // left of register 0: the boundary cell (its M + o + e is the reference's own del_new)
@@ -507,6 +511,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 uint32_t diag = __builtin_amdgcn_alignbit(M[0], oldprev, 16);           // {M[h-1][index - 1]} of register 0's cells
 #pragma unroll
                 for (int j = 0; j < NPK; ++j) {
+                    if (!BT && j >= NPK - 4 && j >= njrun) continue;
                     // everything that reads the OLD row's register j is taken first -- the next register's diagonal too -- so that the new value
                     // can be written over it (in place: as a plain read-later the compiler kept a v_mov copy per register and row)
                     uint32_t insn = add2(M[j], oe2);

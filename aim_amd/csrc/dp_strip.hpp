@@ -188,10 +188,11 @@ __device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, 
 // bits 0 - 3 the cell's own four tests (D extended = its OWN), bit 4 "D of column 1 extended".
 template <int K>
 __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int plen, int tlen, int FS, const uint32_t *FLW, const unsigned char *BF,
-                                                      const unsigned char *ldsP, const unsigned char *ldsT, uint32_t *tile, char *ops, int lane, int &begin_offset)
+                                                      const unsigned char *ldsP, const unsigned char *ldsT, uint32_t *tile, int tile_rows, char *ops, int lane,
+                                                      int &begin_offset)
 {
     constexpr int KP = K / 2, NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;
-    constexpr int kTR = 32;                                       // rows of the window (the walk moves up one row per step at most)
+    const int kTR = tile_rows;                                    // rows of the window: 64 or 128 (what the workgroup's LDS admits; 8 lane words wide)
     const int rs = p.read_size, W = tlen + 1;
     int sentinel = plen + tlen - 1;
     int h = tlen, v = plen;
@@ -200,26 +201,53 @@ __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int
     int tR = -1, tG0 = 0;
     auto refill = [&](int R, int g) {                             // rows R .. R - kTR + 1, lane words g - 7 .. g (clamped at 0)
         tR = R; tG0 = g >= 7 ? g - 7 : 0;
-#pragma unroll
         for (int q = 0; q < kTR / 8; ++q) {
             const int rr = 8 * q + (lane >> 3), r = R - rr, gg = tG0 + (lane & 7);
             if (r >= 0 && gg < FS) {
-#pragma unroll
-                for (int d = 0; d < NQS; ++d) tile[(rr * 8 + (lane & 7)) * NQS + d] = FLW[((size_t)r * FS + gg) * NQS + d];
+                if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(&tile[(rr * 8 + (lane & 7)) * 4]) = *reinterpret_cast<const uint4 *>(&FLW[((size_t)r * FS + gg) * 4]);
+                else *reinterpret_cast<uint2 *>(&tile[(rr * 8 + (lane & 7)) * 2]) = *reinterpret_cast<const uint2 *>(&FLW[((size_t)r * FS + gg) * 2]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
-    auto cellbits = [&](int R, int C) -> uint32_t {               // regular cell (R, C), C >= 1: bit 0 M != D, bit 4 next D extended, bit 16 M != I, bit 20 I extended
-        const int g = (C - 1) / K;
-        if (!(tR >= 0 && R <= tR && R > tR - kTR && g >= tG0 && g < tG0 + 8)) refill(R, g);
+    auto in_tile = [&](int R, int g) { return tR >= 0 && R <= tR && R > tR - kTR && g >= tG0 && g < tG0 + 8; };
+    auto tilebits = [&](int R, int C, int g) -> uint32_t {        // regular cell (R, C), C >= 1, inside the window: bit 0 M != D, bit 4 next D extended, bit 16 M != I, bit 20 I extended
         const int t = (C - 1) - g * K, j = t >> 1;
         return tile[((tR - R) * 8 + (g - tG0)) * NQS + (j >> 2)] >> (8 * (t & 1) + (j & 3));
+    };
+    auto cellbits = [&](int R, int C) -> uint32_t {               // wave-uniform (R, C)
+        const int g = (C - 1) / K;
+        if (!in_tile(R, g)) refill(R, g);
+        return tilebits(R, C, g);
     };
     // (R, C): the canonical position of flat index W h + v (rows of W cells); moves: D at - 1, I at - W, diagonal at - W - 1
     int R = W ? (W * h + v) / W : 0, C = (W * h + v) - R * W;
     int layer = 0;                                                // 0: M, 1: I, 2: D
     while (h > 0 && v > 0) {
+        if (layer == 0 && C >= 1 && R <= tlen) {
+            // A RUN OF DIAGONAL MOVES, 64 cells at a time: lane i looks at cell (R - i, C - i) -- inside the table, inside the window, both "M != D" and "M != I" --
+            // and the run is the leading lanes that pass; each writes its own 'M' / 'X' (the cell's own characters). At e = 1 % a run is ~100 cells:
+            // one lane stepping through them (and the window's refills every 31 rows) was 4.6 of config 4's 23.8 ms.
+            const int g0 = (C - 1) / K;
+            if (!in_tile(R, g0) || (tR - kTR + 1 > 1 && R - (tR - kTR + 1) < kTR / 2)) refill(R, g0);   // (keep half a window of rows above the current one)
+            const int ri = R - lane, ci = C - lane;
+            bool ok = lane < h && lane < v && ci >= 1 && ri >= 1;
+            const int gi = ok ? (ci - 1) / K : 0;
+            ok = ok && in_tile(ri, gi);
+            uint32_t b = 0u;
+            if (ok) b = tilebits(ri, ci, gi);
+            ok = ok && (b & 1u) && (b & 0x10000u);
+            const unsigned long long okm = __ballot(ok);
+            const int run = okm == ~0ull ? kWave : __builtin_ctzll(~okm);
+            if (run > 0) {
+                if (lane < run) {
+                    const int at = sentinel - lane;
+                    if (at >= 0 && at < cap) ops[at] = ldsP[ci - 1] != ldsT[ri - 1] ? 'X' : 'M';
+                }
+                sentinel -= run; h -= run; v -= run; R -= run; C -= run;
+                continue;
+            }
+        }
         uint32_t nD, nI, xD, xI;
         if (C >= 1) {
             const uint32_t b = cellbits(R, C);
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
     const int rowcap = (rs + 47) & ~7;
     int16_t *rowM = reinterpret_cast<int16_t *>(ldsT + seqcap);
     int16_t *rowI = rowM + rowcap;
-    const int rowbytes = (2 * rowcap * 2 > 6 * 1024 ? 2 * rowcap * 2 : 6 * 1024);   // (the tracebacks' tiles live here afterwards: up to 6 KB)
+    const int rowbytes = (2 * rowcap * 2 > 8 * 1024 ? 2 * rowcap * 2 : 8 * 1024);   // (the tracebacks' tiles live here afterwards: 8 KB, 16 KB where the rows leave as much)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;   // LDS byte offset of the dynamic segment
     const uint32_t mb0 = lds0 + (uint32_t)(2 * seqcap + rowbytes);
     const lds_msg_p mbC = (lds_msg_p)(uintptr_t)mb0;                                                  // [kStripMaxWaves][kStripDepth]: strip w's minimum of G over its columns, per row
@@ -671,8 +699,8 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             __syncthreads();                          // everyone has read rowM / tl before the traceback reuses the area as its tile
         }
 
-        if (BT && wv == 0) {
-            if (SWG && !literal) dp_traceback_swg_bits<K>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), ops, lane, begin_offset);
+        if (BT && wv == 0 && !(a.dbg_flags & 1u)) {
+            if (SWG && !literal) dp_traceback_swg_bits<K>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 16 * 1024 ? 128 : 64, ops, lane, begin_offset);
             else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
         }
         if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)
@@ -753,7 +781,7 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     const int nw = sh.nw;
     *block = (uint32_t)(kWave * nw);
     const uint64_t seqcap = (rs + 79) & ~15ull, rowcap = (rs + 47) & ~7ull;
-    const uint64_t rowbytes = std::max<uint64_t>(2 * rowcap * 2, 6 * 1024);
+    const uint64_t rowbytes = std::max<uint64_t>(2 * rowcap * 2, 8 * 1024);
     *lds = (size_t)(2 * seqcap + rowbytes + 2 * kStripMaxWaves * kStripDepth * sizeof(StripMsg) + kStripMaxWaves * 4 + 16 * kStripDepth + 64);
     if (*lds > 160 * 1024) return false;
     // resident workgroups per CU: LDS, and the wavefronts the instantiation's register budget admits (64 * NWMAX threads per CU-quarter...)
