@@ -106,6 +106,7 @@ aim::Knobs read_knobs()
     k.force_wave = env_flag("AIM_FORCE_WAVE");
     k.no_group = env_flag("AIM_NO_GROUP");
     k.no_lane_ext = env_flag("AIM_NO_LANE_EXT");
+    k.no_lane = env_flag("AIM_NO_LANE");
     k.no_lane_pk = env_flag("AIM_NO_LANE_PK");
     k.group_overlap = env_flag("AIM_GROUP_OVERLAP");
     k.wfa_no_ring = env_flag("AIM_WFA_NO_RING");
@@ -233,7 +234,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         pl->scratch_total = (size_t)pl->grid * aim::kGaSlabBytes;   // slow-path columns, one slab per wavefront
         return AIM_OK;
     }
-    if (p.algo == AIM_ALGO_WFA && (mode & MODE_PACKED_IN) && !kn.force_wave && !kn.no_lane_pk && !pl->no_lane &&
+    if (p.algo == AIM_ALGO_WFA && (mode & MODE_PACKED_IN) && !kn.force_wave && !kn.no_lane_pk && !kn.no_lane && !pl->no_lane &&
         aim::wfa_lane_packed_supported(p, !kn.no_lane_ext)) {
         // packed rows in; {idx, score}, compact CIGAR or result_t + ops rows out: one kernel per batch, no scratch (wfa_lane_packed.hpp)
         pl->kid = K_WFA_LANE_PK;
@@ -244,7 +245,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         return AIM_OK;
     }
     if (p.algo == AIM_ALGO_WFA) {
-        const bool lane_ok = !kn.force_wave && !pl->no_lane && aim::wfa_lane_supported(p, !kn.no_lane_ext);
+        const bool lane_ok = !kn.force_wave && !kn.no_lane && !pl->no_lane && aim::wfa_lane_supported(p, !kn.no_lane_ext);
         aim::GroupCfg gc;
         int gg = 0;
         uint32_t ggrid = 0, gchunk = n_pairs;
@@ -284,7 +285,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
 #endif
             return AIM_OK;
         }
-        if (!lane_ok && !kn.force_wave && !kn.no_lane_pk && !pl->no_lane && aim::wfa_lane_packed_supported(p, !kn.no_lane_ext)) {
+        if (!lane_ok && !kn.force_wave && !kn.no_lane_pk && !kn.no_lane && !pl->no_lane && aim::wfa_lane_packed_supported(p, !kn.no_lane_ext)) {
             // ASCII rows of a shape only the packed lane kernel takes (READ_SIZE other than 80 / 112: l = 150 and friends; CIGAR at
             // MAX_SCORE 6..10): pack on the device (batch_io.hpp), run the packed kernel, let the general kernel re-align the
             // non-ACGT pairs (to-do list)

@@ -101,6 +101,7 @@ struct Knobs {
     int dpl_seq_lds = -1;         // AIM_DPL_SEQ_LDS     dp_lane: where the pattern row lives -- 0 global memory, 1 LDS image, 2 registers (READ_SIZE <= 124); unset: the measured default
     int dpl_per_cu = -1;          // AIM_DPL_PER_CU      dp_lane: residency sweep
     bool no_nw_reg = false;       // AIM_NO_NW_REG=1     NW short reads: nw_lane_kernel only (rows in LDS), no nw_reg_kernel (row in registers) in front
+    bool no_lane = false;         // AIM_NO_LANE=1       WFA: no one-pair-per-lane kernel (wfa_lane / wfa_lane_packed): the group kernel takes their shapes (A/B runs)
     int dbg_flags = 0;            // AIM_DEBUG_FLAGS     diagnostic timing runs (KArgs::dbg_flags)
     bool no_swg_reg = false;      // AIM_NO_SWG_REG=1    SWG short reads: swg_lane_kernel only, no swg_reg_kernel (rows in registers) in front
     int nw_reg_per_cu = -1;       // AIM_NW_REG_PER_CU   nw_reg: residency sweep

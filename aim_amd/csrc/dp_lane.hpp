@@ -482,10 +482,10 @@ __global__ __launch_bounds__(64) void swg_lane_kernel(KArgs a)
                 while (v > 0) { OPS(sentinel) = 'D', --sentinel; --v; }
             }
             begin_offset = sentinel + 1;
-            {
+            {   // (only the pieces that hold printed operations, ops[begin_offset, end_offset): host.c:347-349)
                 const uint4 *src = reinterpret_cast<const uint4 *>(RMa);
                 uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
-                for (int q = 0; q < (rs >> 3); ++q) dst[q] = src[q * kWave + lane];
+                for (int q = max(0, begin_offset) >> 4; q <= (end_offset - 1) >> 4 && q < (rs >> 3); ++q) dst[q] = src[q * kWave + lane];
             }
 #undef OPS
         }

@@ -192,32 +192,37 @@ __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int
                                                       int &begin_offset)
 {
     constexpr int KP = K / 2, NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;
-    const int kTR = tile_rows;                                    // rows of the window: 64 or 128 (what the workgroup's LDS admits; 8 lane words wide)
+    const int kTR = tile_rows;                                    // rows of the window: 64 or 256 (what the workgroup's LDS admits)
+    constexpr int kTW = 3;                                        // lane words per row of the window: a BAND around the diagonal through the cell it was filled at
     const int rs = p.read_size, W = tlen + 1;
     int sentinel = plen + tlen - 1;
     int h = tlen, v = plen;
     const int cap = 2 * rs;
     auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
-    int tR = -1, tG0 = 0;
-    auto refill = [&](int R, int g) {                             // rows R .. R - kTR + 1, lane words g - 7 .. g (clamped at 0)
-        tR = R; tG0 = g >= 7 ? g - 7 : 0;
-        for (int q = 0; q < kTR / 8; ++q) {
-            const int rr = 8 * q + (lane >> 3), r = R - rr, gg = tG0 + (lane & 7);
+    // The window: rows tR .. tR - kTR + 1; row tR - rr holds the lane words wbase(rr) .. wbase(rr) + 2, wbase(rr) = word of column (tC - rr) minus one -- the band
+    // follows the diagonal through (tR, tC), which is where the walk goes (a gap moves it by one column: ~K columns of slack either side). 256 rows are 12 KB and
+    // 12 loads per lane; the rectangular window of 128 rows x 8 words was 16 KB, 16 loads, and was refilled twice as often.
+    int tR = -1, tC = 0;
+    auto wbase = [&](int rr) { const int cc = tC - rr; const int g = ((cc > 1 ? cc : 1) - 1) / K; return g > 0 ? g - 1 : 0; };
+    auto refill = [&](int R, int C) {
+        tR = R; tC = C;
+        for (int q = lane; q < kTR * kTW; q += kWave) {
+            const int rr = q / kTW, w = q - rr * kTW, r = R - rr, gg = wbase(rr) + w;
             if (r >= 0 && gg < FS) {
-                if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(&tile[(rr * 8 + (lane & 7)) * 4]) = *reinterpret_cast<const uint4 *>(&FLW[((size_t)r * FS + gg) * 4]);
-                else *reinterpret_cast<uint2 *>(&tile[(rr * 8 + (lane & 7)) * 2]) = *reinterpret_cast<const uint2 *>(&FLW[((size_t)r * FS + gg) * 2]);
+                if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(&tile[q * 4]) = *reinterpret_cast<const uint4 *>(&FLW[((size_t)r * FS + gg) * 4]);
+                else *reinterpret_cast<uint2 *>(&tile[q * 2]) = *reinterpret_cast<const uint2 *>(&FLW[((size_t)r * FS + gg) * 2]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
-    auto in_tile = [&](int R, int g) { return tR >= 0 && R <= tR && R > tR - kTR && g >= tG0 && g < tG0 + 8; };
+    auto in_tile = [&](int R, int g) { if (!(tR >= 0 && R <= tR && R > tR - kTR)) return false; const int w = g - wbase(tR - R); return w >= 0 && w < kTW; };
     auto tilebits = [&](int R, int C, int g) -> uint32_t {        // regular cell (R, C), C >= 1, inside the window: bit 0 M != D, bit 4 next D extended, bit 16 M != I, bit 20 I extended
-        const int t = (C - 1) - g * K, j = t >> 1;
-        return tile[((tR - R) * 8 + (g - tG0)) * NQS + (j >> 2)] >> (8 * (t & 1) + (j & 3));
+        const int t = (C - 1) - g * K, j = t >> 1, rr = tR - R;
+        return tile[(rr * kTW + (g - wbase(rr))) * NQS + (j >> 2)] >> (8 * (t & 1) + (j & 3));
     };
     auto cellbits = [&](int R, int C) -> uint32_t {               // wave-uniform (R, C)
         const int g = (C - 1) / K;
-        if (!in_tile(R, g)) refill(R, g);
+        if (!in_tile(R, g)) refill(R, C);
         return tilebits(R, C, g);
     };
     // (R, C): the canonical position of flat index W h + v (rows of W cells); moves: D at - 1, I at - W, diagonal at - W - 1
@@ -229,7 +234,7 @@ __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int
             // and the run is the leading lanes that pass; each writes its own 'M' / 'X' (the cell's own characters). At e = 1 % a run is ~100 cells:
             // one lane stepping through them (and the window's refills every 31 rows) was 4.6 of config 4's 23.8 ms.
             const int g0 = (C - 1) / K;
-            if (!in_tile(R, g0) || (tR - kTR + 1 > 1 && R - (tR - kTR + 1) < kTR / 2)) refill(R, g0);   // (keep half a window of rows above the current one)
+            if (!in_tile(R, g0) || (tR - kTR + 1 > 1 && R - (tR - kTR + 1) < (kTR > 2 * kWave ? kWave : kTR / 2))) refill(R, C);   // (keep 64 rows -- a window of 64: 32 -- above the current one inside the window)
             const int ri = R - lane, ci = C - lane;
             bool ok = lane < h && lane < v && ci >= 1 && ri >= 1;
             const int gi = ok ? (ci - 1) / K : 0;
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
         }
 
         if (BT && wv == 0 && !(a.dbg_flags & 1u)) {
-            if (SWG && !literal) dp_traceback_swg_bits<K>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 16 * 1024 ? 128 : 64, ops, lane, begin_offset);
+            if (SWG && !literal) dp_traceback_swg_bits<K>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 12 * 1024 ? 256 : 64, ops, lane, begin_offset);
             else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
         }
         if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)

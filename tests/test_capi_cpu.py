@@ -158,14 +158,20 @@ def test_scratch_bound_default_and_override(built):
         r = subprocess.run([os.sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         return tuple(int(x) for x in r.stdout.split())
-    per_pair = 3 * ((rs4 + 16) & ~7) * (rs4 + 3) * 2
+    # round 5: a resident SWG pair's slab is FOUR DIRECTION BITS per cell (K = 20 cells per lane: 16 bytes per lane and row) + a byte per row -- 82 MB instead of
+    # the 614 MB of three int16 planes; the planes survive as a pool of 1 .. 8 tables for the literal path behind the slabs
+    table = 3 * ((rs4 + 20 + 16) & ~7) * (rs4 + 3) * 2
+    per_pair = (((rs4 + 3) * (rs4 // 20 + 2) * 16 + rs4 + 3 + 64) + 255) & ~255
     c4_default, c2_default = q()
     c4_16, c2_16 = q(AIM_SCRATCH_GB="16")
     c4_100, c2_100 = q(AIM_SCRATCH_GB="100")
+    c4_8, _ = q(AIM_SCRATCH_GB="8")
     assert c4_default == c4_16                               # no GPU here: 16 GB fallback
     assert c2_default == c2_16 == c2_100                     # need-capped plan
-    assert c4_16 <= 16 << 30 and c4_16 // per_pair in range(20, 28)     # 5 rounds of 128 pairs
-    assert c4_100 // per_pair == 128                         # one round
+    assert c4_16 == 128 * per_pair + 256 + 8 * table and c4_16 <= 16 << 30     # one round of 128 pairs (round 4: five) and the whole pool
+    assert c4_100 == c4_16                                   # need-capped too
+    assert c4_8 <= 8 << 30 and c4_8 < c4_16                   # a smaller bound trims the grid / the pool: g slabs + t tables, g a multiple of 8
+    assert any((c4_8 - 256 - t * table) % per_pair == 0 and ((c4_8 - 256 - t * table) // per_pair) % 8 == 0 for t in range(1, 9))
 
 
 def test_plans_follow_the_device_compute_unit_count(built):

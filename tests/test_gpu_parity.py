@@ -1650,3 +1650,68 @@ def test_swg_register_kernel_sends_wrapping_pairs_to_the_literal_kernel(gpu):
             s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
             assert s.plan_describe(0).startswith("swg_reg_kernel")
             assert n // 4 <= s.fallback_pairs(0) <= n // 2 + n // 5           # the unrelated half (those that wrap) and the related pairs whose cells pass 127 far from the diagonal -- not everything
+
+
+# ------------------------------------------------------------------ lane kernels beyond 3 / 4 / 1
+LANE_COSTS = [dict(mismatch=4, gap_o=6, gap_e=2), dict(mismatch=2, gap_o=3, gap_e=1), dict(mismatch=5, gap_o=4, gap_e=2)]
+
+
+@pytest.mark.parametrize("cost", LANE_COSTS, ids=lambda c: "x%dg%da%d" % (c["mismatch"], c["gap_o"], c["gap_e"]))
+@pytest.mark.parametrize("l,rs", [(100, 112), (70, 80), (150, 160)])
+@pytest.mark.parametrize("bt", [False, True])
+def test_lane_kernels_take_the_launchers_other_penalty_sets(gpu, cost, l, rs, bt):
+    """run-wfa-pim-wram.py:17-24 takes any -x -g -a; the one-pair-per-lane kernels are built for the sets of AIM_LANE_COST_SETS (wfa_lane.hpp) at the
+    launcher's MAX_SCORE for e = 1 % (ceil(l e) max(x, o + e)): ASCII rows through the default ABI (wfa_lane_kernel at READ_SIZE 80 / 112,
+    wfa_lane_packed_kernel after pack_rows elsewhere) and packed batches with the compact CIGAR -- against the oracle, incl. pairs beyond the
+    cap, a run-time MAX_SCORE below the shape's, and pairs with bytes outside A/C/G/T."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    cap = {4: 8, 2: 4, 5: 6}[cost["mismatch"]]                           # MAX_SCORE of the set's static shape (AIM_LANE_COST_SETS)
+    ms, rs_l = engine.launcher_sizes("wfa", l, 0.01, **cost)
+    assert rs_l == rs
+    ms = min(ms, cap)                                                    # (l = 150: the launcher's MAX_SCORE is two edits' worth -- the group kernel's)
+    n = 4000 + 21
+    req, pat, txt = engine.gen_pairs(900 + l, 0, n, l, 0.01, rs)
+    r2, p2, t2 = engine.gen_pairs(901 + l, 0, 400, l, 0.03, rs)          # some pairs beyond MAX_SCORE
+    req[1000:1400], pat[1000:1400], txt[1000:1400] = r2, p2, t2
+    req["idx"] = np.arange(n)
+    for i in range(0, n, 97):
+        pat[i, i % (l // 2)] = ord("N")
+    for ms_run in (ms, max(0, ms - cost["gap_e"] - 1)):
+        for reduce in (True, False):
+            params = engine.make_params("wfa", ms_run, rs, backtrace=bt, reduce=reduce, **cost)
+            want = b"wfa_lane_kernel" if rs in (80, 112) else b"wfa_lane_packed_kernel"
+            assert capi.load().aim_kernel_name(C.byref(params)) == want
+            res, _, ores = _compare("wfa", params, req, pat, txt)
+            assert (ores["score"] <= ms_run).any() and (ores["score"] == ms_run + 1).any()
+    params = engine.make_params("wfa", ms, rs, backtrace=bt, reduce=True, req8=True, res8=not bt, **cost)
+    ores, want_text = _oracle_text("wfa", params, req, pat, txt)
+    out, _ = _fused(params, req, pat, txt)
+    if bt:
+        assert np.array_equal(out["cig"]["score"], ores["score"]) and engine.format_output_runs(out["cig"], out["runs"]) == want_text
+    else:
+        assert np.array_equal(out["res"]["score"], ores["score"])
+    bigger = engine.make_params("wfa", cap + 1, rs, backtrace=bt, **cost)    # beyond the static shape: the group kernel
+    assert capi.load().aim_kernel_name(C.byref(bigger)) == b"wfa_group_kernel"
+
+
+def test_default_abi_ops_rows_need_no_prefilled_buffer(gpu, sample_bytes, ref_digests):
+    """the kernels write 'M' only where an operation can be printed (ops[begin_offset, end_offset), host.c:347-349) -- whatever the
+    caller's ops buffer held before (here: 0xEE everywhere, through aim_align_device-style reuse of one device set) the reference's file comes out."""
+    from aim_amd import engine
+    req, pat, txt = engine.parse_pairs(sample_bytes, 112)
+    n = len(req)
+    with engine.DeviceSet(1) as s:
+        for algo, ms, key, kw in (("swg", 5, "swg_w8_backtrace", {}), ("wfa", 5, "wfa_reduce_backtrace", dict(reduce=True)), ("nw", 4, "nw_backtrace", {}),
+                                  ("wfa", 5, "wfa_backtrace", {})):
+            # poison: a first launch whose CIGARs are long (unrelated texts) fills the device rows with other operations
+            rng = np.random.default_rng(3)
+            junk = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=txt.shape).astype(np.uint8)
+            pj = engine.make_params(algo, 200 if algo != "wfa" else 5, 112, backtrace=True, **kw)
+            s.configure(pj, n)
+            s.push(0, req, pat, junk); s.launch(); s.pull(0, check=False)
+            params = engine.make_params(algo, ms, 112, backtrace=True, **kw)
+            s.configure(params, n)
+            s.push(0, req, pat, txt); s.launch()
+            res, ops = s.pull(0)
+            assert md5(engine.format_output(res, ops, True)) == ref_digests[key]

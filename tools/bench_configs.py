@@ -13,6 +13,9 @@ from aim_amd import capi, engine  # noqa: E402
 
 CONFIGS = {
     "wfa_l100_e1_cigar": dict(algo="wfa", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True, reduce=True)),
+    "wfa_l100_e1_x4g6a2_score": dict(algo="wfa", l=100, e=0.01, n=1 << 22, kw=dict(reduce=True), cost=dict(mismatch=4, gap_o=6, gap_e=2)),
+    "wfa_l100_e1_x4g6a2_cigar": dict(algo="wfa", l=100, e=0.01, n=1 << 20, kw=dict(reduce=True, backtrace=True), cost=dict(mismatch=4, gap_o=6, gap_e=2)),
+    "wfa_l100_e1_score": dict(algo="wfa", l=100, e=0.01, n=1 << 22, kw=dict(reduce=True)),
     "wfa_l100_e2_score": dict(algo="wfa", l=100, e=0.02, n=1 << 20, kw=dict(reduce=True)),
     "wfa_l100_e2_cigar": dict(algo="wfa", l=100, e=0.02, n=1 << 20, kw=dict(backtrace=True, reduce=True)),
     "wfa_l100_e5_score": dict(algo="wfa", l=100, e=0.05, n=1 << 20, kw=dict(reduce=True)),
@@ -67,8 +70,9 @@ CONFIGS = {
 
 
 def run(name, cfg, reps=3):
-    ms, rs = engine.launcher_sizes(cfg["algo"], cfg["l"], cfg["e"])
-    params = engine.make_params(cfg["algo"], ms, rs, **cfg["kw"])
+    cost = cfg.get("cost", {})
+    ms, rs = engine.launcher_sizes(cfg["algo"], cfg["l"], cfg["e"], **cost)
+    params = engine.make_params(cfg["algo"], ms, rs, **cfg["kw"], **cost)
     req, pat, txt = engine.gen_pairs(42, 0, cfg["n"], cfg["l"], cfg["e"], rs)
     with engine.DeviceSet(1) as s:
         s.configure(params, cfg["n"])
