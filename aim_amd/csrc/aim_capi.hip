@@ -129,6 +129,7 @@ aim::Knobs read_knobs()
     k.group_unit1 = env_int("AIM_GROUP_UNIT1", 0);
     k.ga_per_cu = env_int("AIM_GA_PER_CU", 0);
     k.poison_scratch = env_int("AIM_DEBUG_POISON_SCRATCH", -1);
+    k.poison_ops = env_int("AIM_DEBUG_POISON_OPS", -1);
     k.poison_lds = env_int("AIM_DEBUG_POISON_LDS", -1);
     k.plan_debug = getenv("AIM_PLAN_DEBUG") != nullptr;
     k.cus = (uint32_t)std::max(0, env_int("AIM_CHIP_CUS", 0));   // 0: ask the device (chip_cus)
@@ -620,6 +621,8 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
     ka.runs_cap = fio ? fio->runs_cap : 0u;
     ka.cursor = fio ? fio->cursor : nullptr;
     ka.pair_base = 0;
+    if (kn.poison_ops >= 0 && d_ops && bt)   // debugging aid: results must not depend on what the ops rows held before (only ops[begin_offset, end_offset) is written)
+        HIP_TRY(hipMemsetAsync(d_ops, kn.poison_ops & 0xff, (size_t)n_pairs * 2 * p.read_size, stream));
     switch (pl.kid) {
     case K_WFA_WAVE:
         launch_wfa_wave(bt, red, pl, ka, stream);

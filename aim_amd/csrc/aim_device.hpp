@@ -111,6 +111,7 @@ struct Knobs {
     int ga_per_cu = 0;            // AIM_GA_PER_CU       genasm: wavefronts per CU (residency sweeps; bounded by LDS)
     int group_unit1 = 0;          // AIM_GROUP_UNIT1     wfa_group: step through every score like the reference (A/B of GroupCfg::unit)
     int group_wlds = -1;          // AIM_GROUP_WLDS      wfa_group: entries per LDS ring row (power of two = narrow window, 0 = one home per diagonal)
+    int poison_ops = -1;          // AIM_DEBUG_POISON_OPS      fill the ops rows with this byte before every launch (the kernels write ops[begin_offset, end_offset) only)
     int poison_scratch = -1;      // AIM_DEBUG_POISON_SCRATCH  fill scratch with this byte at configure
     int poison_lds = -1;          // AIM_DEBUG_POISON_LDS      fill dynamic LDS with this byte at kernel entry
     bool plan_debug = false;      // AIM_PLAN_DEBUG=1    print the chosen plan to stderr

@@ -719,13 +719,16 @@ __global__ __launch_bounds__(64, DYN ? 2 : AIM_LANE_MIN_WAVES) void wfa_lane_ker
         int begin_offset = plen + tlen - 1;     // edit_cigar_allocate, wfa.c:57-67
         int status = AIM_PAIR_OK;
         // (the 'M' prefill's wave-uniform bounds, see below: taken where every lane is on)
-        const int w_lo = BT ? wave_min_i32(active ? max(0, min(plen, tlen) - MAXS / E) >> 4 : (1 << 20)) : 0;
+        // (gaps of total length L cost at least o + L e: with the pair's own score, L <= (score - o) / e; a pair beyond MAX_SCORE prints its last byte only)
+        const int gap_len = done ? max(0, score - O) / E : 0;
+        const int w_lo = BT ? wave_min_i32(active ? max(0, (done ? min(plen, tlen) - gap_len : plen + tlen - 1)) >> 4 : (1 << 20)) : 0;
         const int w_hi = BT ? -wave_min_i32(active ? -((plen + tlen + 15) >> 4) : 0) : 0;
         if (BT && active) {
             // memset(cigar->operations, 'M', 2*READ_SIZE) (wfa.c:465): constant data, no VGPR image. Match runs of the backtrace then only move
             // begin_offset; edit ops are patched in as bytes. Only ops[begin_offset, end_offset) is ever looked at (host.c:347-349, edit_cigar_print), and
-            // a CIGAR of score <= MAX_SCORE has at most plen + MAX_SCORE / e (= tlen + MAX_SCORE / e) operations, so begin_offset >= min(plen, tlen) -
-            // MAX_SCORE / e: the 16-byte pieces in front of that (and behind plen + tlen) are not written -- 8 of a row's 14 at l = 100 (round 5).
+            // a CIGAR with gaps of total length L has plen + (insertions) = tlen + (deletions) <= max(plen, tlen) + L operations, so begin_offset >=
+            // min(plen, tlen) - L, L <= (score - o) / e: the 16-byte pieces in front of that (and behind plen + tlen) are not written -- 7 of a row's 14
+            // are at l = 100 (round 5).
             char *ops = a.ops + (uint64_t)pair * (2 * RS);
             uint4 *orow = reinterpret_cast<uint4 *>(ops);
             const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);

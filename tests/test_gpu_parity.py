@@ -1695,10 +1695,11 @@ def test_lane_kernels_take_the_launchers_other_penalty_sets(gpu, cost, l, rs, bt
     assert capi.load().aim_kernel_name(C.byref(bigger)) == b"wfa_group_kernel"
 
 
-def test_default_abi_ops_rows_need_no_prefilled_buffer(gpu, sample_bytes, ref_digests):
+def test_default_abi_ops_rows_need_no_prefilled_buffer(gpu, sample_bytes, ref_digests, monkeypatch):
     """the kernels write 'M' only where an operation can be printed (ops[begin_offset, end_offset), host.c:347-349) -- whatever the
     caller's ops buffer held before (here: 0xEE everywhere, through aim_align_device-style reuse of one device set) the reference's file comes out."""
     from aim_amd import engine
+    monkeypatch.setenv("AIM_DEBUG_POISON_OPS", "238")                      # every launch starts from rows of 0xEE
     req, pat, txt = engine.parse_pairs(sample_bytes, 112)
     n = len(req)
     with engine.DeviceSet(1) as s:
