@@ -54,6 +54,16 @@ def _deps(path, seen=None):
     return seen
 
 
+def _toolchain_id():
+    """Resolved compiler path + its --version text: part of the staleness key of the object files."""
+    path = os.path.realpath(HIPCC)
+    try:
+        ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+    except Exception as e:            # (no compiler: the build itself will say so)
+        ver = "unavailable: %r" % (e,)
+    return path + "\n" + ver
+
+
 def units():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -64,7 +74,8 @@ def build_lib(force=False, out=LIB, objdir=None, extra_flags=()):
     os.makedirs(os.path.dirname(out), exist_ok=True)
     flag_stamp = os.path.join(objdir, "flags.txt")
     flags = HIP_FLAGS + list(extra_flags)
-    if not os.path.exists(flag_stamp) or open(flag_stamp).read() != " ".join(flags):
+    stamp = " ".join(flags) + "\n" + _toolchain_id()      # (objects of another compiler or ROCm version are stale too -- ADVICE r04)
+    if not os.path.exists(flag_stamp) or open(flag_stamp).read() != stamp:
         force = True
     jobs, objs = [], []
     for src in units():
@@ -76,7 +87,8 @@ def build_lib(force=False, out=LIB, objdir=None, extra_flags=()):
         workers = max(1, min(len(jobs), os.cpu_count() or 1))
         with concurrent.futures.ThreadPoolExecutor(workers) as ex:
             list(ex.map(_run, jobs))
-        open(flag_stamp, "w").write(" ".join(flags))
+    if jobs or not os.path.exists(flag_stamp):
+        open(flag_stamp, "w").write(stamp)
     if jobs or _newer(out, objs):
         _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out

@@ -414,7 +414,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         Plan fb;
         memset(&fb, 0, sizeof fb);
         aim::Knobs kq = kn;
-        kq.dpl_seq_lds = 2;   // the to-do pass: every lane loads its own pair's pattern row into registers (the listed pairs are not consecutive: no staged image)
+        kq.dpl_seq_lds = p.read_size <= 124 ? 2 : 0;   // the to-do pass: every lane loads its own pair's pattern row into registers (the listed pairs are not consecutive: no staged image); READ_SIZE 128: from global memory -- never an LDS image (the plan's LDS and the launch agree)
         kq.dpl_no_reg = 0;
         if (!aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds))
             return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
@@ -447,7 +447,7 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         Plan fb;
         memset(&fb, 0, sizeof fb);
         aim::Knobs kq = kn;
-        kq.dpl_seq_lds = 2;
+        kq.dpl_seq_lds = p.read_size <= 124 ? 2 : 0;
         kq.dpl_no_reg = 0;
         if (!aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds))
             return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
@@ -758,7 +758,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         else aim::nw_reg_launch(p, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         aim::Knobs kq = kn;
-        kq.dpl_seq_lds = 2;
+        kq.dpl_seq_lds = p.read_size <= 124 ? 2 : 0;
         kq.dpl_no_reg = 0;
         ka.dbg_lds_bytes = (uint32_t)pl.fb_lds;
         aim::dp_lane_launch(p, kq, pl.fb_grid, pl.fb_lds, false, ka, stream);

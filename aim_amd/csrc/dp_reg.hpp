@@ -41,13 +41,19 @@
 namespace aim {
 
 constexpr int kRegWin = 16;        // registers (32 indices) in which a row may start
+constexpr int kNwTail = 8;         // tail cells of the LAST row a score-only pair may have beyond (tlen, W): plen <= tlen + 1 + kNwTail (round 5)
 constexpr int kRegInf = 16000;     // the value left of a row's start
 
 // Shapes: NPK registers per row = 2 * NPK indices > READ_SIZE
 // Registers of a row. The launchers' READ_SIZE rule (run-nw-pim-wram.py: ceil((l + l*e + 7) / 8) * 8) leaves pattern and text at READ_SIZE - 7 characters at
 // most: a row of 2 * NPK >= READ_SIZE - 6 indices holds every pair they produce; a longer pattern or text (legal: up to READ_SIZE) goes to the to-do list.
 // (Until late in round 4: 42 / 58 / 66 = READ_SIZE + 4 indices, 7-10 % of them never used.)
-inline int nw_reg_npk(int read_size, bool bt = false) { return read_size <= 80 ? 38 : (read_size <= 112 ? 54 : (read_size <= 128 && !bt ? 62 : 0)); }   // (62: score-only -- the direction table has 8 dwords per row)
+// (Round 5, ADVICE r04: classes for READ_SIZE <= 48 / 64 / 96 too -- a row may start in its first 32 indices only, so at READ_SIZE 48 or 88 no pair qualified for the
+// class above it and the whole batch went through the to-do list.)
+__host__ __device__ inline int nw_reg_npk(int read_size, bool bt = false)
+{
+    return read_size <= 48 ? 22 : read_size <= 64 ? 30 : read_size <= 80 ? 38 : read_size <= 96 ? 46 : read_size <= 112 ? 54 : (read_size <= 128 && !bt ? 62 : 0);   // (62: score-only -- the direction table has 8 dwords per row)
+}
 
 inline bool nw_reg_supported(const aim_params_t &p)
 {
@@ -60,18 +66,19 @@ inline bool nw_reg_supported(const aim_params_t &p)
 __host__ __device__ inline size_t nw_reg_lds_bytes(const aim_params_t &p)   // text image / ops staging + the pair queue (512 B)
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    const int npk = p.read_size <= 80 ? 38 : (p.read_size <= 112 ? 54 : 62);
+    const int npk = nw_reg_npk(p.read_size, bt);
     const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave;
     return ((bt && o > t) ? o : t) + 512;
 }
 
 template <int NPK, bool BT>
-__global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void nw_reg_kernel(KArgs a)   // (two wavefronts per SIMD: vector + accumulation registers <= 256)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
     constexpr int RSK = 2 * NPK;          // indices of a row of registers
     constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
+    constexpr bool TAILS = !BT;               // last-row tail cells in this kernel (score-only)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
@@ -108,9 +115,12 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             aim_request_t rc;
             rc.pattern_len = rc.text_len = 0; rc.padding = 0; rc.idx = 0;
             if (act) rc = load_request(a, cand);
-            // this kernel's pairs: no tail cells (plen <= tlen + 1) and a row start inside the window
-            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 && rc.pattern_len >= RSK - 2 * kRegWin &&
-                              rc.pattern_len <= RSK - 1 && rc.text_len <= 4 * NWD;   // ... and both sequences inside the row / the staged text image
+            // this kernel's pairs: plen <= tlen + 1, or (score-only, round 5) at most kNwTail tail cells beyond (h, W) -- those of the rows before the last are
+            // overwritten by the next row before anything else reads them, so the rows run over the columns 0 .. W like a plen == tlen + 1 pair's and the LAST
+            // row's tail cells are computed once, when that row is done (tail_cells below) -- and a row start inside the window
+            const int cpe = rc.pattern_len > rc.text_len ? rc.text_len + 1 : rc.pattern_len;   // columns the rows run over
+            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 + ((TAILS && !(a.dbg_flags & 2u)) ? kNwTail : 0) && cpe >= RSK - 2 * kRegWin &&
+                              cpe <= RSK - 1 && rc.pattern_len <= rs && rc.text_len <= 4 * NWD;   // ... and both sequences inside the row / the staged text image
             const unsigned long long rest = __ballot(act && !take), mask_below = (1ull << lane) - 1ull;
             if (rest) {   // everything else: the to-do list of nw_lane_kernel (one atomic per wavefront)
                 uint32_t base = 0;
@@ -134,8 +144,10 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
         if (mine) rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const int W = tlen + 1;
-        const bool isW = mine && plen == W;                  // the row's last cell is the next row's boundary cell
-        const int s0 = mine ? RSK - 1 - plen : 0;             // index of column 0 (0 .. 31)
+        const bool isW = mine && plen >= W;                  // cell (h, W) is the next row's boundary cell
+        const int pe = plen >= W ? W : plen;                 // the rows' last column
+        const int ntail = mine ? plen - pe : 0;              // tail cells of the last row (score-only)
+        const int s0 = mine ? RSK - 1 - pe : 0;              // index of column 0 (0 .. 31)
         const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);   // (idle lanes: pair 0's rows, read and ignored)
         const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
         // the text row goes to LDS, transposed [dword][lane] (one conflict-free ds_read per ROW of the table), the pattern row into
@@ -248,12 +260,55 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
                 oldprev = oldj;
 
             }
-            if (h == tlen) score = (int)(int16_t)(dst[NPK - 1] >> 16) + GAP_I * tlen + GAP_D * plen;   // R_tlen[plen], un-tilted
+            if (h == tlen) score = (int)(int16_t)(dst[NPK - 1] >> 16) + GAP_I * tlen + GAP_D * pe;   // R_tlen[pe], un-tilted
             if (BT && mine && h <= tlen) {                     // the row's direction bits: two 16-byte stores per lane
                 typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
                 aim_u32x4 w1 = {dirw[4], dirw[5], dirw[6], dirw[7]};
                 if (NPK <= 32) { aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]}; __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0))); }
                 __builtin_nontemporal_store(w1, reinterpret_cast<aim_u32x4 *>(&TBW(h, 4)));
+            }
+        };
+        // plen >= tlen + 2 (score-only): the last row's tail cells v = W + c, c = 1 .. ntail, right after that row (nw.c:137-145 with the flat indices resolved: the
+        // cell on the left is the previous tail cell, the cell "above" is cell (tlen, c) of this same row, the diagonal one cell (tlen, c - 1)); `row` is row tlen
+        // of the lanes concerned. Fields of the row at per-lane indices: binary select trees over VALUES (a chain of `idx == j ?` selects would be taken for a
+        // dynamic index and put the row into scratch).
+        auto tail_cells = [&](int h, uint32_t (&row)[NPK]) __attribute__((always_inline)) {
+            const bool me = TAILS && mine && ntail > 0 && tlen == h;
+            if (!TAILS || __ballot(me) == 0ull) return;        // wave-uniform
+            // the ten fields s0 .. s0 + 9 of the row (columns 0 .. 9), at STATIC positions: the row's registers shifted down by s0 >> 1 registers in four
+            // mask-select stages (v_bfi under v_bfe_i32 masks: compare + v_cndmask pairs cost a scalar hazard each, and a chain of `idx == j ?` selects would be
+            // taken for a dynamic index), then by one field where s0 is odd
+            const int q = s0 >> 1;
+            auto sel = [](uint32_t m, uint32_t x, uint32_t y) __attribute__((always_inline)) { return (x & m) | (y & ~m); };   // m ? x : y, bitwise
+            uint32_t m8 = (uint32_t)__builtin_amdgcn_sbfe(q, 3, 1), m4 = (uint32_t)__builtin_amdgcn_sbfe(q, 2, 1), m2 = (uint32_t)__builtin_amdgcn_sbfe(q, 1, 1),
+                     m1 = (uint32_t)__builtin_amdgcn_sbfe(q, 0, 1), mo = (uint32_t)__builtin_amdgcn_sbfe(s0, 0, 1);
+            opaque(m8); opaque(m4); opaque(m2); opaque(m1); opaque(mo);
+            uint32_t ta[14], tb[10], tc[8], tw[7], w[6];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) ta[k] = sel(m8, (k + 8 < NPK) ? row[k + 8] : 0u, (k < NPK) ? row[k] : 0u);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tb[k] = sel(m4, ta[k + 4], ta[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tc[k] = sel(m2, tb[k + 2], tb[k]);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) tw[k] = sel(m1, tc[k + 1], tc[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w[k] = sel(mo, __builtin_amdgcn_alignbit(tw[k + 1], tw[k], 16), tw[k]);   // field c of the row's columns: half c & 1 of w[c >> 1]
+            if (me) {
+                const unsigned char *pb8 = reinterpret_cast<const unsigned char *>(gP), *tb8 = reinterpret_cast<const unsigned char *>(gT);
+                const int tch = (int)tb8[tlen - 1];
+                int left = score;                                  // R(tlen, W), un-tilted above
+                int prev_up = (int)(int16_t)(w[0] & 0xffffu) + GAP_I * tlen;   // R(tlen, 0) = B(tlen): the diagonal of the first tail cell
+#pragma unroll
+                for (int c = 1; c <= kNwTail; ++c) {
+                    const int tf = (int)(int16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffffu));
+                    const int up = tf + GAP_I * tlen + GAP_D * c;  // R(tlen, c)
+                    const int pch = c <= ntail ? (int)pb8[W + c - 1] : 0;
+                    const int cell = min(prev_up + ((pch == tch) ? 0 : MISMATCH), min(up + GAP_I, left + GAP_D));
+                    prev_up = up;
+                    left = c <= ntail ? cell : left;
+                }
+                score = left;
             }
         };
         auto rows = [&](auto j0_tag) __attribute__((always_inline)) {
@@ -262,7 +317,9 @@ __global__ __launch_bounds__(64) void nw_reg_kernel(KArgs a)
             } else {
                 for (int h = 1; h <= hmax; h += 2) {
                     do_row(j0_tag, h, Mp, Mq);
+                    tail_cells(h, Mq);
                     do_row(j0_tag, h + 1, Mq, Mp);             // (a row past hmax computes on and is read by nobody)
+                    tail_cells(h + 1, Mp);
                 }
             }
         };
@@ -731,7 +788,10 @@ void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs
         if (bt) hipLaunchKernelGGL((nw_reg_kernel<N, true>), dim3(grid), dim3(kWave), lds, s, ka);             \
         else hipLaunchKernelGGL((nw_reg_kernel<N, false>), dim3(grid), dim3(kWave), lds, s, ka);               \
     } while (0)
-    if (npk == 38) AIM_NWREG(38);
+    if (npk == 22) AIM_NWREG(22);
+    else if (npk == 30) AIM_NWREG(30);
+    else if (npk == 38) AIM_NWREG(38);
+    else if (npk == 46) AIM_NWREG(46);
     else if (npk == 54) AIM_NWREG(54);
     else if (npk == 62 && !bt) hipLaunchKernelGGL((nw_reg_kernel<62, false>), dim3(grid), dim3(kWave), lds, s, ka);
 #undef AIM_NWREG

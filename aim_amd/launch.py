@@ -43,6 +43,7 @@ def _parser(algo):
     ap.add_argument("-d", "--nr_of_dpus", type=int, help="logical NR_DPUs of the reference partition rule (default=1)")
     ap.add_argument("--gpus", type=int, default=1, help="MI355X devices to shard over")
     ap.add_argument("--mram", action="store_true", help="SWG only: int16 cells like SWG/DPU-MRAM")
+    ap.add_argument("--slots", type=int, default=0, help="batches in flight per device (host --slots; default: the host's 2, genasm 4): each slot pins its own host and device buffers")
     ap.add_argument("--dry-run", action="store_true", help="print the host command and exit")
     return ap
 
@@ -73,7 +74,7 @@ def parse(algo, argv):
     return dict(algo=algo, input=args["input"], output=args["output"], n=args["number_reads"], match=m, mismatch=x,
                 gap_o=g, gap_e=a, max_score=int(max_score), read_size=int(read_size), backtrace=args["backtrace"],
                 reduce=bool(args.get("reduced")), nr_dpus=args["nr_of_dpus"] or 1, gpus=args["gpus"],
-                swg_w16=args["mram"], dry_run=args["dry_run"])
+                swg_w16=args["mram"], dry_run=args["dry_run"], slots=args.get("slots") or 0)
 
 
 def flag_line(cfg):
@@ -105,10 +106,13 @@ def host_command(cfg):
         cmd.append("--reduce")
     if cfg["swg_w16"]:
         cmd.append("--swg-w16")
-    if cfg["algo"] == "genasm":
-        # four batches in flight per device: a pair that loses the diagonal keeps one wavefront busy long after its batch is done, and the
-        # next batches run under that tail (16 384 pairs of 100 kb through the CLI: 1 / 2 / 4 slots = 1.3 / 2.1 / 4.3e5 pairs/s)
-        cmd += ["--slots", "4"]
+    # batches in flight per device (host --slots). GenASM defaults to four: a pair that loses the diagonal keeps one wavefront busy long after its batch is
+    # done and the next batches run under that tail (16 384 pairs of 100 kb through the CLI: 1 / 2 / 4 slots = 1.3 / 2.1 / 4.3e5 pairs/s).
+    # Every slot carries its own pinned host AND device buffers (both sequence arrays + results / CIGAR): four slots are four times the pinned memory
+    # per device, times --gpus -- `--slots N` lowers it on a small host.
+    slots = cfg.get("slots") or (4 if cfg["algo"] == "genasm" else 0)
+    if slots:
+        cmd += ["--slots", str(slots)]
     return cmd
 
 

@@ -57,7 +57,14 @@ def gather_cigars(cig, runs, dist=None, force=False):
             dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1))
         return out
 
-    counts = all_gather(torch.tensor([runs.numel()], dtype=torch.int64, device=runs.device)).view(-1).tolist()
+    # run counts AND header counts first: the header gather below wants equal sizes on every rank (a shorter last shard would hang the collective or
+    # shift offsets silently -- ADVICE r04), and the rebased run offsets are int32
+    both = all_gather(torch.tensor([runs.numel(), cig.shape[0]], dtype=torch.int64, device=runs.device)).view(world, 2).tolist()
+    counts = [int(c[0]) for c in both]
+    if any(int(c[1]) != int(cig.shape[0]) for c in both):
+        raise ValueError("gather_cigars: every rank must pass the same number of CIGAR headers (got %s); pad the last shard" % [int(c[1]) for c in both])
+    if sum(counts) >= 2 ** 31:
+        raise OverflowError("gather_cigars: %d runs over all ranks do not fit the int32 run_offset" % sum(counts))
     longest = max(max(counts), 1)
     padded = torch.zeros(longest, dtype=runs.dtype, device=runs.device)
     padded[: runs.numel()] = runs

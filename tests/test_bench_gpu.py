@@ -58,15 +58,17 @@ def test_bench_two_ranks_control_flow(built):
 def test_bench_other_baseline_configs_run_through_the_same_harness(built):
     """`bench.py --config cfg3 | cfg4 | cfg5`: the other BASELINE configurations through the same static split / timing / one-line
     contract, each priced against the roof that bounds its kernel; cfg3 also under two ranks."""
-    for cfg, pairs, bound in (("cfg3", "4096", "valu"), ("cfg4", "16", "valu"), ("cfg5", "64", "valu")):
+    for cfg, pairs, bound in (("cfg3", "4096", "valu"), ("cfg4", "16", "valu"), ("cfg5", "64", "valu"), ("cfg5", "256", "valu")):
+        extra = ["--batches", "4"] if pairs == "256" else []                 # cfg5's own form: four batches in flight on four streams
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--pairs", pairs, "--steps", "2", "--warmup", "1",
-                            "--length", {"cfg3": "1000", "cfg4": "2000", "cfg5": "5000"}[cfg]], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                            "--length", {"cfg3": "1000", "cfg4": "2000", "cfg5": "5000"}[cfg]] + extra, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert r.returncode == 0, (cfg, r.stderr[-2000:])
         d = _last_json(r.stdout)
         assert d["verified_vs_oracle"] is True and d["value"] > 0 and d["roofline"]["bound"] == bound and cfg in d["config"]["workload"]
         assert d["cpu_baseline"]["value"] > 0
         if cfg == "cfg5":    # round 4: lanes switched on next to SIMD time, and whether the batch holds a pair that lost the diagonal
             assert d["tail"]["pairs_that_lost_the_diagonal"] == 0 and d["tail"]["median_score"] > 0
+            assert d["tail"]["batches"] == (4 if extra else 1) and (d["single_batch"] is not None) == bool(extra)
             assert d["roofline"]["useful_lane_frac"] is None or 0 < d["roofline"]["useful_lane_frac"] <= 1
         else:
             assert d["tail"] is None

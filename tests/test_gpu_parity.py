@@ -1542,7 +1542,8 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
                 continue
             assert s.plan_describe(0).startswith("nw_reg_kernel"), s.plan_describe(0)
             fb = s.fallback_pairs(0)
-            tails = int((req["pattern_len"] > req["text_len"] + 1).sum())
+            keep = 1 if bt else 9                                            # round 5, score-only: up to 8 tail cells in the last row stay in the kernel
+            tails = int((req["pattern_len"] > req["text_len"] + keep).sum())
             assert tails <= fb <= tails + n // 40, (fb, tails)               # the to-do list: tail pairs + the short outliers
     monkeypatch.setenv("AIM_NO_NW_REG", "1")
     params = engine.make_params("nw", ms, rs, backtrace=bt)
