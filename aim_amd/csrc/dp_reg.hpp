@@ -41,7 +41,7 @@
 namespace aim {
 
 constexpr int kRegWin = 16;        // registers (32 indices) in which a row may start
-constexpr int kNwTail = 8;         // tail cells of the LAST row a score-only pair may have beyond (tlen, W): plen <= tlen + 1 + kNwTail (round 5)
+constexpr int kNwTail = 8;         // tail cells of the LAST row a pair may have beyond (tlen, W): plen <= tlen + 1 + kNwTail (round 5)
 constexpr int kRegInf = 16000;     // the value left of a row's start
 
 // Shapes: NPK registers per row = 2 * NPK indices > READ_SIZE
@@ -52,7 +52,8 @@ constexpr int kRegInf = 16000;     // the value left of a row's start
 // class above it and the whole batch went through the to-do list.)
 __host__ __device__ inline int nw_reg_npk(int read_size, bool bt = false)
 {
-    return read_size <= 48 ? 22 : read_size <= 64 ? 30 : read_size <= 80 ? 38 : read_size <= 96 ? 46 : read_size <= 112 ? 54 : (read_size <= 128 && !bt ? 62 : 0);   // (62: score-only -- the direction table has 8 dwords per row)
+    (void)bt;
+    return read_size <= 48 ? 22 : read_size <= 64 ? 30 : read_size <= 80 ? 38 : read_size <= 96 ? 46 : read_size <= 112 ? 54 : (read_size <= 128 ? 62 : 0);   // (62 registers = the 8 dwords of direction bits a row has)
 }
 
 inline bool nw_reg_supported(const aim_params_t &p)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     debug_poison_lds(a, smem);
     constexpr int RSK = 2 * NPK;          // indices of a row of registers
     constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
-    constexpr bool TAILS = !BT;               // last-row tail cells in this kernel (score-only)
+    constexpr bool TAILS = true;              // last-row tail cells in this kernel (with CIGAR too: their direction bits stay in a register, see the walk)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     const int GAP_D = a.p.gap_d, GAP_I = a.p.gap_i, MISMATCH = a.p.mismatch;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             opaque(inj[j]);
         }
         int score = 0;
+        uint32_t tailbits = 0u;                                // BACKTRACE: the direction bits of the last row's tail cells, two per cell (cell c at bits 2c, 2c + 1)
         const int hmax = -wave_min_i32(mine ? -tlen : 0);
         // one row: `src` (row h - 1) -> `dst` (row h). The row loop alternates between two register arrays: updated in place, the old value
         // of register j - 1 (the next cell's diagonal input) had to be copied aside before every overwrite -- one v_mov per register and row.
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const int tf = (int)(int16_t)((c & 1) ? (w[c >> 1] >> 16) : (w[c >> 1] & 0xffffu));
                     const int up = tf + GAP_I * tlen + GAP_D * c;  // R(tlen, c)
                     const int pch = c <= ntail ? (int)pb8[W + c - 1] : 0;
-                    const int cell = min(prev_up + ((pch == tch) ? 0 : MISMATCH), min(up + GAP_I, left + GAP_D));
+                    const int mm = prev_up + ((pch == tch) ? 0 : MISMATCH), ins = up + GAP_I, del = left + GAP_D;
+                    const int cell = min(mm, min(ins, del));
+                    if (BT && c <= ntail) tailbits |= ((min(mm, ins) < del ? 1u : 0u) | (mm < ins ? 2u : 0u)) << (2 * c);   // "not D", "not I": the tests of nw_traceback, in its order
                     prev_up = up;
                     left = c <= ntail ? cell : left;
                 }
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         };
         auto rows = [&](auto j0_tag) __attribute__((always_inline)) {
             if (BT) {   // (with the direction bits the two-array form needs more than 256 VGPRs = one wavefront per SIMD: in place, one copy per register and row)
-                for (int h = 1; h <= hmax; ++h) do_row(j0_tag, h, Mp, Mp);
+                for (int h = 1; h <= hmax; ++h) { do_row(j0_tag, h, Mp, Mp); tail_cells(h, Mp); }
             } else {
                 for (int h = 1; h <= hmax; h += 2) {
                     do_row(j0_tag, h, Mp, Mq);
@@ -353,12 +357,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
             while (h > 0 && v > 0) {
-                const int i = v + s0, j = i >> 1;
-                const uint32_t word = TBW(h, j >> 3);
-                const uint32_t code = (word >> (16 * (i & 1) + 2 * (j & 7))) & 3u;
+                // the cell the reference reads at flat index W h + v. v <= W: cell (h, v) of the table. v > W (a pair with tail cells; the walk got here
+                // from the last row's tail): the flat index lies in row h + 1 -- the last row's tail cell v - W (h == tlen: its bits are in `tailbits`,
+                // its characters its own), or cell (h + 1, v - W) of the table, which overwrote the tail cell of row h (that cell's characters)
+                uint32_t code;
+                int pi = v - 1, ti = h - 1;
+                if (v > W && h == tlen) code = (tailbits >> (2 * (v - W))) & 3u;
+                else {
+                    const int hh = v > W ? h + 1 : h, vv = v > W ? v - W : v;
+                    if (v > W) { pi = vv - 1; ti = hh - 1; }
+                    const int i = vv + s0, j = i >> 1;
+                    const uint32_t word = TBW(hh, j >> 3);
+                    code = (word >> (16 * (i & 1) + 2 * (j & 7))) & 3u;
+                }
                 if (!(code & 1u)) { OPS(sentinel) = 'D'; --sentinel; --v; }
                 else if (!(code & 2u)) { OPS(sentinel) = 'I'; --sentinel; --h; }
-                else { OPS(sentinel) = (pb[v - 1] != tbytes[h - 1]) ? 'X' : 'M'; --sentinel; --h; --v; }
+                else { OPS(sentinel) = (pb[pi] != tbytes[ti]) ? 'X' : 'M'; --sentinel; --h; --v; }
             }
             while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
             while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
@@ -420,7 +434,7 @@ constexpr int kSwgWin = 16;        // registers (32 indices) in which a row may 
 // Registers of a row: the launchers' READ_SIZE rule (run-swg-pim-wram.py: ceil((l + l*e + 7) / 8) * 8) leaves pattern and text at READ_SIZE - 7 characters at most, and
 // column v sits at index v - 1: 2 * NPK >= READ_SIZE - 7 indices hold every pair they produce (a longer pattern, legal up to READ_SIZE, goes to the to-do list).
 inline int swg_reg_npk(int read_size) { return read_size <= 48 ? 21 : read_size <= 64 ? 29 : read_size <= 80 ? 37 : read_size <= 96 ? 45 : read_size <= 112 ? 53 : read_size <= 128 ? 61 : 0; }
-constexpr int kSwgTail = 8;        // tail cells of the last row a pair may have beyond (tlen, W): plen <= tlen + 1 + kSwgTail (score-only)
+constexpr int kSwgTail = 8;        // tail cells of the last row a pair may have beyond (tlen, W): plen <= tlen + 1 + kSwgTail
 inline int swg_reg_cell_bytes(const aim_params_t &p) { return (p.flags & AIM_FLAG_SWG_W16) ? 2 : (p.max_score < 127 ? 1 : 2); }   // = swg_cell_bytes (dp_lane.hpp)
 
 inline bool swg_reg_supported(const aim_params_t &p)
@@ -641,7 +655,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             sreg = t[0];
         }
         int sc16 = (int)(int16_t)(lhi ? (sreg >> 16) : (sreg & 0xffffu));     // M[tlen][pe] * SC
-        if (ISW && !BT) {
+        uint32_t tailbits = 0u;                               // BACKTRACE: the four direction bits of the last row's tail cells (cell c at bits 4c .. 4c + 3)
+        if (ISW) {
             // plen >= tlen + 2: the LAST row's tail cells v = W + c, c = 1 .. plen - W, one after the other (swg.c:151-162 with the flat indices resolved: the cell
             // on the left is the previous tail cell, the cell "above" is cell (tlen, c) of this same row, the diagonal one cell (tlen, c - 1))
             const int ntail = lw ? plen - pe : 0;
@@ -665,9 +680,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     if (c <= ntail) {
                         const int mU = pick16(m0, m1, m2, m3, c - 1), iU = pick16(i0, i1, i2, i3, c - 1);
                         const int dg = c == 1 ? (int)(int16_t)(MbOldH >> 16) : pick16(m0, m1, m2, m3, c - 2);   // (c == 1: the last row's boundary cell)
-                        const int cD = min((int)(int16_t)(upM + OEs), (int)(int16_t)(upD + Es));
-                        const int cI = min((int)(int16_t)(mU + OEs), (int)(int16_t)(iU + Es));
-                        const int cM = min((int)(int16_t)(dg + (((int)pb8[pe + c - 1] == tch) ? 0 : Xs)), min(cI, cD));
+                        const int dn = (int)(int16_t)(upM + OEs), de = (int)(int16_t)(upD + Es), in_ = (int)(int16_t)(mU + OEs), ie = (int)(int16_t)(iU + Es);
+                        const int cD = min(dn, de), cI = min(in_, ie);
+                        const int mm = (int)(int16_t)(dg + (((int)pb8[pe + c - 1] == tch) ? 0 : Xs));
+                        const int cM = min(mm, min(cI, cD));
+                        if (BT) tailbits |= ((min(mm, cI) < cD ? 1u : 0u) | (mm < cI ? 2u : 0u) | (de < dn ? 4u : 0u) | (ie < in_ ? 8u : 0u)) << (4 * (c & 7));   // "M != D", "M != I", "D extended", "I extended" (c = 8 -> nibble 0: cell 0 is no tail cell)
                         acc |= (uint32_t)cM & 0x8000u;
                         upM = cM; upD = cD;
                         sc16 = cM;
@@ -700,15 +717,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 int sentinel = end_offset - 1;
                 int h = tlen, v = plen;
                 int layer = 0;                                // 0: M, 1: I, 2: D
+                const int Wc = tlen + 1;
                 while (h > 0 && v > 0) {
-                    const int i = v - 1, j = i >> 1;
-                    const uint32_t word = TBW(h, j >> 2);
-                    const uint32_t bits = word >> (8 * (i & 1) + (j & 3));   // bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended
+                    // the cell the reference reads at flat index W h + v. v <= W: cell (h, v) of the table. v > W (a pair with tail cells; the walk got here
+                    // from the last row's tail): the flat index lies in row h + 1 -- the last row's tail cell v - W (h == tlen: its bits are in `tailbits`,
+                    // its characters its own), or cell (h + 1, v - W) of the table, which overwrote the tail cell of row h (that cell's characters)
+                    uint32_t bits;                            // bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended
+                    int pi = v - 1, ti = h - 1;
+                    if (v > Wc && h == tlen) {
+                        const uint32_t nb = tailbits >> (4 * ((v - Wc) & 7));
+                        bits = (nb & 1u) | ((nb & 2u) << 15) | ((nb & 4u) << 2) | ((nb & 8u) << 17);
+                    } else {
+                        const int hh = v > Wc ? h + 1 : h, vv = v > Wc ? v - Wc : v;
+                        if (v > Wc) { pi = vv - 1; ti = hh - 1; }
+                        const int i = vv - 1, j = i >> 1;
+                        bits = TBW(hh, j >> 2) >> (8 * (i & 1) + (j & 3));
+                    }
                     if (layer == 2) { OPS(sentinel) = 'D'; --sentinel; if (!(bits & 0x10u)) layer = 0; --v; }
                     else if (layer == 1) { OPS(sentinel) = 'I'; --sentinel; if (!(bits & 0x100000u)) layer = 0; --h; }
                     else if (!(bits & 1u)) layer = 2;
                     else if (!(bits & 0x10000u)) layer = 1;
-                    else { OPS(sentinel) = (pb[v - 1] != tbytes[h - 1]) ? 'X' : 'M'; --sentinel; --h; --v; }
+                    else { OPS(sentinel) = (pb[pi] != tbytes[ti]) ? 'X' : 'M'; --sentinel; --h; --v; }
                 }
                 while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
                 while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
@@ -747,7 +776,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // this kernel's pairs: at most kSwgTail tail cells in the last row (with CIGAR: none), the rows' end inside the window, both sequences inside the
             // row / the staged text image
             const int cpe = rc.pattern_len > rc.text_len ? rc.text_len + 1 : rc.pattern_len;
-            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 + (BT ? 0 : kSwgTail) && cpe >= RSK - 2 * kSwgWin + 1 &&
+            const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 + kSwgTail && cpe >= RSK - 2 * kSwgWin + 1 &&
                               rc.pattern_len <= RSK && rc.text_len <= 4 * NWD && rc.text_len <= rs;
             const bool w = take && rc.pattern_len > rc.text_len;
             const unsigned long long rest = __ballot(act && !take);
@@ -793,7 +822,7 @@ void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs
     else if (npk == 38) AIM_NWREG(38);
     else if (npk == 46) AIM_NWREG(46);
     else if (npk == 54) AIM_NWREG(54);
-    else if (npk == 62 && !bt) hipLaunchKernelGGL((nw_reg_kernel<62, false>), dim3(grid), dim3(kWave), lds, s, ka);
+    else if (npk == 62) AIM_NWREG(62);
 #undef AIM_NWREG
 }
 #else

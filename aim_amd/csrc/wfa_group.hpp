@@ -798,7 +798,7 @@ inline bool wfa_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs 
     if (rows >= 16 && (rows & (rows - 1)) != 0) {   // no power of two: only the G = 16 kernels address such rows
         Knobs quiet = kn;
         quiet.plan_debug = 0;
-        if (!wfa_group_plan_rows(p, n_pairs, quiet, packed, rows, c, G, grid, lds, hist_pair_bytes) || *G != 16 || c->wmagic == 0) rows = -1;
+        if (!wfa_group_plan_rows(p, n_pairs, quiet, packed, rows, c, G, grid, lds, hist_pair_bytes) || (*G != 16 && !(*G == 8 && kn.group_g == 8)) || c->wmagic == 0) rows = -1;
     }
     return wfa_group_plan_rows(p, n_pairs, kn, packed, rows, c, G, grid, lds, hist_pair_bytes);
 }
@@ -833,7 +833,12 @@ void wfa_group_launch(const aim_params_t &p, int G, const GroupCfg &c, uint32_t 
         else if (bt) hipLaunchKernelGGL((wfa_group_kernel<GG, false, true>), dim3(grid), dim3(kWave), lds, s, ka, c);   \
         else hipLaunchKernelGGL((wfa_group_kernel<GG, false, false>), dim3(grid), dim3(kWave), lds, s, ka, c);          \
     } while (0)
-    if (c.wmagic) {   // rows that are no power of two (the planner admits them at G = 16 with the reduction only)
+    if (c.wmagic) {   // rows that are no power of two (the planner admits them at G = 16 with the reduction only; G = 8 when forced: VERDICT r04 item 4a's experiment)
+        if (G == 8) {
+            if (bt) hipLaunchKernelGGL((wfa_group_kernel<8, true, true, true>), dim3(grid), dim3(kWave), lds, s, ka, c);
+            else hipLaunchKernelGGL((wfa_group_kernel<8, true, false, true>), dim3(grid), dim3(kWave), lds, s, ka, c);
+            return;
+        }
         if (bt) hipLaunchKernelGGL((wfa_group_kernel<16, true, true, true>), dim3(grid), dim3(kWave), lds, s, ka, c);
         else hipLaunchKernelGGL((wfa_group_kernel<16, true, false, true>), dim3(grid), dim3(kWave), lds, s, ka, c);
         return;

@@ -92,7 +92,7 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 100, 1064, backtrace=True))) == b"dp_wave_kernel"      # int8 cells (MAX_SCORE < 127): row-scan kernel's literal path
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 400, 20000))) == b"dp_wave_kernel"                      # beyond 16 384 columns
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_reg_kernel"                           # round 4: rows in registers up to READ_SIZE 128 (112 with CIGAR)
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 120, backtrace=True))) == b"nw_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 120, backtrace=True))) == b"nw_reg_kernel"          # round 5: READ_SIZE 120 / 128 with CIGAR too (l = 100, e = 10 %)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 136))) == b"nw_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_reg_kernel"                          # round 5: M and I rows in registers up to READ_SIZE 128
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 112, backtrace=True))) == b"swg_reg_kernel"       # (int16 cells too)

@@ -1537,12 +1537,12 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
         with engine.DeviceSet(1) as s:
             s.configure(params, n)
             s.push(0, req, pat, txt); s.launch(); s.pull(0)
-            if rs > 128 or (rs > 112 and bt):                                # (READ_SIZE 120 with CIGAR: beyond the shapes the register kernel is built for)
+            if rs > 128:
                 assert s.plan_describe(0).startswith("nw_lane_kernel"), s.plan_describe(0)
                 continue
             assert s.plan_describe(0).startswith("nw_reg_kernel"), s.plan_describe(0)
             fb = s.fallback_pairs(0)
-            keep = 1 if bt else 9                                            # round 5, score-only: up to 8 tail cells in the last row stay in the kernel
+            keep = 9                                                         # round 5: up to 8 tail cells in the last row stay in the kernel (with CIGAR: their direction bits in a register)
             tails = int((req["pattern_len"] > req["text_len"] + keep).sum())
             assert tails <= fb <= tails + n // 40, (fb, tails)               # the to-do list: tail pairs + the short outliers
     monkeypatch.setenv("AIM_NO_NW_REG", "1")
@@ -1622,7 +1622,7 @@ def test_swg_rows_in_registers_kernel(gpu, monkeypatch, l, err, bt):
             s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
             assert s.plan_describe(0).startswith("swg_reg_kernel"), s.plan_describe(0)
             fb = s.fallback_pairs(0)
-            tails = int((req["pattern_len"] > req["text_len"] + (1 if bt else 9)).sum())   # with CIGAR: plen >= tlen + 2; score-only: more than 8 tail cells in the last row
+            tails = int((req["pattern_len"] > req["text_len"] + 9).sum())     # more than 8 tail cells in the last row
             assert tails <= fb, (fb, tails)
             if not cost and not kw and err <= 0.05 and l >= 60:
                 assert fb <= tails + n // 20, (fb, tails)                       # default costs: the to-do list is the tail pairs + the outliers + the unrelated pairs

@@ -38,6 +38,7 @@ CONFIGS = {
     "nw_l100_e5_score": dict(algo="nw", l=100, e=0.05, n=1 << 20, kw=dict()),
     "nw_l100_e5_cigar": dict(algo="nw", l=100, e=0.05, n=1 << 20, kw=dict(backtrace=True)),
     "nw_l100_e10_score": dict(algo="nw", l=100, e=0.10, n=1 << 20, kw=dict()),
+    "nw_l100_e10_cigar": dict(algo="nw", l=100, e=0.10, n=1 << 20, kw=dict(backtrace=True)),
     "nw_l70_e2_score": dict(algo="nw", l=70, e=0.02, n=1 << 20, kw=dict()),
     "swg_l100_e1_cigar": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "swg_l100_e1_score": dict(algo="swg", l=100, e=0.01, n=1 << 20, kw=dict()),
