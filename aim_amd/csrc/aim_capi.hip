@@ -1077,7 +1077,7 @@ int aim_set_configure_slots(aim_set_t *set, const aim_params_t *params, uint32_t
         }
         for (auto &s : d.slots) {
             // Debugging aid: AIM_DEBUG_POISON_SCRATCH=<0..255> fills the scratch with that byte. Results must not depend on
-            // it (every scratch byte a launch reads must have been written by that launch); see tools/poison_probe.py. On
+            // it (every scratch byte a launch reads must have been written by that launch). On
             // the slot's own stream and completed here: launches run on non-blocking streams that do not synchronise with
             // the null stream.
             if (d.plan.scratch_total && kn.poison_scratch >= 0) {

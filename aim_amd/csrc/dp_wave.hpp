@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64 * NW) void dp_wave_kernel(KArgs a)
                     // Only cell (h, W) of a row before the last is ever used (it lands on flat[W*(h+1)] = row h+1's boundary);
                     // cells (h, v > W) alias flat positions that row h+1 overwrites before anything reads them, and within
                     // the tail they only feed each other. Walking the whole chain W..plen on every row was dead work that
-                    // set config 4's time: 87.6 ms vs 49.0 ms for the same pairs without tails (tools/cfg4_tail_probe.py).
+                    // set config 4's time: 87.6 ms vs 49.0 ms for the same pairs without tails (round-2 probe that swapped pattern and text; since removed).
                     const int vend = (h == tlen) ? plen : W;
                     for (int v = W; v <= vend; ++v) {
                         int leftM, leftI, diagM;
@@ -607,7 +607,7 @@ inline int dp_wave_nw(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn)
     // Up to 8 blocks per row: just enough wavefronts per pair to put ~4096 wavefronts (4 per SIMD) on the chip, never more
     // than the row has blocks. Fewer wavefronts per pair mean less (at 1: no) cross-wavefront synchronisation and more pairs
     // resident; with few pairs the wavefronts of a pair are the only parallelism there is. Measured, kernel ms at 1 / 2 / 4
-    // wavefronts (tools/dpw_nw_probe.py): READ_SIZE 1064 NW 4096 pairs 4.85 / 5.85 / 10.4, 1024 pairs 2.60 / 2.37 / -, 512 pairs
+    // wavefronts (round-2 probe, since removed: AIM_DPW_NW forces the count): READ_SIZE 1064 NW 4096 pairs 4.85 / 5.85 / 10.4, 1024 pairs 2.60 / 2.37 / -, 512 pairs
     // 2.49 / 2.09 / 2.38; READ_SIZE 2048, 2048 pairs NW 9.66 / 9.46 / 11.2, SWG 17.2 / 15.9 / 17.1; READ_SIZE 3072, 2048 pairs
     // NW 19.1 / 18.8 / 24.0, SWG 38.9 / 34.3 / 37.6 (8 wavefronts 32.8 / 45.6).
     if (nblocks <= 8) {

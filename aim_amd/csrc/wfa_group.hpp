@@ -730,7 +730,7 @@ inline bool wfa_group_plan_rows(const aim_params_t &p, uint32_t n_pairs, const K
         g = 64;
     } else {
         // A G <= 16 plan that LDS holds to fewer than 6 workgroups per CU loses to a wavefront per pair at up to 16
-        // per CU. Measured (tools/group_policy.py, score-only, G64/G16 pairs/s, each plan at its real LDS fit): 3 per CU
+        // per CU. Measured (round 2 probe, since removed; tools/group_policy2.py is its successor; score-only, G64/G16 pairs/s, each plan at its real LDS fit): 3 per CU
         // 1.56x (l=1000 e=5%), 4 per CU 1.55x (l=400 e=10%); 6 per CU 1.07x / 0.91x / 0.79x; 11 per CU 0.57x; 16 per CU
         // 0.48x. 5 per CU is not measured.
         const size_t stage = (g >= AIM_GROUP_DIRECT_G || packed) ? 8 : (size_t)2 * ((((size_t)(kWave / g) * p.read_size + 15) / 16) * 16) + 8;   // G >= 32 packs from global memory

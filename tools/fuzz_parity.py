@@ -174,7 +174,7 @@ def main():
             if err:
                 print(json.dumps(dict(case, ok=False)), flush=True)
                 print("MISMATCH:", err, flush=True)
-                os.makedirs("gpurun_out", exist_ok=True)   # the failing batch, for tools/ga_debug.py
+                os.makedirs("gpurun_out", exist_ok=True)   # the failing batch, for a replay
                 np.savez_compressed("gpurun_out/fuzz_genasm_fail.npz", req=req, pat=pat, txt=txt, rs=rs, bt=int(bt), ga=ga)
                 return 1
             continue

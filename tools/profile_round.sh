@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats + PMC summaries for every BASELINE configuration's kernel (tools/pmc_summary.py: stats pass and PMC
 # passes are separate runs), then the kernel timers of every configuration of tools/bench_configs.py.
 # Results go to profiles/<round-dir>/ AND are mirrored under gpurun_out/ (the only directory gpurun copies back).
-R=${1:-r04}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
+R=${1:-r05}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 tools/pmc_summary.py --out $P/wfa_lane_pmc_summary.json --kernel wfa_lane_kernel --pairs 4194304 --alg-bytes 905968812 --fetch-x2 --io compact \
    --note "Cross-check: 4194304 pairs x (224 B rows + 8 B request) = 973.1 MB read, x 8 B result = 33.6 MB written." \
@@ -12,11 +12,11 @@ python3 tools/pmc_summary.py --out $P/wfa_group_pmc_summary.json --kernel wfa_gr
    --note "cfg3: WFA-adaptive l=1000 e=5% with CIGAR, 65536 pairs; per-lane int16 LDS/HBM traffic: FETCH_SIZE kept raw (uncalibrated width)." \
    -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_group.log 2>&1; tail -1 $O/pmc_group.log
 python3 tools/pmc_summary.py --out $P/dp_strip_pmc_summary.json --kernel dp_strip_kernel --pairs 256 \
-   --note "cfg4: SWG l=10000 e=1% with CIGAR, 256 pairs, column-strip pipeline; table stores are 16 B per lane (WRITE_SIZE exact), mixed-width reads: FETCH_SIZE kept raw." \
+   --note "cfg4: SWG l=10000 e=1% with CIGAR, 256 pairs, column-strip pipeline; round 5: four direction bits per cell (one 16-byte store per lane and row, WRITE_SIZE exact) instead of the int16 M plane." \
    -- python3 tools/bench_configs.py swg_l10000_e1_cigar_n256 > $O/pmc_dps.log 2>&1; tail -1 $O/pmc_dps.log
-python3 tools/pmc_summary.py --out $P/wfa_lane_packed_pmc_summary.json --kernel wfa_lane_packed_kernel --pairs 4194304 --fetch-x2 --alg-bytes 905968812 \
+python3 tools/pmc_summary.py --out $P/wfa_lane_packed_pmc_summary.json --kernel wfa_lane_packed_kernel --pairs 4194304 --fetch-x2 --alg-bytes 335544320 \
    --plan "wfa_lane_packed_kernel n=4194304 (the e2e leg's plan: aim_set_plan_describe of the packed batch; bench.py prints the headline ASCII kernel's plan)" \
-   --note "the drop-in path's kernel on packed batches (bench.py e2e leg, score-only): 4194304 pairs x (2 x 28 B packed rows + 8 B request) read, x 8 B written." \
+   --note "the drop-in path's kernel on packed batches (bench.py e2e leg, score-only): 4194304 pairs x (2 x 28 B packed rows + 8 B request) read, x 8 B written = 80 B of the PACKED wire format per pair: algorithmic bytes here are those (VERDICT r04 weak 12: the ASCII figure over a kernel that reads 2-bit rows gave 1.68 of the roof)." \
    -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_lanepk.log 2>&1; tail -1 $O/pmc_lanepk.log
 python3 tools/pmc_summary.py --out $P/wfa_group_tb_pmc_summary.json --kernel wfa_group_tb_kernel --pairs 65536 \
    --note "cfg3's traceback kernel (one pair per lane over the compact per-pair history regions)." \
@@ -33,6 +33,21 @@ python3 tools/pmc_summary.py --out $P/nw_reg_cigar_pmc_summary.json --kernel nw_
 python3 tools/pmc_summary.py --out $P/wfa_group_long_pmc_summary.json --kernel wfa_group_kernel --pairs 8192 \
    --note "WFA-adaptive l=10000 e=1% (MAX_SCORE 500, READ_SIZE 10112) score-only, 8192 pairs: wfa_group_kernel G=32 since round 4 (wfa_wave_kernel before)." \
    -- python3 tools/bench_configs.py wfa_l10000_e1_score > $O/pmc_grouplong.log 2>&1; tail -1 $O/pmc_grouplong.log
+python3 tools/pmc_summary.py --out $P/swg_reg_pmc_summary.json --kernel swg_reg_kernel --pairs 1048576 \
+   --note "SWG l=100 e=1% score-only, 1 Mi pairs: M and I rows in registers (dp_reg.hpp, round 5; int8 cells as value * 256 in 16-bit fields)." \
+   -- python3 tools/bench_configs.py swg_l100_e1_score > $O/pmc_swgreg.log 2>&1; tail -1 $O/pmc_swgreg.log
+python3 tools/pmc_summary.py --out $P/swg_reg_cigar_pmc_summary.json --kernel swg_reg_kernel --pairs 1048576 \
+   --note "SWG l=100 e=1% with CIGAR, 1 Mi pairs: four direction bits per cell (14 dwords per row and lane, stored as 16)." \
+   -- python3 tools/bench_configs.py swg_l100_e1_cigar > $O/pmc_swgregc.log 2>&1; tail -1 $O/pmc_swgregc.log
+AIM_NO_SWG_REG=1 python3 tools/pmc_summary.py --out $P/swg_lane_pmc_summary.json --kernel swg_lane_kernel --pairs 1048576 \
+   --note "swg_lane_kernel alone (AIM_NO_SWG_REG=1: what round 4 ran; now the to-do pass of swg_reg): SWG l=100 e=1% score-only, 1 Mi pairs." \
+   -- python3 tools/bench_configs.py swg_l100_e1_score > $O/pmc_swglane.log 2>&1; tail -1 $O/pmc_swglane.log
+AIM_NO_NW_REG=1 python3 tools/pmc_summary.py --out $P/nw_lane_pmc_summary.json --kernel nw_lane_kernel --pairs 1048576 \
+   --note "nw_lane_kernel alone (AIM_NO_NW_REG=1): NW l=100 e=1% score-only, 1 Mi pairs." \
+   -- python3 tools/bench_configs.py nw_l100_e1_score > $O/pmc_nwlane.log 2>&1; tail -1 $O/pmc_nwlane.log
+python3 tools/pmc_summary.py --out $P/nw_reg_e5_pmc_summary.json --kernel nw_reg_kernel --pairs 1048576 \
+   --note "NW l=100 e=5% score-only, 1 Mi pairs: the last row's tail cells in the kernel (round 5: no to-do pass)." \
+   -- python3 tools/bench_configs.py nw_l100_e5_score > $O/pmc_nwreg5.log 2>&1; tail -1 $O/pmc_nwreg5.log
 python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
 python3 -c "
 import sys, json
