@@ -229,7 +229,9 @@ def test_round4_plan_shapes(built):
             l = plan(engine.make_params("genasm", 0, rs, backtrace=True), n)
             assert l.startswith("genasm_wave_kernel") and "grid=%d " % grid in l and "lds=4160" in l, l
         assert plan(engine.make_params("nw", 4, 128), 1 << 20).startswith("nw_reg_kernel")
-        assert plan(engine.make_params("nw", 4, 128, backtrace=True), 1 << 20).startswith("nw_lane_kernel")
+        assert plan(engine.make_params("nw", 4, 128, backtrace=True), 1 << 20).startswith("nw_reg_kernel")     # round 5: 62 registers = the 8 dwords of direction bits a row has
+        assert plan(engine.make_params("nw", 4, 136, backtrace=True), 1 << 20).startswith("nw_lane_kernel")
+        assert plan(engine.make_params("nw", 4, 48), 1 << 20).startswith("nw_reg_kernel") and plan(engine.make_params("swg", 4, 88), 1 << 20).startswith("swg_reg_kernel")
         assert plan(engine.make_params("nw", 4, 112, backtrace=True), 1 << 20).startswith("nw_reg_kernel")
         assert plan(engine.make_params("nw", 4, 112, gap=60), 1 << 20).startswith("nw_lane_kernel")     # costs too large for INF = 16 000 to stay out of reach
     finally:
