@@ -768,10 +768,9 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         aim::dp_wave_launch(p, p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_DP_STRIP:
-        if (p.algo == AIM_ALGO_SWG) {   // [slabs | lock words | pool tables of the literal path]: the locks are free at every launch
-            HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.grid * pl.scratch_per_wg, 0, 256, stream));
-            ka.pool_cap = pl.pool_cap;
-        }
+        // [slabs | lock words | pool tables of the literal path]: the locks are free at every launch
+        HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.grid * pl.scratch_per_wg, 0, 256, stream));
+        ka.pool_cap = pl.pool_cap;
         aim::dp_strip_launch(p, pl.strip_k, pl.grid, pl.block, pl.lds, ka, stream);
         break;
     case K_GENASM:

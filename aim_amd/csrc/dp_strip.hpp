@@ -186,7 +186,7 @@ __device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, 
 // Per row and lane NQS dwords (dword q: registers 4q .. 4q + 3; byte b of it: low nibble bit k = register 4q + k's "M != D" (b = 0, 1: low / high half) or
 // "M != I" (b = 2, 3), high nibble: "next D extended" / "I extended"), row h's words at FLW[(h * FS + lane) * NQS]; boundary cells (column 0) in BF[row]:
 // bits 0 - 3 the cell's own four tests (D extended = its OWN), bit 4 "D of column 1 extended".
-template <int K>
+template <int K, bool SWG>
 __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int plen, int tlen, int FS, const uint32_t *FLW, const unsigned char *BF,
                                                       const unsigned char *ldsP, const unsigned char *ldsT, uint32_t *tile, int tile_rows, char *ops, int lane,
                                                       int &begin_offset)
@@ -263,8 +263,10 @@ __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int
             const uint32_t b = BF[R];
             nD = b & 1u; nI = (b >> 1) & 1u; xD = (b >> 2) & 1u; xI = (b >> 3) & 1u;
         }
-        if (layer == 2) { put('D'); if (!xD) layer = 0; --v; if (C > 0) --C; else { --R; C = W - 1; } }
-        else if (layer == 1) { put('I'); if (!xI) layer = 0; --h; --R; }
+        if (!SWG && !nD) layer = 2;                           // NW (nw_traceback, nw.c:67-107: "== left + GAP_D", then "== up + GAP_I", else the diagonal): a gap move is
+        else if (!SWG && !nI) layer = 1;                      // one operation, no layers -- the two gap branches below, taken at once, "extended" never consulted
+        if (layer == 2) { put('D'); if (!SWG || !xD) layer = 0; --v; if (C > 0) --C; else { --R; C = W - 1; } }
+        else if (layer == 1) { put('I'); if (!SWG || !xI) layer = 0; --h; --R; }
         else if (!nD) layer = 2;
         else if (!nI) layer = 1;
         else {   // diagonal move: the cell equals its diagonal + MATCH or + MISMATCH according to the characters IT was computed with -- canonical cell (R, C) was
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
     // small POOL of tables behind the slabs, taken under a lock (strip_pool_acquire): 61 MB instead of 613 MB per resident pair at READ_SIZE 10 112.
     constexpr int NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;       // dwords of direction bits per lane and row (a 12-byte word is stored as 16)
     int16_t *tb = reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
-    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;      // (SWG: re-pointed at a pool table on the literal path)
+    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;      // (the literal path: re-pointed at a pool table; NW: one plane of it)
     const int FS = rs / K + 2;                    // lanes per row that can hold a column
     uint32_t *FLW = reinterpret_cast<uint32_t *>(tb);             // SWG strip path: direction bits
     unsigned char *BF = reinterpret_cast<unsigned char *>(FLW + (size_t)(rs + 3) * FS * NQS);   // ... and the boundary cells' bytes, [row]
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
         const bool literal = !exact_ok || plen > 2 * tlen || (min(plen, W - 1) > nw * kWave * K);
 
         int pool_slot = -1;
-        if (literal && SWG) {   // the three int16 planes of the literal path: a table of the pool (workgroups wait for a free one; holders always finish)
+        if (literal) {   // the int16 planes of the literal path (SWG three, NW one): a table of the pool (workgroups wait for a free one; holders always finish)
             if (tid == 0) {
                 int got = -1;
                 while (got < 0) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             }
             __syncthreads();
             pool_slot = tl[4];
-            TM = pool_tables + (size_t)pool_slot * 3 * plane; TI = TM + plane; TD = TM + 2 * plane;
+            TM = pool_tables + (size_t)pool_slot * (SWG ? 3 : 1) * plane; TI = TM + plane; TD = TM + 2 * plane;
         }
         if (literal) {
             if (tid == 0) { score = dp_literal_fill<SWG, false>(a.p, plen, tlen, gP, gT, TM, TI, TD); tl[3] = score; }
@@ -407,11 +409,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 opaque(vmb);
                 vmask[j] = dps_from(vmb);
             }
-            if (BT && !SWG) {
-                for (int v = tid; v <= Rr; v += NT) TM[7 + v] = (int16_t)(v * GD);
-                for (int h = 1 + tid; h <= tlen; h += NT) TM[(size_t)h * S + 7] = (int16_t)(h * GI);   // row-init boundary cells flat[W*h]
-            }
-            if (BT && SWG) {   // row-init boundary cells {M = I = o + h e, D = MAX_SCORE}: the walk only ever asks whether column 1's D was extended from them
+            if (BT && SWG) {   // row-init boundary cells {M = I = o + h e, D = MAX_SCORE}: the walk only ever asks whether column 1's D was extended from them (NW: nothing)
                 for (int h = 1 + tid; h <= tlen + 1; h += NT) BF[h] = (unsigned char)((O + h * E) + O <= MAXS ? 0 : 16);
             }
             // (the row-init stores above vs the tail owner's store to the same boundary cell below: write after write across
@@ -581,8 +579,8 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                             cI = min(BM + OE, BI + E);
                             cM = min(diag_keep + ((pchW == tch) ? MATCH : MISMATCH), min(cI, cDd));
                         } else {
-                            cI = cDd = 0;
-                            cM = min(diag_keep + ((pchW == tch) ? 0 : MISMATCH), min(BM + GI, upM + GD));
+                            cI = BM + GI; cDd = upM + GD;   // ("ins" and "del" of nw.c:137-143; B(h + 1)'s I / D slots are not read by NW)
+                            cM = min(diag_keep + ((pchW == tch) ? 0 : MISMATCH), min(cI, cDd));
                         }
                         const lds_int_p bs = Bl + 4 * ((h + 1) & (kStripDepth - 1));
                         bs[0] = cM; bs[1] = cI; bs[2] = cDd;
@@ -590,13 +588,13 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         if (BT) {
                             if (SWG) BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0) | (upD + E < upM + OE ? 4 : 0) | (BI + E < BM + OE ? 8 : 0) |
                                                                  (cM + O <= cDd ? 0 : 16));
-                            else TM[(size_t)(h + 1) * S + 7] = (int16_t)cM;   // canonical home of flat[W*h + W]
+                            else BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0));   // NW: "not D", "not I"
                         }
                     }
                 }
                 AIM_SSTAMP(5);   // tail cell / picks
                 // ---- table (BT): 16-byte stores where the lane's cells are all inside the row (off the critical path: after the posts)
-                if (BT && SWG && nvalid > 0) {   // four direction bits per cell: the sign bytes of four saturating differences, gathered by v_perm_b32 (selectors
+                if (BT && nvalid > 0) {   // four direction bits per cell (NW: the first two): the sign bytes of four saturating differences, gathered by v_perm_b32 (selectors
                                                  // 8 .. 11 replicate a source's sign bits) and merged per four registers; the two gap tests are in fw already
 #pragma unroll
                     for (int j = 0; j < KP; ++j) {
@@ -607,18 +605,6 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     uint32_t *dst = FLW + ((size_t)h * FS + wv * kWave + lane) * NQS;
                     if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
                     else *reinterpret_cast<uint2 *>(dst) = make_uint2(fw[0], fw[1]);
-                }
-                if (BT && !SWG && nvalid > 0) {
-                    const size_t trow = (size_t)h * S + 7 + v0;
-                    if constexpr (K % 8 == 0) {
-#pragma unroll
-                        for (int q = 0; q < K / 8; ++q)
-                            *reinterpret_cast<uint4 *>(&TM[trow + 8 * q]) = make_uint4(dps_bits(Mp[4 * q]), dps_bits(Mp[4 * q + 1]), dps_bits(Mp[4 * q + 2]), dps_bits(Mp[4 * q + 3]));
-                    } else {   // K = 20: a lane's cells start on an 8-byte boundary only
-#pragma unroll
-                        for (int q = 0; q < K / 4; ++q)
-                            *reinterpret_cast<uint2 *>(&TM[trow + 4 * q]) = make_uint2(dps_bits(Mp[2 * q]), dps_bits(Mp[2 * q + 1]));
-                    }
                 }
             }
             AIM_SSTAMP(7);       // (the last row's table stores)
@@ -651,7 +637,6 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     auto tw_flush = [&]() {
                         if (tw_g >= 0 && lane == 0) for (int d = 0; d < NQS; ++d) FLW[((size_t)(h + 1) * FS + tw_g) * NQS + d] = tw[d];
                     };
-                    const size_t tdst = (size_t)(h + 1) * S + 7;
                     for (int v = W; v <= plen; ++v) {
                         int leftM, leftI, diagM;
                         if (v == W) { leftM = bM; leftI = bI; diagM = tl[2]; }
@@ -667,14 +652,13 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                             cI = min(leftM + OE, leftI + E);
                             cM = min(diagM + ((pch == tch) ? MATCH : MISMATCH), min(cI, cDd));
                         } else {
-                            cI = cDd = 0;
-                            cM = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(leftM + GI, upM + GD));
+                            cI = leftM + GI; cDd = upM + GD;
+                            cM = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(cI, cDd));
                         }
-                        if (BT && !SWG) { if (lane == 0) TM[tdst + (v - W)] = (int16_t)cM; }
-                        if (BT && SWG) {   // the direction bits of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array)
-                            const uint32_t nD = cM != cDd ? 1u : 0u, nI = cM != cI ? 1u : 0u, xD = upD + E < upM + OE ? 1u : 0u, xI = leftI + E < leftM + OE ? 1u : 0u;
+                        if (BT) {   // the direction bits of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array); NW: "not D", "not I" only
+                            const uint32_t nD = cM != cDd ? 1u : 0u, nI = cM != cI ? 1u : 0u, xD = (SWG && upD + E < upM + OE) ? 1u : 0u, xI = (SWG && leftI + E < leftM + OE) ? 1u : 0u;
                             const int C = v - W;
-                            if (C == 0) { if (lane == 0) BF[h + 1] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | (cM + O <= cDd ? 0u : 16u)); }
+                            if (C == 0) { if (lane == 0) BF[h + 1] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | ((!SWG || cM + O <= cDd) ? 0u : 16u)); }
                             else {
                                 if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left (column 1's: BF bit 4, set with column 0)
                                     const int t = (C - 2) - tw_g * K, j = t >> 1;
@@ -691,7 +675,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         upM = cM; upD = cDd;
                         lastM = cM;
                     }
-                    if (BT && SWG) tw_flush();
+                    if (BT) tw_flush();
                     if (lane == 0) tl[3] = lastM;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -705,7 +689,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
         }
 
         if (BT && wv == 0 && !(a.dbg_flags & 1u)) {
-            if (SWG && !literal) dp_traceback_swg_bits<K>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 12 * 1024 ? 256 : 64, ops, lane, begin_offset);
+            if (!literal) dp_traceback_swg_bits<K, SWG>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 12 * 1024 ? 256 : 64, ops, lane, begin_offset);
             else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
         }
         if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)
@@ -775,14 +759,15 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     if (!dp_strip_shape(p, kn, &sh, n_pairs)) return false;
     *k_out = sh.k;
     const uint64_t S = (uint64_t)dp_strip_stride((int)rs, sh.k);
-    // NW: one int16 plane per workgroup. SWG (round 5): four direction bits per cell (NQS dwords per lane and row) + one byte per row, and a POOL of
-    // three-plane tables for the literal path behind the slabs (dp_strip_pool_bytes); score-only launches touch neither.
+    // Round 5: four direction bits per cell (NW uses two; NQS dwords per lane and row) + one byte per row, and a POOL of int16 tables (SWG three planes,
+    // NW one) for the literal path behind the slabs; score-only launches touch the pool on the literal path only.
     const uint64_t nq = (uint64_t)((sh.k / 2 + 3) / 4), nqs = nq == 3 ? 4 : nq, fs = rs / (uint64_t)sh.k + 2;
-    uint64_t per = swg ? (rs + 3) * fs * nqs * 4 + (rs + 3) + 64 : S * (rs + 3) * 2;
-    if (swg && !(p.flags & AIM_FLAG_BACKTRACE)) per = 256;
+    uint64_t per = (rs + 3) * fs * nqs * 4 + (rs + 3) + 64;
+    if (!(p.flags & AIM_FLAG_BACKTRACE)) per = 256;
     per = (per + 255) & ~255ull;
-    const uint64_t table = swg ? 3 * S * (rs + 3) * 2 : 0;         // one pool table
-    if (swg) { if (budget < 256 + table + per) return false; budget -= 256 + table; }   // (at least one table; more as the budget allows, dp_strip_pool_tables)
+    const uint64_t table = (swg ? 3 : 1) * S * (rs + 3) * 2;       // one pool table (the literal path's int16 planes)
+    if (budget < 256 + table + per) return false;
+    budget -= 256 + table;                                         // (at least one table; more as the budget allows)
     const int nw = sh.nw;
     *block = (uint32_t)(kWave * nw);
     const uint64_t seqcap = (rs + 79) & ~15ull, rowcap = (rs + 47) & ~7ull;
@@ -802,12 +787,12 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     *grid = g;
     *scratch_per_wg = per;
     *scratch_total = (size_t)(per * g);
-    if (swg) {   // [slabs | 256 B of lock words | pool tables]: up to 8 tables where the budget admits them
+    {   // [slabs | 256 B of lock words | pool tables]: up to 8 tables where the budget admits them
         uint64_t tables = 1;
         while (tables < 8 && tables < g && per * g + 256 + (tables + 1) * table <= budget + table) ++tables;
         *pool_tables = (uint32_t)tables;
         *scratch_total += (size_t)(256 + tables * table);
-    } else *pool_tables = 0;
+    }
     return true;
 }
 
