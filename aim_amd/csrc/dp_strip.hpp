@@ -80,98 +80,12 @@ __device__ __forceinline__ int strip_wait(lds_msg_p m, int seq)
     }
 }
 
-// swg_traceback (swg.c:45-119) over the strip kernel's COMPACT table: the M plane (int16, canonical slab) plus two bits per cell --
-// "M != D" and "M != I" -- instead of the I and D planes (2.25 instead of 6 bytes per cell: with all three planes config 4 was bound
-// by its 157 GB of table writes). Everything the reference's walk compares follows from those: in layer M it asks m == D, m == I,
-// then compares m with the diagonal M; entering a gap layer it KNOWS the layer's value (it equals m), and along a gap
-// D[v-1] = D[v] - e (I[h-1] = I[h] - e) whenever the "opened here" test D[v] == M[v-1] + o + e fails -- the recurrence itself,
-// exact because no int16 store wraps (dp_strip_exact_ok). Flags: per row and lane one 8-byte word, cell t = 2 j + hi at bits
-// (hi ? 16 : 0) + 2 (j & 7) of word j >> 3 (row h's words at FL[h * FS + lane]); boundary cells (column 0) in BF[row].
 #ifdef AIM_STRIP_STAMPS   // diagnostic builds only (tools/strip_stamps.py): s_memtime per phase of a row, summed per wavefront, dumped into the pair's ops row
 #define AIM_SSTAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     __builtin_amdgcn_sched_barrier(0); ssum[i] += t_ - slast; slast = t_; } while (0)
 #else
 #define AIM_SSTAMP(i) do { } while (0)
 #endif
-
-template <int K>
-__device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, int plen, int tlen, int S, int FS, const int16_t *TM, const uint2 *FL,
-                                                         const unsigned char *BF, int16_t *tile, char *ops, int lane, int &begin_offset, int &status)
-{
-    const int rs = p.read_size, W = tlen + 1;
-    const int OE = p.gap_o + p.gap_e, E = p.gap_e, MATCH = p.match, MISMATCH = p.mismatch;
-    auto addr = [&](int f) -> size_t { const int r = f / W; return (size_t)r * S + 7 + (f - r * W); };
-    int sentinel = plen + tlen - 1;
-    int h = tlen, v = plen;
-    const int cap = 2 * rs;
-    auto put = [&](char ch) { if (lane == 0 && sentinel >= 0 && sentinel < cap) ops[sentinel] = ch; --sentinel; };
-    // kTR-row x 64-column window of M (dp_wave.hpp's tiled walk, taller: the walk moves up one row per step at most, so a window
-    // of 32 rows lasts ~31 steps -- with 8 rows the refills' HBM round trips were the traceback's time) + the flag words of the
-    // lanes that own those columns
-    constexpr int kTR = 32;
-    int16_t *tileM = tile;                                                   // [kTR rows][8 units][8 cells]
-    uint2 *tileF = reinterpret_cast<uint2 *>(tile + kTR * 64);               // [kTR rows][8 words]
-    int tR = -1, tC0 = 0, tG0 = 0;
-    auto refill = [&](int R, int C) {                             // C >= 1
-        const int u0 = ((C - 1) >> 3) - 7;
-        tR = R; tC0 = 8 * u0 + 1;
-        tG0 = ((tC0 > 1 ? tC0 : 1) - 1) / K;
-#pragma unroll
-        for (int q = 0; q < kTR / 8; ++q) {
-            const int rr = 8 * q + (lane >> 3);                   // row of the window this lane fills in round q
-            const int r = R - rr, u = u0 + (lane & 7);
-            if (r >= 0 && u >= -1) {
-                const size_t e = (size_t)r * S + 8 * (size_t)(u + 1);
-                *reinterpret_cast<uint4 *>(&tileM[(rr * 8 + (lane & 7)) * 8]) = *reinterpret_cast<const uint4 *>(&TM[e]);
-            }
-            const int g = tG0 + (lane & 7);
-            if (r >= 0 && g < FS) tileF[rr * 8 + (lane & 7)] = FL[(size_t)r * FS + g];
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    };
-    auto in_tile = [&](int R, int C) { return tR >= 0 && R <= tR && R - 1 >= tR - (kTR - 1) && C - 1 >= tC0 && C <= tC0 + 63; };
-    auto tget = [&](int r, int c) { const int cc = c - tC0; return (int)tileM[(((tR - r) * 8 + (cc >> 3)) << 3) + (cc & 7)]; };
-    auto flags_of = [&](uint2 w, int t) { const int j = t >> 1; const uint32_t part = j < 8 ? w.x : w.y; return (int)((part >> (((t & 1) ? 16 : 0) + 2 * (j & 7))) & 3u); };
-    enum { L_M, L_I, L_D };
-    int layer = L_M, gapv = 0;                                   // gapv: the value of the gap layer at the current cell (D or I)
-    while (h > 0 && v > 0) {
-        const int at = W * h + v;
-        const int R = at / W, C = at - R * W;
-        int m, mu, ml, mg, ne;
-        if (C >= 1) {
-            if (!in_tile(R, C)) refill(R, C);
-            m = tget(R, C); mu = tget(R, C - 1); ml = tget(R - 1, C); mg = tget(R - 1, C - 1);
-            const int g = (C - 1) / K;
-            ne = flags_of(tileF[(tR - R) * 8 + (g - tG0)], (C - 1) - g * K);
-        } else {
-            m = TM[addr(at)]; mu = TM[addr(at - 1)]; ml = TM[addr(at - W)]; mg = TM[addr(at - W - 1)];
-            ne = BF[R];
-        }
-        if (layer == L_D) {
-            put('D');
-            if (gapv == mu + OE) layer = L_M; else gapv -= E;
-            --v;
-        } else if (layer == L_I) {
-            put('I');
-            if (gapv == ml + OE) layer = L_M; else gapv -= E;
-            --h;
-        } else {
-            if (!(ne & 1)) { layer = L_D; gapv = m; }
-            else if (!(ne & 2)) { layer = L_I; gapv = m; }
-            else if (m == mg + MATCH) { put('M'); --h; --v; }
-            else if (m == mg + MISMATCH) { put('X'); --h; --v; }
-            else { status = AIM_PAIR_SWG_NO_OP; break; }
-        }
-    }
-    if (status == AIM_PAIR_OK) {
-        for (int i = lane; i < h; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'I'; }
-        if (h > 0) sentinel -= h;
-        for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
-        if (v > 0) sentinel -= v;
-    }
-    begin_offset = sentinel + 1;
-}
-
 
 // swg_traceback (swg.c:45-119) over FOUR DIRECTION BITS per cell, decided at fill time (round 5) -- no value plane at all:
 // 0.5 - 0.8 instead of 2.25 bytes per cell (config 4 wrote 61.8 GB per 256 pairs, 52 GB of it the int16 M plane). The four tests of the reference's
@@ -187,10 +101,10 @@ __device__ __forceinline__ void dp_traceback_swg_compact(const aim_params_t &p, 
 // "M != I" (b = 2, 3), high nibble: "next D extended" / "I extended"), row h's words at FLW[(h * FS + lane) * NQS]; boundary cells (column 0) in BF[row]:
 // bits 0 - 3 the cell's own four tests (D extended = its OWN), bit 4 "D of column 1 extended".
 template <int K, bool SWG>
-__device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int plen, int tlen, int FS, const uint32_t *FLW, const unsigned char *BF,
+__device__ __forceinline__ bool dp_traceback_swg_bits(const aim_params_t &p, int plen, int tlen, int FS, const uint32_t *FLW, const unsigned char *BF,
                                                       const unsigned char *ldsP, const unsigned char *ldsT, uint32_t *tile, int tile_rows, char *ops, int lane,
-                                                      int &begin_offset)
-{
+                                                      int &begin_offset, bool banded, int band_lo, int band_hi)
+{   // banded: direction bits exist only where C - R lies in [band_lo, band_hi] (the strips around the diagonal, dp_strip_kernel); returns true when the walk left it
     constexpr int KP = K / 2, NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;
     const int kTR = tile_rows;                                    // rows of the window: 64 or 256 (what the workgroup's LDS admits)
     constexpr int kTW = 3;                                        // lane words per row of the window: a BAND around the diagonal through the cell it was filled at
@@ -229,6 +143,9 @@ __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int
     int R = W ? (W * h + v) / W : 0, C = (W * h + v) - R * W;
     int layer = 0;                                                // 0: M, 1: I, 2: D
     while (h > 0 && v > 0) {
+        // (the cells of a diagonal run share C - R; the D layer looks at C - 1: the band handed in is one narrower. A pair with tail cells lands, from the last
+        //  row's tail, in the first plen - tlen columns of the last rows -- flat indices beyond W -- and leaves them through column 0: those cells have bits too)
+        if (banded && C >= 1 && R <= tlen && (C - R < band_lo || C - R > band_hi) && !(plen > tlen && R >= tlen - (plen - tlen) - 1 && C <= plen - tlen + 1)) return true;
         if (layer == 0 && C >= 1 && R <= tlen) {
             // A RUN OF DIAGONAL MOVES, 64 cells at a time: lane i looks at cell (R - i, C - i) -- inside the table, inside the window, both "M != D" and "M != I" --
             // and the run is the leading lanes that pass; each writes its own 'M' / 'X' (the cell's own characters). At e = 1 % a run is ~100 cells:
@@ -281,6 +198,7 @@ __device__ __forceinline__ void dp_traceback_swg_bits(const aim_params_t &p, int
     for (int i = lane; i < v; i += kWave) { const int at = sentinel - i; if (at >= 0 && at < cap) ops[at] = 'D'; }
     if (v > 0) sentinel -= v;
     begin_offset = sentinel + 1;
+    return false;
 }
 
 // K: cells per lane; NWMAX: the most wavefronts a workgroup of this instantiation is launched with (its register budget:
@@ -374,8 +292,16 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SWG's ops prefill by all threads completes before the traceback patches it
             __syncthreads();
             score = tl[3];
-        } else {
-            // ---------------------------------------------------------------------------------------- strip pipeline
+        }
+        // ---------------------------------------------------------------------------------------- strip pipeline
+        // With CIGAR the direction bits are made only by the strips AROUND THE DIAGONAL (a band of +- 32 K columns about the two diagonals through the table's
+        // corners: two or three of config 4's eight strips per row) -- the four tests cost ~25 % of a row and sit on the pipeline's critical path, and the walk
+        // of related reads never leaves the band. When it does (the walk checks C - R at every step), the pair is filled again with every strip's bits.
+        for (int attempt = 0; !literal && attempt < 2; ++attempt) {
+            constexpr bool BAND = BT && K == 20;      // (the shapes with registers to spare for a second copy of the row: K = 24 / 32 and 16 x 12 spill with it)
+            const bool full_bits = !BAND || attempt == 1 || nw == 1;
+            const int band_m = 32 * K, band_d0 = min(0, plen - tlen), band_d1 = max(0, plen - tlen);
+            const int strip_c0 = 1 + wv * kWave * K, strip_c1 = strip_c0 + kWave * K - 1;
             for (int i = tid * 4; i < seqcap; i += NT * 4) {   // sequences into LDS, zero beyond their length (dword granularity)
                 uint32_t wp = 0, wt = 0;
                 for (int b = 0; b < 4; ++b) {
@@ -457,7 +383,8 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
 #ifdef AIM_STRIP_STAMPS
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(slast) :: "memory");
 #endif
-            for (int h = 1; h <= tlen; ++h) {
+            auto row = [&](auto gen_tag, int h) __attribute__((always_inline)) {
+                constexpr bool GEN = decltype(gen_tag)::value;   // this strip makes the row's direction bits
                 AIM_SSTAMP(7);   // loop back-edge
                 const int slot = h & (kStripDepth - 1);
                 const uint32_t tch2 = (uint32_t)ldsT[h - 1] * 0x00010001u;
@@ -491,7 +418,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         if (SWG) {
                             const dps2 insn = Mp[j] + OEp, inse = Ip[j] + Ep;
                             ins = dps_min(insn, inse);
-                            if (BT) {   // "I extended": I_up + e < M_up + o + e (sign byte of the saturating difference -> bytes 2, 3, high nibble)
+                            if (BT && GEN) {   // "I extended": I_up + e < M_up + o + e (sign byte of the saturating difference -> bytes 2, 3, high nibble)
                                 const uint32_t sI = __builtin_amdgcn_perm(0u, dps_bits(__builtin_elementwise_sub_sat(inse, insn)), 0x09080c0cu);
                                 fw[j >> 2] |= sI & (0x10100000u << (j & 3));
                             }
@@ -555,7 +482,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     dps2 s_; s_.x = kInf16; s_.y = G[j].x;
                     const dps2 prej = dps_min(c, s_);                      // {pre(2j), pre(2j+1)}
                     c = dps_splat(min((int)prej.y, (int)G[j].y));
-                    if (BT && SWG) {   // "the next cell's D was extended": pre(v) < G(v) (-> bytes 0, 1, high nibble)
+                    if (BT && GEN && SWG) {   // "the next cell's D was extended": pre(v) < G(v) (-> bytes 0, 1, high nibble)
                         const uint32_t sD = __builtin_amdgcn_perm(0u, dps_bits(__builtin_elementwise_sub_sat(prej, G[j])), 0x0c0c0908u);
                         fw[j >> 2] |= sD & (0x00001010u << (j & 3));
                     }
@@ -594,7 +521,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                 }
                 AIM_SSTAMP(5);   // tail cell / picks
                 // ---- table (BT): 16-byte stores where the lane's cells are all inside the row (off the critical path: after the posts)
-                if (BT && nvalid > 0) {   // four direction bits per cell (NW: the first two): the sign bytes of four saturating differences, gathered by v_perm_b32 (selectors
+                if (BT && GEN && nvalid > 0) {   // four direction bits per cell (NW: the first two): the sign bytes of four saturating differences, gathered by v_perm_b32 (selectors
                                                  // 8 .. 11 replicate a source's sign bits) and merged per four registers; the two gap tests are in fw already
 #pragma unroll
                     for (int j = 0; j < KP; ++j) {
@@ -606,6 +533,15 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
                     else *reinterpret_cast<uint2 *>(dst) = make_uint2(fw[0], fw[1]);
                 }
+            };
+            for (int h = 1; h <= tlen; ++h) {
+                // (wave-uniform) does this strip's column range meet the band of row h?
+                const bool gen = full_bits || (strip_c1 >= h + band_d0 - band_m && strip_c0 <= h + band_d1 + band_m) ||
+                                 (plen > tlen && h >= tlen - (plen - tlen) - 2 && strip_c0 <= plen - tlen + 2);   // (where the walk of a pair with tail cells lands: dp_traceback_swg_bits)
+                if constexpr (BAND) {
+                    if (gen) row(std::true_type{}, h);
+                    else row(std::false_type{}, h);
+                } else row(std::true_type{}, h);
             }
             AIM_SSTAMP(7);       // (the last row's table stores)
             // ---- after the last row: its regular part into LDS (score; the tail walk reads it), then the reference's tail cells
@@ -686,12 +622,20 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             }
             if (plen == 0 || tlen == 0) score = 0;
             __syncthreads();                          // everyone has read rowM / tl before the traceback reuses the area as its tile
+            if (!BT) break;
+            if (wv == 0) {
+                bool left = false;
+                if (!(a.dbg_flags & 1u))
+                    left = dp_traceback_swg_bits<K, SWG>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 12 * 1024 ? 256 : 64, ops, lane,
+                                                         begin_offset, !full_bits, band_d0 - band_m + 2, band_d1 + band_m - 2);
+                if (lane == 0) tl[5] = left ? 1 : 0;
+            }
+            __syncthreads();
+            if (tl[5] == 0) break;                    // (else: the walk left the band -- once more, with every strip's bits)
+            begin_offset = plen + tlen - 1;
         }
 
-        if (BT && wv == 0 && !(a.dbg_flags & 1u)) {
-            if (!literal) dp_traceback_swg_bits<K, SWG>(a.p, plen, tlen, FS, FLW, BF, ldsP, ldsT, reinterpret_cast<uint32_t *>(rowM), rowbytes >= 12 * 1024 ? 256 : 64, ops, lane, begin_offset);
-            else dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, !literal, ops, lane, begin_offset, status);
-        }
+        if (BT && literal && wv == 0 && !(a.dbg_flags & 1u)) dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, false, ops, lane, begin_offset, status);
         if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)
             __syncthreads();
             if (tid == 0) atomicExch(&pool_locks[pool_slot], 0u);
@@ -734,7 +678,8 @@ inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *s
         const int nw = (rs + kWave * k - 1) / (kWave * k);
         if (nw > (k == 16 ? 12 : 8)) continue;
         // few pairs (about one per CU, config 4): the busiest SIMD's wavefronts set the time; many pairs: the total work does
-        const long cost = (n_pairs > 4u * kn.cus ? (long)nw : (long)((nw + 3) / 4)) * (110 + 10L * k);
+        long cost = (n_pairs > 4u * kn.cus ? (long)nw : (long)((nw + 3) / 4)) * (110 + 10L * k);
+        if (k >= 24 && p.algo == AIM_ALGO_SWG && (p.flags & AIM_FLAG_BACKTRACE)) cost += cost / 4;   // (round 5: with the direction bits these instantiations spill 15 - 51 registers)
         if (!best_k || cost < best_cost) { best_k = k; best_nw = nw; best_cost = cost; }
     }
     if (!best_k) return false;

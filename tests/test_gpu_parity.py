@@ -1717,3 +1717,28 @@ def test_default_abi_ops_rows_need_no_prefilled_buffer(gpu, sample_bytes, ref_di
             s.push(0, req, pat, txt); s.launch()
             res, ops = s.pull(0)
             assert md5(engine.format_output(res, ops, True)) == ref_digests[key]
+
+
+@pytest.mark.parametrize("algo", ["swg", "nw"])
+def test_dp_strip_walk_that_leaves_the_band_is_redone_with_every_strips_bits(gpu, monkeypatch, algo):
+    """Round 5: with CIGAR the K = 20 strip shape makes direction bits only in the strips around the diagonal and fills a pair again when its walk leaves
+    that band (dp_strip.hpp). Pairs whose optimal path shifts by ~900 diagonals half-way (a 900-base block missing from the text, 900 other bases appended: the
+    lengths stay equal) leave it; related pairs in the same batch do not. Both against the oracle, scores and CIGARs."""
+    from aim_amd import capi, engine
+    import ctypes as C
+    monkeypatch.setenv("AIM_STRIP_K", "20")
+    l, rs, n = 3000, 3064, 24
+    ms = 500 if algo == "swg" else 400
+    req, pat, txt = engine.gen_pairs(515, 0, n, l, 0.01, rs)
+    rng = np.random.default_rng(8)
+    for i in range(0, n, 2):
+        p = pat[i, :l].copy()
+        t = np.concatenate([p[:1000], p[1900:], rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=900).astype(np.uint8)])
+        txt[i, :] = 0
+        txt[i, :l] = t
+        req["pattern_len"][i] = l
+        req["text_len"][i] = l
+    params = engine.make_params(algo, ms, rs, backtrace=True, swg_w16=(algo == "swg"))
+    assert capi.load().aim_kernel_name(C.byref(params)) == b"dp_strip_kernel"
+    res, ops, ores = _compare(algo, params, req, pat, txt)
+    assert (ores["score"][0::2] > 4 * ores["score"][1::2].max()).all()          # the shifted pairs really are different animals

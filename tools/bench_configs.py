@@ -49,6 +49,7 @@ CONFIGS = {
     "swg_l70_e2_score": dict(algo="swg", l=70, e=0.02, n=1 << 20, kw=dict()),
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
+    "swg_l10000_e1_cigar_n2048": dict(algo="swg", l=10000, e=0.01, n=2048, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict(backtrace=True)),
     "nw_l1000_e5_cigar": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l1000_e5_score": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict()),
