@@ -268,6 +268,18 @@ def main():
         os.environ.update(env)
         req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
         if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")   # non-ACGT byte
+        if algo != "wfa" and l >= 1500 and rng.random() < 0.3:     # paths that shift by many diagonals half-way (a block missing from the text, other bases appended): the banded
+            blk = rng.choice([l // 5, l // 3, 700, 1300])          # direction bits of dp_strip (K = 20) must notice and fill the pair again
+            for i in range(0, n, rng.choice([1, 2, 5])):
+                pl = int(req["pattern_len"][i])
+                if pl < 2 * blk + 10: continue
+                p_ = pat[i, :pl]
+                cut = rng.randint(1, pl - blk - 1)
+                t_ = np.concatenate([p_[:cut], p_[cut + blk:], np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(blk)), dtype=np.uint8)])[:rs]
+                txt[i, :] = 0
+                txt[i, :len(t_)] = t_
+                req["text_len"][i] = len(t_)
+            if rng.random() < 0.5: env["AIM_STRIP_K"] = "20"; os.environ["AIM_STRIP_K"] = "20"
         kn = lib.aim_kernel_name(C.byref(params)).decode()
         case = dict(algo=algo, l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, env=env, **{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
         try:
