@@ -94,8 +94,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // comparison (the minima, the direction bits and their tie order) is unchanged; the score is un-tilted once at the end. |T| <= GAP_I * tlen +
     // GAP_D * plen < 8 000 (nw_reg_supported), INF = 16 000 stays out of reach.
     const dps2 x2 = dps_splat(MISMATCH), c2 = dps_splat(-(GAP_I + GAP_D));
-    // direction table: 8 dwords per row and lane (dword q: registers 8q .. 8q + 7, register k's two cells at bits 2k (low half) and
-    // 16 + 2k (high half); bit 0 "not D", bit 1 "not I"); 4 dwords = one 16-byte unit, units lane-interleaved
+    // direction table: 8 dwords per row and lane (dword q: registers 8q .. 8q + 7; register 8q + r at bit r of every byte: byte 0 / 1 = "not D" of its low / high
+    // half, byte 2 / 3 = "not I"); 4 dwords = one 16-byte unit, units lane-interleaved
     uint32_t *tbw = reinterpret_cast<uint32_t *>(tb);
 #define TBW(h, q) tbw[((size_t)((h) * 2 + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
 
@@ -211,10 +211,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, set above), re-tilted for (h, 0)
             const uint32_t binj = (((src[NPK - 1] >> 16) + kW) & 0xffffu) * 0x00010001u;
             uint32_t rprev = (uint32_t)kRegInf << 16;         // the register left of this one: m[index - 1] in its HIGH half
-            dps2 code[8];                                     // BACKTRACE: direction bits of the registers of the current group of eight
-            uint32_t dirw[8];
+            uint32_t dirw[8];                                 // BACKTRACE: the row's direction bits
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { code[k] = dps_splat(0); dirw[k] = 0u; }
+            for (int k = 0; k < 8; ++k) dirw[k] = 0u;
             uint32_t oldprev = (uint32_t)kRegInf << 16;
 #pragma unroll
             for (int j = J0; j < NPK; ++j) {
@@ -240,16 +239,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         "v_min_i16_sdwa %0, %3, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
                         : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)));
                     const uint32_t sD = dps_bits(A - dps_from(t1)), sI = dps_bits(sub - ins);   // sign bits: chain lost strictly / insertion lost strictly
-                    const uint32_t neD = (sD >> 15) & 0x00010001u;
-                    uint32_t cj = ((sI >> 14) & 0x00020002u) | neD;
+                    // Round 5: the four sign bits of a register as four BYTES (v_perm_b32, selectors 8 .. 11 replicate a source's sign bits), bit r of each byte kept
+                    // for register 8q + r: four instructions per register where shifting, masking and three levels of v_pk_mad_u16 were eight
+                    // (dword q: byte 0 / 1 = "not D" of the low / high halves, byte 2 / 3 = "not I").
+                    uint32_t cj = __builtin_amdgcn_perm(sI, sD, 0x0b0a0908u);
                     opaque(cj);   // (volatile, like the chain above: the bits are made HERE -- left to itself the compiler makes all 58 registers' bits at the end of the row, with every register's sub / ins / A / chain live until then: ~400 VGPRs)
-                    code[j & 7] = dps_from(cj);
-                    if ((j & 7) == 7 || j == NPK - 1) {   // eight registers' codes -> one dword (v_pk_mad_u16: fields never carry into each other)
-                        const dps2 c4 = dps_splat(4), c16 = dps_splat(16), c256 = dps_splat(256);
-                        const dps2 c01 = code[1] * c4 + code[0], c23 = code[3] * c4 + code[2], c45 = code[5] * c4 + code[4], c67 = code[7] * c4 + code[6];
-                        dirw[j >> 3] = dps_bits((c67 * c16 + c45) * c256 + (c23 * c16 + c01));
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) code[k] = dps_splat(0);
+                    dirw[j >> 3] |= cj & (0x01010101u << (j & 7));
+                    if ((j & 7) == 7 || j == NPK - 1) {
                         if ((j >> 3) == 3 && mine && h <= tlen) {   // the first four dwords leave as soon as they are complete (their registers are free for the rest of the row)
                             typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
                             aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]};
@@ -367,8 +363,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const int hh = v > W ? h + 1 : h, vv = v > W ? v - W : v;
                     if (v > W) { pi = vv - 1; ti = hh - 1; }
                     const int i = vv + s0, j = i >> 1;
-                    const uint32_t word = TBW(hh, j >> 3);
-                    code = (word >> (16 * (i & 1) + 2 * (j & 7))) & 3u;
+                    const uint32_t word = TBW(hh, j >> 3) >> (8 * (i & 1) + (j & 7));
+                    code = (word & 1u) | ((word >> 15) & 2u);
                 }
                 if (!(code & 1u)) { OPS(sentinel) = 'D'; --sentinel; --v; }
                 else if (!(code & 2u)) { OPS(sentinel) = 'I'; --sentinel; --h; }
