@@ -429,7 +429,13 @@ constexpr int kSwgWin = 16;        // registers (32 indices) in which a row may 
 
 // Registers of a row: the launchers' READ_SIZE rule (run-swg-pim-wram.py: ceil((l + l*e + 7) / 8) * 8) leaves pattern and text at READ_SIZE - 7 characters at most, and
 // column v sits at index v - 1: 2 * NPK >= READ_SIZE - 7 indices hold every pair they produce (a longer pattern, legal up to READ_SIZE, goes to the to-do list).
-inline int swg_reg_npk(int read_size) { return read_size <= 48 ? 21 : read_size <= 64 ? 29 : read_size <= 80 ? 37 : read_size <= 96 ? 45 : read_size <= 112 ? 53 : read_size <= 128 ? 61 : 0; }
+// READ_SIZE 144 / 160 / 176 (l = 150: the common short-read length): 69 / 77 / 85 registers per row -- M and I rows alone are up to 170 registers, so these classes keep the
+// PATTERN in LDS (bytes, one ds_read per two registers and row, expanded to 16-bit fields with one v_perm per register) instead of in 85 more registers.
+__host__ __device__ inline int swg_reg_npk(int read_size)
+{
+    return read_size <= 48 ? 21 : read_size <= 64 ? 29 : read_size <= 80 ? 37 : read_size <= 96 ? 45 : read_size <= 112 ? 53 : read_size <= 128 ? 61 :
+           read_size <= 144 ? 69 : read_size <= 160 ? 77 : read_size <= 176 ? 85 : 0;
+}
 constexpr int kSwgTail = 8;        // tail cells of the last row a pair may have beyond (tlen, W): plen <= tlen + 1 + kSwgTail
 inline int swg_reg_cell_bytes(const aim_params_t &p) { return (p.flags & AIM_FLAG_SWG_W16) ? 2 : (p.max_score < 127 ? 1 : 2); }   // = swg_cell_bytes (dp_lane.hpp)
 
@@ -438,7 +444,9 @@ inline bool swg_reg_supported(const aim_params_t &p)
     if (p.algo != AIM_ALGO_SWG || swg_reg_npk(p.read_size) == 0 || p.read_size < 40) return false;
     if (p.match != 0 || p.mismatch < 1 || p.gap_o < 1 || p.gap_e < 1 || p.max_score < 0) return false;
     const long oe = (long)p.gap_o + p.gap_e, cmax = std::max<long>(oe, p.mismatch);
-    if (swg_reg_cell_bytes(p) == 1) return cmax <= 127 && p.max_score <= 127;   // (two values <= 127: a wrapped sum is negative)
+    if (swg_reg_cell_bytes(p) == 1)   // (two values <= 127: a wrapped sum is negative; and the column initialisation o + v e must not wrap for the lengths the launchers'
+                                      //  READ_SIZE rule leaves -- at l = 150 EVERY int8 pair wraps (quirk S3) and would only pass through here to be flagged)
+        return cmax <= 127 && p.max_score <= 127 && (long)p.gap_o + (p.read_size - 8L) * p.gap_e <= 127;
     return std::max<long>(p.max_score, p.gap_o) + (p.read_size + 2L) * p.gap_e + 2 * cmax < 32000;   // int16 cells: nothing can wrap
 }
 
@@ -446,7 +454,7 @@ __host__ __device__ inline int swg_reg_units(int npk) { return ((npk + 3) / 4 + 
 __host__ __device__ inline size_t swg_reg_lds_bytes(const aim_params_t &p, int npk)   // text image / ops staging + the two pair queues (1 KB)
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave;
+    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 61 ? 2 : 1), o = (size_t)2 * p.read_size * kWave;   // (npk > 61: text image + pattern image)
     return ((bt && o > t) ? o : t) + 1024;
 }
 inline size_t swg_reg_slab_bytes(int npk, int read_size) { return (size_t)(read_size + 2) * swg_reg_units(npk) * 16 * kWave; }
@@ -474,6 +482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int NQ = (NPK + 3) / 4;     // dwords of direction bits per row and lane
     constexpr int NU = (NQ + 3) / 4;      // ... in 16-byte units
     constexpr int JW = NPK - kSwgWin;     // first register in which a row may end
+    constexpr bool PL = NPK > 61;         // the pattern row lives in LDS (READ_SIZE 144 .. 176), not in NPK more registers
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
     const int OE = a.p.gap_o + a.p.gap_e, GAP_E = a.p.gap_e, MISMATCH = a.p.mismatch, MAXS = a.p.max_score;
@@ -517,14 +526,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // the text row goes to LDS, transposed [dword][lane] (one conflict-free ds_read per ROW of the table), the pattern row into registers as
         // 16-bit fields (character v - 1 at index v - 1: no shift)
         uint32_t *ldsT = reinterpret_cast<uint32_t *>(smem);
-        uint32_t pc[NPK];
+        uint32_t *ldsP = ldsT + NWD * kWave;                  // PL: the pattern rows, transposed like the text's
+        uint32_t pc[PL ? 1 : NPK];
         __syncthreads();                                      // (single wavefront: the previous batch's traceback is done with this area)
 #pragma unroll
         for (int i = 0; i < NWD; ++i) {
             const uint32_t pw = i < rsw ? gP[i] : 0u;
             ldsT[i * kWave + lane] = i < rsw ? gT[i] : 0u;
-            if (2 * i < NPK) pc[2 * i] = __builtin_amdgcn_perm(0u, pw, 0x0c010c00u);           // bytes 0, 1 -> 16-bit fields (indices 4i, 4i + 1)
-            if (2 * i + 1 < NPK) pc[2 * i + 1] = __builtin_amdgcn_perm(0u, pw, 0x0c030c02u);   // bytes 2, 3
+            if (PL) ldsP[i * kWave + lane] = pw;
+            else {
+                if (2 * i < NPK) pc[2 * i] = __builtin_amdgcn_perm(0u, pw, 0x0c010c00u);           // bytes 0, 1 -> 16-bit fields (indices 4i, 4i + 1)
+                if (2 * i + 1 < NPK) pc[2 * i + 1] = __builtin_amdgcn_perm(0u, pw, 0x0c030c02u);   // bytes 2, 3
+            }
         }
         // row 0 (the "first column" loop of swg_compute, swg.c:131-136): M = D = o + v e (wrapped like the reference's store), I = MAX_SCORE; columns
         // beyond plen hold 0 (never read by a cell of the pair). plen == tlen + 1: flat cell (0, W) IS the boundary cell (1, 0), and the row
@@ -576,6 +589,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
                 aim_u32x4 unit = {0u, 0u, 0u, 0u};
                 uint32_t diag = __builtin_amdgcn_alignbit(M[0], oldprev, 16);           // {M[h-1][index - 1]} of register 0's cells
+                uint32_t pword = 0u;                                                    // PL: the pattern dword of the current two registers
 #pragma unroll
                 for (int j = 0; j < NPK; ++j) {
                     if (!BT && j >= NPK - 4 && j >= njrun) continue;
@@ -585,7 +599,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     uint32_t dnext = j + 1 < NPK ? __builtin_amdgcn_alignbit(M[j + 1], M[j], 16) : 0u;
                     opaque(insn);
                     opaque(dnext);
-                    const uint32_t f = pk_ne01(pc[j], tch2, ones);
+                    uint32_t pcj;
+                    if (PL) {
+                        if ((j & 1) == 0) pword = ldsP[(j >> 1) * kWave + lane];
+                        pcj = __builtin_amdgcn_perm(0u, pword, (j & 1) ? 0x0c030c02u : 0x0c010c00u);
+                    } else pcj = pc[j];
+                    const uint32_t f = pk_ne01(pcj, tch2, ones);
                     const uint32_t mm = dps_bits(dps_from(f) * dps_from(x2) + dps_from(diag));   // m_match (MATCH = 0)
                     const uint32_t inse = add2(I[j], e2);
                     const uint32_t ins = min2(insn, inse);
@@ -845,6 +864,9 @@ void swg_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArg
     else if (npk == 45) AIM_SWGREG(45);
     else if (npk == 53) AIM_SWGREG(53);
     else if (npk == 61) AIM_SWGREG(61);
+    else if (npk == 69) AIM_SWGREG(69);
+    else if (npk == 77) AIM_SWGREG(77);
+    else if (npk == 85) AIM_SWGREG(85);
 #undef AIM_SWGREG
 #undef AIM_SWGREG2
 }

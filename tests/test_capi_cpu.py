@@ -96,7 +96,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 136))) == b"nw_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_reg_kernel"                          # round 5: M and I rows in registers up to READ_SIZE 128
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 112, backtrace=True))) == b"swg_reg_kernel"       # (int16 cells too)
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 136))) == b"swg_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 160, swg_w16=True))) == b"swg_reg_kernel"            # (l = 150, int16 cells: the pattern row in LDS, M and I in 154 registers)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 160))) == b"swg_lane_kernel"                         # (l = 150, int8 cells: o + v e passes 127 -- every pair wraps (S3): no point in the register pass)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 184))) == b"swg_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112, match=-1))) == b"swg_lane_kernel"              # (negative costs: cells may be negative without a wrap)
 
 

@@ -92,7 +92,7 @@ def main():
             # short-read NW / SWG: READ_SIZE 40 .. 128, lengths anywhere inside it, per-pair length outliers (tails plen >= tlen + 2, short reads
             # left of nw_reg_kernel's window), penalties on both sides of nw_reg_supported(), with and without the register kernel
             algo = rng.choice(["nw", "nw", "nw", "swg"])
-            rs = rng.choice([40, 48, 64, 72, 80, 88, 96, 104, 112, 112, 112, 120, 128])
+            rs = rng.choice([40, 48, 64, 72, 80, 88, 96, 104, 112, 112, 112, 120, 128, 136, 144, 160, 160, 176])   # (> 128: swg_reg with the pattern row in LDS; NW: nw_lane)
             l = rng.randint(max(1, rs - 40), rs - 8)
             e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10])
             if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
