@@ -215,10 +215,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
             for (int k = 0; k < 8; ++k) dirw[k] = 0u;
             uint32_t oldprev = (uint32_t)kRegInf << 16;
+            // (BACKTRACE updates the row in place: the NEXT register's diagonal is taken before this register is overwritten -- as a plain read-later the compiler kept a
+            //  v_mov copy per register and row; the score-only variant alternates between two arrays and needs neither)
+            uint32_t dnext = __builtin_amdgcn_alignbit(src[J0], oldprev, 16);
 #pragma unroll
             for (int j = J0; j < NPK; ++j) {
                 const uint32_t oldj = src[j];
-                const dps2 diag = dps_from(__builtin_amdgcn_alignbit(oldj, oldprev, 16));   // {R_{h-1}[2j - 1], R_{h-1}[2j]}
+                const dps2 diag = dps_from(BT ? dnext : __builtin_amdgcn_alignbit(oldj, oldprev, 16));   // {R_{h-1}[2j - 1], R_{h-1}[2j]}
+                if (BT) {
+                    dnext = j + 1 < NPK ? __builtin_amdgcn_alignbit(src[j + 1], oldj, 16) : 0u;
+                    opaque(dnext);
+                }
                 const dps2 f = dps_from(pk_ne01(pc[j], tch2, ones));
                 const dps2 sub = (f * x2 + c2) + diag;
                 const dps2 ins = dps_from(oldj);                 // (tilted: the move from the row above costs nothing)
@@ -234,11 +241,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         : "=&v"(res) : "v"(rprev), "v"(dps_bits(A)));
                 } else {
                     // the same chain with both gap candidates kept, packed {m[2j], m[2j - 1]} = the cells' left neighbours (t1), for the direction bits
+                    uint32_t sI = dps_bits(sub - ins);   // insertion lost strictly (taken BEFORE the chain: the old row's register is dead from here on and takes the new value)
+                    opaque(sI);
                     asm volatile("v_min_i16_sdwa %0, %3, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
                         "v_alignbit_b32 %1, %0, %2, 16\n\t"
                         "v_min_i16_sdwa %0, %3, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
                         : "=&v"(res), "=&v"(t1) : "v"(rprev), "v"(dps_bits(A)));
-                    const uint32_t sD = dps_bits(A - dps_from(t1)), sI = dps_bits(sub - ins);   // sign bits: chain lost strictly / insertion lost strictly
+                    const uint32_t sD = dps_bits(A - dps_from(t1));   // sign bit: chain lost strictly
                     // Round 5: the four sign bits of a register as four BYTES (v_perm_b32, selectors 8 .. 11 replicate a source's sign bits), bit r of each byte kept
                     // for register 8q + r: four instructions per register where shifting, masking and three levels of v_pk_mad_u16 were eight
                     // (dword q: byte 0 / 1 = "not D" of the low / high halves, byte 2 / 3 = "not I").
