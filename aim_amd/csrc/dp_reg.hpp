@@ -52,8 +52,9 @@ constexpr int kRegInf = 16000;     // the value left of a row's start
 // class above it and the whole batch went through the to-do list.)
 __host__ __device__ inline int nw_reg_npk(int read_size, bool bt = false)
 {
-    (void)bt;
-    return read_size <= 48 ? 22 : read_size <= 64 ? 30 : read_size <= 80 ? 38 : read_size <= 96 ? 46 : read_size <= 112 ? 54 : (read_size <= 128 ? 62 : 0);   // (62 registers = the 8 dwords of direction bits a row has)
+    (void)bt;   // READ_SIZE 144 / 160 / 176 (l = 150): 70 / 78 / 86 registers per row with the PATTERN row in LDS (as swg_reg_kernel's large classes) and 12 dwords of direction bits
+    return read_size <= 48 ? 22 : read_size <= 64 ? 30 : read_size <= 80 ? 38 : read_size <= 96 ? 46 : read_size <= 112 ? 54 : read_size <= 128 ? 62 :
+           read_size <= 144 ? 70 : read_size <= 160 ? 78 : read_size <= 176 ? 86 : 0;
 }
 
 inline bool nw_reg_supported(const aim_params_t &p)
@@ -68,7 +69,7 @@ __host__ __device__ inline size_t nw_reg_lds_bytes(const aim_params_t &p)   // t
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
     const int npk = nw_reg_npk(p.read_size, bt);
-    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4, o = (size_t)2 * p.read_size * kWave;
+    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 62 ? 2 : 1), o = (size_t)2 * p.read_size * kWave;   // (npk > 62: text image + pattern image)
     return ((bt && o > t) ? o : t) + 512;
 }
 
@@ -79,6 +80,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     debug_poison_lds(a, smem);
     constexpr int RSK = 2 * NPK;          // indices of a row of registers
     constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
+    constexpr bool PL = NPK > 62;             // the (shifted) pattern row lives in LDS as bytes, not in NPK more registers (READ_SIZE 144 .. 176)
+    constexpr int NDQ = NPK > 64 ? 12 : 8;    // dwords of direction bits per row and lane (8 registers per dword), in 16-byte units
     constexpr bool TAILS = true;              // last-row tail cells in this kernel (with CIGAR too: their direction bits stay in a register, see the walk)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // direction table: 8 dwords per row and lane (dword q: registers 8q .. 8q + 7; register 8q + r at bit r of every byte: byte 0 / 1 = "not D" of its low / high
     // half, byte 2 / 3 = "not I"); 4 dwords = one 16-byte unit, units lane-interleaved
     uint32_t *tbw = reinterpret_cast<uint32_t *>(tb);
-#define TBW(h, q) tbw[((size_t)((h) * 2 + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
+#define TBW(h, q) tbw[((size_t)((h) * (NDQ / 4) + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
 
     // Pairs are taken through a small LDS queue: groups of 64 consecutive pairs are classified (this kernel's / to-do list) and the
     // kernel's own are queued; the row loop runs on 64 QUEUED pairs at a time. (Without it the to-do pairs' lanes idle through the whole
@@ -176,6 +179,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int j = NPK - 1; j >= 0; --j) pc[j] = __builtin_amdgcn_alignbit(pc[j], j ? pc[j - 1] : 0u, 16);
             }
         }
+        uint32_t *ldsP = ldsT + NWD * kWave;                  // PL: the shifted pattern row as bytes (field i of the row = byte i), transposed like the text's
+        if (PL) {
+#pragma unroll
+            for (int i = 0; i < (NPK + 1) / 2; ++i)
+                ldsP[i * kWave + lane] = __builtin_amdgcn_perm(2 * i + 1 < NPK ? pc[2 * i + 1] : 0u, pc[2 * i], 0x06040200u);   // the low bytes of four 16-bit fields
+        }
         // row 0: column v = v * GAP_D at index v + s0, INF left of it
         uint32_t Mp[NPK];
 #pragma unroll
@@ -211,9 +220,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, set above), re-tilted for (h, 0)
             const uint32_t binj = (((src[NPK - 1] >> 16) + kW) & 0xffffu) * 0x00010001u;
             uint32_t rprev = (uint32_t)kRegInf << 16;         // the register left of this one: m[index - 1] in its HIGH half
-            uint32_t dirw[8];                                 // BACKTRACE: the row's direction bits
+            uint32_t dirw[NDQ];                               // BACKTRACE: the row's direction bits
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dirw[k] = 0u;
+            for (int k = 0; k < NDQ; ++k) dirw[k] = 0u;
+            uint32_t pword = 0u;                              // PL: the pattern dword of the current two registers
             uint32_t oldprev = (uint32_t)kRegInf << 16;
             // (BACKTRACE updates the row in place: the NEXT register's diagonal is taken before this register is overwritten -- as a plain read-later the compiler kept a
             //  v_mov copy per register and row; the score-only variant alternates between two arrays and needs neither)
@@ -226,7 +236,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     dnext = j + 1 < NPK ? __builtin_amdgcn_alignbit(src[j + 1], oldj, 16) : 0u;
                     opaque(dnext);
                 }
-                const dps2 f = dps_from(pk_ne01(pc[j], tch2, ones));
+                uint32_t pcj;
+                if (PL) {
+                    if ((j & 1) == 0 || j == J0) pword = ldsP[(j >> 1) * kWave + lane];
+                    pcj = __builtin_amdgcn_perm(0u, pword, (j & 1) ? 0x0c030c02u : 0x0c010c00u);
+                } else pcj = pc[j];
+                const dps2 f = dps_from(pk_ne01(pcj, tch2, ones));
                 const dps2 sub = (f * x2 + c2) + diag;
                 const dps2 ins = dps_from(oldj);                 // (tilted: the move from the row above costs nothing)
                 dps2 A = dps_min(sub, ins);
@@ -255,10 +270,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     opaque(cj);   // (volatile, like the chain above: the bits are made HERE -- left to itself the compiler makes all 58 registers' bits at the end of the row, with every register's sub / ins / A / chain live until then: ~400 VGPRs)
                     dirw[j >> 3] |= cj & (0x01010101u << (j & 7));
                     if ((j & 7) == 7 || j == NPK - 1) {
-                        if ((j >> 3) == 3 && mine && h <= tlen) {   // the first four dwords leave as soon as they are complete (their registers are free for the rest of the row)
+                        if (((j >> 3) & 3) == 3 && (j >> 3) < NDQ - 1 && mine && h <= tlen) {   // a unit of four dwords leaves as soon as it is complete (its registers are free for the rest of the row)
                             typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                            aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]};
-                            __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0)));
+                            const int q0 = (j >> 3) - 3;
+                            aim_u32x4 w0 = {dirw[q0], dirw[q0 + 1], dirw[q0 + 2], dirw[q0 + 3]};
+                            __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, q0)));
                         }
                     }
                 }
@@ -270,9 +286,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (h == tlen) score = (int)(int16_t)(dst[NPK - 1] >> 16) + GAP_I * tlen + GAP_D * pe;   // R_tlen[pe], un-tilted
             if (BT && mine && h <= tlen) {                     // the row's direction bits: two 16-byte stores per lane
                 typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                aim_u32x4 w1 = {dirw[4], dirw[5], dirw[6], dirw[7]};
+                aim_u32x4 w1 = {dirw[NDQ - 4], dirw[NDQ - 3], dirw[NDQ - 2], dirw[NDQ - 1]};   // the last unit (the earlier ones left mid-row)
                 if (NPK <= 32) { aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]}; __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0))); }
-                __builtin_nontemporal_store(w1, reinterpret_cast<aim_u32x4 *>(&TBW(h, 4)));
+                __builtin_nontemporal_store(w1, reinterpret_cast<aim_u32x4 *>(&TBW(h, NDQ - 4)));
             }
         };
         // plen >= tlen + 2 (score-only): the last row's tail cells v = W + c, c = 1 .. ntail, right after that row (nw.c:137-145 with the flat indices resolved: the
@@ -402,7 +418,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
-inline size_t nw_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * 8 * 4 * kWave; }   // 8 dwords of direction bits per row and lane
+inline size_t nw_reg_slab_bytes(int npk, int read_size) { return (size_t)(read_size + 2) * (npk > 64 ? 12 : 8) * 4 * kWave; }   // 8 (12) dwords of direction bits per row and lane
 
 
 // =====================================================================================================================================
@@ -847,6 +863,9 @@ void nw_reg_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs
     else if (npk == 46) AIM_NWREG(46);
     else if (npk == 54) AIM_NWREG(54);
     else if (npk == 62) AIM_NWREG(62);
+    else if (npk == 70) AIM_NWREG(70);
+    else if (npk == 78) AIM_NWREG(78);
+    else if (npk == 86) AIM_NWREG(86);
 #undef AIM_NWREG
 }
 #else

@@ -93,7 +93,8 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 400, 20000))) == b"dp_wave_kernel"                      # beyond 16 384 columns
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_reg_kernel"                           # round 4: rows in registers up to READ_SIZE 128 (112 with CIGAR)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 120, backtrace=True))) == b"nw_reg_kernel"          # round 5: READ_SIZE 120 / 128 with CIGAR too (l = 100, e = 10 %)
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 136))) == b"nw_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 160, backtrace=True))) == b"nw_reg_kernel"         # (l = 150: the pattern row in LDS, 12 dwords of direction bits)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184))) == b"nw_lane_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_reg_kernel"                          # round 5: M and I rows in registers up to READ_SIZE 128
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 112, backtrace=True))) == b"swg_reg_kernel"       # (int16 cells too)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 160, swg_w16=True))) == b"swg_reg_kernel"            # (l = 150, int16 cells: the pattern row in LDS, M and I in 154 registers)
@@ -232,7 +233,7 @@ def test_round4_plan_shapes(built):
             assert l.startswith("genasm_wave_kernel") and "grid=%d " % grid in l and "lds=4160" in l, l
         assert plan(engine.make_params("nw", 4, 128), 1 << 20).startswith("nw_reg_kernel")
         assert plan(engine.make_params("nw", 4, 128, backtrace=True), 1 << 20).startswith("nw_reg_kernel")     # round 5: 62 registers = the 8 dwords of direction bits a row has
-        assert plan(engine.make_params("nw", 4, 136, backtrace=True), 1 << 20).startswith("nw_lane_kernel")
+        assert plan(engine.make_params("nw", 4, 184, backtrace=True), 1 << 20).startswith("nw_lane_kernel")
         assert plan(engine.make_params("nw", 4, 48), 1 << 20).startswith("nw_reg_kernel") and plan(engine.make_params("swg", 4, 88), 1 << 20).startswith("swg_reg_kernel")
         assert plan(engine.make_params("nw", 4, 112, backtrace=True), 1 << 20).startswith("nw_reg_kernel")
         assert plan(engine.make_params("nw", 4, 112, gap=60), 1 << 20).startswith("nw_lane_kernel")     # costs too large for INF = 16 000 to stay out of reach
