@@ -421,7 +421,7 @@ def main():
         kname = lib.aim_kernel_name(C.byref(params)).decode()
         plan_buf = C.create_string_buffer(512)
         capi.check(lib.aim_plan_describe(C.byref(params), B, plan_buf, len(plan_buf)))
-        traffic = pmc_traffic(kname, n, args.io) if (headline and not args.backtrace) else None
+        traffic = pmc_traffic(kname, n, args.io + ("+cigar" if args.backtrace else "")) if headline else None   # (the CIGAR instantiation has a summary of its own)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                     "traffic_unit": "bytes/launch", "traffic_source": traffic[1] if traffic else None,

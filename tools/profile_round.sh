@@ -8,6 +8,9 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 tools/pmc_summary.py --out $P/wfa_lane_pmc_summary.json --kernel wfa_lane_kernel --pairs 4194304 --alg-bytes 905968812 --fetch-x2 --io compact \
    --note "Cross-check: 4194304 pairs x (224 B rows + 8 B request) = 973.1 MB read, x 8 B result = 33.6 MB written." \
    -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-default-io > $O/pmc_lane.log 2>&1; tail -1 $O/pmc_lane.log
+python3 tools/pmc_summary.py --out $P/wfa_lane_cigar_pmc_summary.json --kernel wfa_lane_kernel --pairs 1048576 --alg-bytes 331699290 --fetch-x2 --io compact+cigar \
+   --note "bench.py --backtrace --pairs 1048576: the headline kernel's CIGAR instantiation (8-byte requests in, 24-byte results + ops rows out, only the printable piece of a row prefilled); algorithmic bytes as bench.py counts them: sequence bytes + 16 B per pair + the operations produced." \
+   -- python3 bench.py --backtrace --pairs 1048576 --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --no-default-io > $O/pmc_lane_cigar.log 2>&1; tail -1 $O/pmc_lane_cigar.log
 python3 tools/pmc_summary.py --out $P/wfa_group_pmc_summary.json --kernel wfa_group_kernel --pairs 65536 \
    --note "cfg3: WFA-adaptive l=1000 e=5% with CIGAR, 65536 pairs; per-lane int16 LDS/HBM traffic: FETCH_SIZE kept raw (uncalibrated width)." \
    -- python3 tools/bench_configs.py wfa_l1000_e5_cigar > $O/pmc_group.log 2>&1; tail -1 $O/pmc_group.log
