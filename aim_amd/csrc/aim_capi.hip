@@ -29,6 +29,7 @@
 #include "dp_wave.hpp"
 #include "dp_strip.hpp"
 #include "dp_reg.hpp"
+#include "dp_group.hpp"
 #include "batch_io.hpp"
 #include "genasm_wave.hpp"
 
@@ -56,7 +57,7 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // launch planning
 // ---------------------------------------------------------------------------
-enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6, K_DP_STRIP = 7, K_DP_REG = 8 };
+enum KernelId { K_WFA_WAVE = 0, K_WFA_LANE = 1, K_DP_LANE = 2, K_DP_WAVE = 3, K_WFA_GROUP = 4, K_GENASM = 5, K_WFA_LANE_PK = 6, K_DP_STRIP = 7, K_DP_REG = 8, K_DP_GROUP = 9 };
 
 // What a launch is asked to consume / produce besides the default ABI (ASCII rows in, result_t + ops rows out). A plan
 // honours a mode bit only when its kernel can (Plan::pk / Plan::emits_runs); otherwise the caller runs the conversion
@@ -81,7 +82,8 @@ struct Plan {
     uint32_t chunk_pairs;   // K_WFA_GROUP + BACKTRACE: pairs per compute + traceback launch (their history regions fit the scratch bound)
     aim::GroupCfg gcfg;     // K_WFA_GROUP
     int group_g;
-    int strip_k;            // K_DP_STRIP: cells per lane
+    int strip_k;            // K_DP_STRIP: cells per lane (K_DP_GROUP: of the fallback launch; 0 = its fallback is a dp_lane.hpp kernel)
+    uint32_t fb_block;      // K_DP_GROUP: workgroup size of a dp_strip fallback
     bool pack_first;        // K_WFA_LANE_PK on a batch of ASCII rows: pack_rows_kernel first (scratch: to-do | flag bits | packed P | packed T | general kernel)
     size_t pack_bytes;      // ... bytes of the flag bits + both packed arrays
     bool pk;                // the kernel reads the packed rows of the batch itself (no unpack pass)
@@ -120,6 +122,7 @@ aim::Knobs read_knobs()
     k.dpl_per_cu = env_int("AIM_DPL_PER_CU", -1);
     k.no_nw_reg = env_flag("AIM_NO_NW_REG");
     k.no_swg_reg = env_flag("AIM_NO_SWG_REG");
+    k.no_dp_group = env_flag("AIM_NO_DP_GROUP");
     k.dbg_flags = env_int("AIM_DEBUG_FLAGS", 0);
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
@@ -393,6 +396,33 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         pl->scratch_total = (size_t)(per * grid);
         return AIM_OK;
     }
+    // NW / SWG medium reads, score-only: G lanes per pair (dp_group.hpp); empty sequences and plen > 2 tlen reach nw_lane / swg_lane (READ_SIZE <= 320) or
+    // dp_strip_kernel (to-do mode) through the to-do list. [fallback kernel's scratch | to-do region]
+    if (aim::dp_group_supported(p, kn)) {
+        Plan fb;
+        memset(&fb, 0, sizeof fb);
+        if (p.read_size <= 320) {
+            aim::Knobs kq = kn;
+            kq.dpl_seq_lds = 0;   // the to-do pass: every lane loads its own pair's rows from global memory (the listed pairs are not consecutive)
+            kq.dpl_no_reg = 0;
+            if (!aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds))
+                return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+            fb.strip_k = 0;
+        } else if (!aim::dp_strip_plan(p, n_pairs, budget / 2, kn, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.strip_k, &fb.pool_cap))
+            return fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
+        pl->kid = K_DP_GROUP;
+        pl->block = 64;
+        aim::dp_group_plan(p, n_pairs, kn, &pl->grid, &pl->lds);
+        pl->scratch_per_wg = fb.scratch_per_wg;
+        pl->fb_grid = fb.grid;
+        pl->fb_block = fb.block;
+        pl->fb_lds = fb.lds;
+        pl->strip_k = fb.strip_k;
+        pl->pool_cap = fb.pool_cap;
+        pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
+        pl->scratch_total = ((fb.scratch_total + 255) & ~(size_t)255) + pl->todo_bytes;
+        return AIM_OK;
+    }
     // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
     if (p.read_size > 320 || kn.force_dpwave) {
         const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
@@ -493,6 +523,7 @@ const char *kernel_name(const Plan &pl, const aim_params_t &p)
     case K_DP_REG: return p_is_nw(&p) ? "nw_reg_kernel" : "swg_reg_kernel";
     case K_DP_WAVE: return "dp_wave_kernel";
     case K_DP_STRIP: return "dp_strip_kernel";
+    case K_DP_GROUP: return "dp_group_kernel";
     case K_GENASM: return "genasm_wave_kernel";
     }
     return "";
@@ -509,6 +540,7 @@ int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint6
     else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
     else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
     else if (pl.kid == K_DP_REG) snprintf(extra, sizeof extra, " fb_grid=%u fb_lds=%zu", pl.fb_grid, pl.fb_lds);
+    else if (pl.kid == K_DP_GROUP) snprintf(extra, sizeof extra, " lanes_per_pair=%d fb_grid=%u fb_block=%u fb_lds=%zu", aim::dp_group_lanes(p.read_size), pl.fb_grid, pl.fb_block, pl.fb_lds);
     return snprintf(out, cap, "%s n=%u grid=%u block=%u lds=%zu scratch=%zu budget=%llu%s", kernel_name(pl, p), n_pairs, pl.grid,
                     pl.block, pl.lds, pl.scratch_total, (unsigned long long)budget, extra);
 }
@@ -762,6 +794,26 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         kq.dpl_no_reg = 0;
         ka.dbg_lds_bytes = (uint32_t)pl.fb_lds;
         aim::dp_lane_launch(p, kq, pl.fb_grid, pl.fb_lds, false, ka, stream);
+        break;
+    }
+    case K_DP_GROUP: {
+        // [fallback kernel's scratch | to-do region]: count zeroed per launch; the group kernel; then the literal-capable kernel over the pairs it left
+        uint32_t *todo_d = reinterpret_cast<uint32_t *>((char *)d_scratch + (pl.scratch_total - pl.todo_bytes));
+        HIP_TRY(hipMemsetAsync(todo_d, 0, 64, stream));
+        ka.todo = todo_d;
+        aim::dp_group_launch(p, pl.grid, pl.lds, ka, stream);
+        HIP_TRY(hipGetLastError());
+        ka.dbg_lds_bytes = (uint32_t)pl.fb_lds;
+        if (pl.strip_k == 0) {
+            aim::Knobs kq = kn;
+            kq.dpl_seq_lds = 0;
+            kq.dpl_no_reg = 0;
+            aim::dp_lane_launch(p, kq, pl.fb_grid, pl.fb_lds, false, ka, stream);
+        } else {
+            HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.fb_grid * pl.scratch_per_wg, 0, 256, stream));
+            ka.pool_cap = pl.pool_cap;
+            aim::dp_strip_launch(p, pl.strip_k, pl.fb_grid, pl.fb_block, pl.fb_lds, ka, stream);
+        }
         break;
     }
     case K_DP_WAVE:
@@ -1428,9 +1480,9 @@ int aim_set_fallback_pairs(aim_set_t *set, uint32_t device, uint32_t *n_fallback
     if (!s.launched) return fail(AIM_ESTATE, "device %d has not been launched", d.dev);
     *n_fallback = 0;
     const Plan &pl = s.plan_last;   // the plan the launch actually followed, not a re-plan
-    if ((pl.kid != K_WFA_GROUP && pl.kid != K_DP_REG && !pl.pack_first) || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
+    if ((pl.kid != K_WFA_GROUP && pl.kid != K_DP_REG && pl.kid != K_DP_GROUP && !pl.pack_first) || s.n_pairs == 0) return AIM_OK;   // wfa_lane_kernel has no fallback: it aligns every pair itself
     HIP_TRY(hipSetDevice(d.dev));
-    const char *count_at = static_cast<const char *>(s.d_scratch) + (pl.kid == K_DP_REG ? pl.scratch_total - pl.todo_bytes : 0);   // the to-do count
+    const char *count_at = static_cast<const char *>(s.d_scratch) + ((pl.kid == K_DP_REG || pl.kid == K_DP_GROUP) ? pl.scratch_total - pl.todo_bytes : 0);   // the to-do count
     HIP_TRY(hipMemcpy(n_fallback, count_at, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return AIM_OK;
 }

@@ -1,0 +1,317 @@
+// dp_group.hpp -- NW / SWG on MEDIUM reads (READ_SIZE 177 .. 1024: between the per-lane register kernels of dp_reg.hpp and the multi-wavefront strips
+// of dp_strip.hpp): G CONSECUTIVE LANES OWN A PAIR, 64 / G pairs per wavefront, every lane K = 32 consecutive cells of its pair's row in registers as
+// packed int16 pairs -- dp_strip.hpp's row body (previous row in registers, two cells per vector instruction, the in-row gap chain as a prefix minimum)
+// with the strip boundaries INSIDE the wavefront: what crosses a lane boundary travels by DPP, the prefix minimum over a pair's lanes is ONE wave scan on
+// keys that carry the pair's rank in their high bits, and nothing waits for a mailbox. Round 5: the length sweep (profiles/r05/length_sweep.txt) showed
+// l = 180 .. 700 at 300 - 1 600 GCUPS (NW) / 180 - 840 (SWG) on nw_lane / swg_lane / single-wavefront strips, against 5 500 at l = 150 and 2 000 - 2 900
+// from l = 1000 up.
+//
+// Same results as nw_compute / swg_compute (NW/DPU-WRAM/dpu/nw.c:109-153, SWG/DPU-WRAM/dpu/swg.c:121-171) by dp_strip.hpp's argument (dp_strip_exact_ok:
+// no int16 store of the reference can wrap, so the prefix-minimum form equals its cell-by-cell arithmetic), including the flat table's aliasing for
+// plen > tlen: cell (h, W) is the boundary cell of row h + 1 (computed by the lane that owns column W - 1, handed to the pair's lanes by ds_bpermute),
+// and the last row's tail cells are walked by the pair's first lane over the row's LDS image. Pairs outside (a sequence empty, plen > 2 tlen) go to the
+// to-do list: dp_lane.hpp's kernels (READ_SIZE <= 320) or dp_strip_kernel in to-do mode drain it behind this kernel.
+#pragma once
+
+#include "aim_device.hpp"
+#include "dp_strip.hpp"
+#include "wfa_lane.hpp"   // LANE_TODO_*
+#include "dp_lane.hpp"    // swg_cell_bytes
+
+namespace aim {
+
+constexpr int kDpgKP = 16;                    // packed registers per lane and row (32 columns)
+constexpr int kDpgMinRs = 177, kDpgMaxRs = 1024;
+
+__host__ __device__ inline int dp_group_lanes(int read_size) { return (read_size + 2 * kDpgKP - 1) / (2 * kDpgKP); }   // G: lanes per pair (6 .. 32)
+
+// LDS of one pair slot: pattern | text | the last row's M, I (int16) | 16 B {M, D of cell W - 1, M of the cell above it}
+__host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
+__host__ __device__ inline size_t dp_group_lds_bytes(int rs) { return (size_t)(kWave / dp_group_lanes(rs)) * (size_t)dp_group_slot_bytes(rs) + 64; }
+
+inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
+{
+    if (kn.no_dp_group || kn.force_dpwave || kn.dpw_legacy) return false;
+    if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG) return false;
+    if (p.read_size < kDpgMinRs || p.read_size > kDpgMaxRs) return false;
+    if (p.flags & AIM_FLAG_BACKTRACE) return false;
+    if (p.algo == AIM_ALGO_SWG && swg_cell_bytes(p) == 1) return false;   // int8 cells wrap by design: the literal kernels
+    return dp_strip_exact_ok(p, false);
+}
+
+template <int ALGO, bool BT, int KP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dp_group_kernel(KArgs a, int G)
+{
+    static_assert(!BT, "score-only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    debug_poison_lds(a, smem);
+    constexpr bool SWG = (ALGO == AIM_ALGO_SWG);
+    constexpr int K = 2 * KP;
+    const int lane = threadIdx.x;
+    const int rs = a.p.read_size;
+    const int P = kWave / G;                                   // pairs per wavefront
+    const int q = lane / G, g = lane - q * G;                  // pair slot, lane of the pair
+    const bool lane_on = q < P;                                // (64 - P G lanes idle)
+    const int seqcap = (rs + 79) & ~15, rowcap = (rs + 47) & ~7;
+    char *slot = smem + (size_t)(lane_on ? q : 0) * (size_t)dp_group_slot_bytes(rs);
+    unsigned char *ldsP = reinterpret_cast<unsigned char *>(slot), *ldsT = ldsP + seqcap;
+    int16_t *rowM = reinterpret_cast<int16_t *>(ldsT + seqcap), *rowI = rowM + rowcap;
+    int *tl = reinterpret_cast<int *>(rowI + rowcap);
+    uint32_t *todo = const_cast<uint32_t *>(a.todo);
+    const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
+    const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
+    const int GE = SWG ? E : GD;                               // step of the in-row chain
+    const int v0 = 1 + g * K;                                  // first column of this lane
+    const uint32_t n_units = (a.n_pairs + (uint32_t)P - 1u) / (uint32_t)P;
+    const int rank_hi = lane_on ? (P - 1 - q) : (P + 1);       // scan keys: pairs on the left carry LARGER high bits and lose every minimum
+
+    for (uint32_t it = 0;; ++it) {
+        uint32_t unit;
+        if (!xcd_unit(n_units, it, &unit)) break;
+        const uint32_t pair = unit * (uint32_t)P + (uint32_t)q;
+        const bool valid = lane_on && pair < a.n_pairs;
+        aim_request_t rq;
+        rq.pattern_len = rq.text_len = 0; rq.padding = 0; rq.idx = 0;
+        if (valid) rq = load_request(a, pair);
+        int plen = rq.pattern_len, tlen = rq.text_len;
+        // not this kernel's: an empty sequence, aliasing beyond one row (plen > 2 tlen), lengths beyond the rows (the literal kernels report those)
+        const bool outl = valid && (plen < 1 || tlen < 1 || plen > 2 * tlen || plen > rs || tlen > rs);
+        {
+            const unsigned long long m = __ballot(outl && g == 0), below = (1ull << lane) - 1ull;
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (outl && g == 0) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(m & below)] = pair + a.pair_base;
+            }
+        }
+        const bool act = valid && !outl;
+        if (!act) { plen = 0; tlen = 0; }
+        const int hmax = -wave_min_i32(-tlen);                 // rows of this wavefront (wave-uniform)
+        if (hmax == 0) continue;
+        const int W = tlen + 1;
+        __syncthreads();                                       // (single wavefront: the previous unit's tail walks are done with the slots)
+        if (act) {   // sequences into the pair's slot, zero beyond their length (dp_strip.hpp)
+            const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
+            const unsigned char *gT = reinterpret_cast<const unsigned char *>(a.texts + (uint64_t)pair * rs);
+            for (int i = g * 4; i < seqcap; i += G * 4) {
+                uint32_t wp = 0, wt = 0;
+                if (i + 3 < plen && (rs & 3) == 0) wp = *reinterpret_cast<const uint32_t *>(gP + i);
+                else for (int b = 0; b < 4; ++b) if (i + b < plen) wp |= (uint32_t)gP[i + b] << (8 * b);
+                if (i + 3 < tlen && (rs & 3) == 0) wt = *reinterpret_cast<const uint32_t *>(gT + i);
+                else for (int b = 0; b < 4; ++b) if (i + b < tlen) wt |= (uint32_t)gT[i + b] << (8 * b);
+                *reinterpret_cast<uint32_t *>(ldsP + i) = wp;
+                *reinterpret_cast<uint32_t *>(ldsT + i) = wt;
+            }
+        }
+        __syncthreads();
+        const int Rr = min(plen, W - 1);                       // regular columns 1 .. Rr
+        const bool has_tail = act && plen >= W;
+        const bool any_tail = __ballot(has_tail) != 0ull;      // wave-uniform
+        dps2 Mp[KP], Ip[KP], cD[KP], vmask[KP];
+        int nvalid = Rr - v0 + 1;                              // cells of this lane inside the row
+        nvalid = nvalid < 0 ? 0 : (nvalid > K ? K : nvalid);
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int va = v0 + 2 * j, vb = va + 1;
+            dps2 m, d;
+            if (SWG) { m.x = (short)(O + va * E); m.y = (short)(O + vb * E); }
+            else { m.x = (short)(va * GD); m.y = (short)(vb * GD); }
+            d.x = (short)(va * GE); d.y = (short)(vb * GE);
+            Mp[j] = m;
+            Ip[j] = dps_splat(MAXS);
+            cD[j] = d;
+            dps2 vm; vm.x = (short)((2 * j < nvalid) ? -1 : 0); vm.y = (short)((2 * j + 1 < nvalid) ? -1 : 0);
+            uint32_t vmb = dps_bits(vm);
+            opaque(vmb);
+            vmask[j] = dps_from(vmb);
+        }
+        uint32_t pc16[KP];                                     // this lane's pattern characters as 16-bit fields
+#pragma unroll
+        for (int j = 0; j < KP; ++j) pc16[j] = (uint32_t)ldsP[v0 - 1 + 2 * j] | ((uint32_t)ldsP[v0 + 2 * j] << 16);
+        const bool tail_owner = has_tail && v0 <= Rr && Rr < v0 + K;   // this lane owns column W - 1 = Rr
+        const int tail_t = Rr - v0;                                     // ... as its cell tail_t
+        const int own_addr = (q * G + (has_tail ? (Rr - 1) / K : g)) * 4;   // ds_bpermute address of the pair's tail owner (no tail: oneself)
+        const int pchW = has_tail ? (int)ldsP[W - 1] : 0;
+        int BM = 0, BI = 0, BD = 0, BMprev = 0;                         // B(h), and B(h - 1).M (row 0: 0)
+        int nBM = 0, nBI = 0, nBD = 0;                                  // B(h + 1) of a pair with tail cells, as its owner lane computed it
+        const dps2 OEp = dps_splat(OE), Ep = dps_splat(E), GIp = dps_splat(GI);
+        dps2 c1[KP];                                                    // G = A - c1: SWG (v + 1) e - (o + e); NW v g
+#pragma unroll
+        for (int j = 0; j < KP; ++j) c1[j] = cD[j] + dps_splat(SWG ? (E - OE) : 0);
+        const dps2 costD = dps_splat(MISMATCH - (SWG ? MATCH : 0)), costM = dps_splat(SWG ? MATCH : 0);
+        uint32_t ones = 0x00010001u;
+        opaque(ones);
+        int tailM_M = 0, tailM_D = 0, tail_diag = 0;                    // the tail owner's {M, D} of cell (h, W - 1) and M of (h - 1, W - 1)
+        auto pick = [&](const dps2 (&arr)[KP], int t) {                 // cell t of a packed register row, t per lane: a binary select tree (dp_strip.hpp)
+            uint32_t v[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) v[j] = dps_bits(arr[j]);
+            const int d = t >> 1;
+#pragma unroll
+            for (int step = 1; step < KP; step <<= 1) {
+                const bool odd = (d & step) != 0;
+#pragma unroll
+                for (int j = 0; j + step < KP; j += 2 * step) v[j] = odd ? v[j + step] : v[j];
+            }
+            const uint32_t w = v[0];
+            return (t & 1) ? (int)(int16_t)(w >> 16) : (int)(int16_t)(w & 0xffffu);
+        };
+
+        for (int h = 1; h <= hmax; ++h) {
+            const uint32_t tch2 = (uint32_t)ldsT[h - 1] * 0x00010001u;
+            // ---- diagonal input of this lane's first cell: M[h-1][v0 - 1] (the lane on the left; the pair's first lane: B(h - 1).M)
+            int dfirst = __builtin_amdgcn_update_dpp(0, (int)Mp[KP - 1].y, 0x138, 0xf, 0xf, false);   // wave_shr:1
+            if (g == 0) dfirst = BMprev;
+            // ---- pre-carry: I, A, G of this lane's K cells, two per instruction
+            dps2 A[KP], Iv[KP], Gv[KP];
+            dps2 gmin = dps_splat(kInf16);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const uint32_t up = dps_bits(Mp[j]);
+                const uint32_t prev = j ? dps_bits(Mp[j - 1]) : ((uint32_t)(uint16_t)dfirst << 16);
+                const dps2 diag = dps_from(__builtin_amdgcn_alignbit(up, prev, 16));       // {M[v-1], M[v]} of the previous row
+                const dps2 f = dps_from(pk_ne01(pc16[j], tch2, ones));
+                const dps2 sub = f * costD + (diag + costM);
+                dps2 ins;
+                if (SWG) ins = dps_min(Mp[j] + OEp, Ip[j] + Ep);
+                else ins = Mp[j] + GIp;
+                Iv[j] = ins;
+                A[j] = dps_min(sub, ins);
+                dps2 gg = A[j] - c1[j];
+                gg = dps_from((dps_bits(gg) & dps_bits(vmask[j])) | (0x7fff7fffu & ~dps_bits(vmask[j])));
+                Gv[j] = gg;
+                gmin = dps_min(gmin, gg);
+            }
+            // ---- exclusive prefix minimum over the lanes of the pair: one wave scan on (rank of the pair, value) keys
+            const int lane_min = min((int)gmin.x, (int)gmin.y);
+            int total;
+            const int key = (rank_hi << 16) | (lane_min + 0x8000);
+            const int sk = wave_excl_scan_min(key, lane, &total);
+            const int lane_pre = ((sk >> 16) == rank_hi) ? (sk & 0xffff) - 0x8000 : kDpInf;
+            // ---- B(h): the boundary cell of this row
+            if (h == 1 || !has_tail) {
+                if (SWG) { BM = O + h * E; BI = BM; BD = MAXS; }
+                else { BM = h * GI; BI = BD = 0; }
+            } else { BM = nBM; BI = nBI; BD = nBD; }
+            const int carry_in = SWG ? min(BD, BM + O) : BM;   // G[0]
+            // ---- post-carry: D / R and M of the K cells; the new row replaces the old one in the registers
+            const int pre = min(carry_in, lane_pre);
+            dps2 c = dps_splat(pre);
+            dps2 Do[KP];
+            const int diag_keep = any_tail ? pick(Mp, tail_t) : 0;   // M[h-1][W-1] (before the row is replaced)
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                dps2 s_; s_.x = kInf16; s_.y = Gv[j].x;
+                const dps2 prej = dps_min(c, s_);                      // {pre(2j), pre(2j+1)}
+                c = dps_splat(min((int)prej.y, (int)Gv[j].y));
+                Do[j] = prej + cD[j];
+                Mp[j] = dps_min(A[j], Do[j]);
+                if (SWG) Ip[j] = Iv[j];
+            }
+            BMprev = BM;
+            // ---- first tail cell (h, W): the boundary cell of row h + 1 (rows before the last; the last row's tail is walked below)
+            if (any_tail) {
+                const int upM = pick(Mp, tail_t), upD = pick(Do, tail_t);
+                int cM = 0, cI = 0, cDd = 0;
+                if (tail_owner && h <= tlen) {
+                    tailM_M = upM; tailM_D = upD; tail_diag = diag_keep;
+                    const int tch = (int)(tch2 & 0xffu);
+                    if (SWG) {
+                        cDd = min(upM + OE, upD + E);
+                        cI = min(BM + OE, BI + E);
+                        cM = min(diag_keep + ((pchW == tch) ? MATCH : MISMATCH), min(cI, cDd));
+                    } else {
+                        cI = BM + GI; cDd = upM + GD;
+                        cM = min(diag_keep + ((pchW == tch) ? 0 : MISMATCH), min(cI, cDd));
+                    }
+                }
+                nBM = __builtin_amdgcn_ds_bpermute(own_addr, cM);
+                nBI = __builtin_amdgcn_ds_bpermute(own_addr, cI);
+                nBD = __builtin_amdgcn_ds_bpermute(own_addr, cDd);
+            }
+            // ---- a pair's last row: its regular part into the slot (score; the tail walk reads it)
+            if (__ballot(act && h == tlen) != 0ull) {
+                if (act && h == tlen) {
+#pragma unroll
+                    for (int t = 0; t < K; ++t)
+                        if (t < nvalid) {
+                            rowM[v0 + t] = (t & 1) ? Mp[t >> 1].y : Mp[t >> 1].x;
+                            if (SWG) rowI[v0 + t] = (t & 1) ? Ip[t >> 1].y : Ip[t >> 1].x;
+                        }
+                    if (tail_owner) { tl[0] = tailM_M; tl[1] = tailM_D; tl[2] = tail_diag; }
+                    if (g == 0) { rowM[0] = (int16_t)BM; if (SWG) rowI[0] = (int16_t)BI; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- after the last row: the reference's tail cells v = W .. plen of the LAST row, sequentially, by the pair's first lane (dp_strip.hpp)
+        if (act && g == 0) {
+            int score;
+            if (has_tail) {
+                const int h = tlen;
+                const int tch = ldsT[h - 1];
+                const int bM = rowM[0], bI = SWG ? (int)rowI[0] : 0;
+                int upM = tl[0], upD = tl[1];
+                int lastM = 0;
+                for (int v = W; v <= plen; ++v) {
+                    int leftM, leftI, diagM;
+                    if (v == W) { leftM = bM; leftI = bI; diagM = tl[2]; }
+                    else {
+                        leftM = rowM[v - W];
+                        leftI = SWG ? (int)rowI[v - W] : 0;
+                        diagM = (v - 1 == W) ? bM : (int)rowM[v - 1 - W];
+                    }
+                    const int pch = ldsP[v - 1];
+                    int cM, cI, cDd;
+                    if (SWG) {
+                        cDd = min(upM + OE, upD + E);
+                        cI = min(leftM + OE, leftI + E);
+                        cM = min(diagM + ((pch == tch) ? MATCH : MISMATCH), min(cI, cDd));
+                    } else {
+                        cI = leftM + GI; cDd = upM + GD;
+                        cM = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(cI, cDd));
+                    }
+                    upM = cM; upD = cDd;
+                    lastM = cM;
+                }
+                score = lastM;
+            } else score = (int)rowM[plen];
+            aim_result_t r;
+            r.max_operations = plen + tlen;
+            r.begin_offset = plen + tlen - 1;
+            r.end_offset = plen + tlen;
+            r.score = score;
+            r.status = AIM_PAIR_OK;
+            r.idx = rq.idx;
+            store_result(a, pair, r);
+        }
+    }
+}
+
+// [to-do region only] one wavefront per workgroup, two per SIMD (the row body holds ~10 arrays of KP registers)
+inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, size_t *lds)
+{
+    const int G = dp_group_lanes(p.read_size), P = kWave / G;
+    *lds = dp_group_lds_bytes(p.read_size);
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
+    uint32_t g = resident_grid(kn, per_cu);
+    const uint32_t n_units = (n_pairs + (uint32_t)P - 1u) / (uint32_t)P;
+    const uint32_t need = ((n_units + 7u) / 8u) * 8u;
+    if (g > need) g = need < 8u ? 8u : need;
+    *grid = g;
+    return true;
+}
+
+#ifdef AIM_TU_DP_GROUP
+void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
+{
+    const int G = dp_group_lanes(p.read_size);
+    if (p.algo == AIM_ALGO_NW) hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_NW, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+    else hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_SWG, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+}
+#else
+void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
+#endif
+
+}  // namespace aim

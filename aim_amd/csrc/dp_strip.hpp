@@ -21,6 +21,7 @@
 
 #include "aim_device.hpp"
 #include "dp_wave.hpp"
+#include "wfa_lane.hpp"   // LANE_TODO_* (to-do mode)
 
 namespace aim {
 
@@ -250,9 +251,12 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
     const bool exact_ok = dp_strip_exact_ok(a.p, false);
     const int v0 = 1 + (wv * kWave + lane) * K;  // first column of this lane
 
+    // to-do mode (a.todo set: the pairs dp_group_kernel left, dp_group.hpp): the units are the listed pairs
+    const uint32_t n_work = a.todo ? a.todo[LANE_TODO_COUNT] : a.n_pairs;
     for (uint32_t it = 0;; ++it) {
         uint32_t pair;
-        if (!xcd_unit(a.n_pairs, it, &pair)) break;
+        if (!xcd_unit(n_work, it, &pair)) break;
+        if (a.todo) pair = a.todo[LANE_TODO_LIST + pair] - a.pair_base;
         const aim_request_t rq = load_request(a, pair);
         const int plen = rq.pattern_len, tlen = rq.text_len;
         const unsigned char *gP = reinterpret_cast<const unsigned char *>(a.patterns + (uint64_t)pair * rs);
