@@ -84,6 +84,7 @@ struct Plan {
     int group_g;
     int strip_k;            // K_DP_STRIP: cells per lane (K_DP_GROUP: of the fallback launch; 0 = its fallback is a dp_lane.hpp kernel)
     uint32_t fb_block;      // K_DP_GROUP: workgroup size of a dp_strip fallback
+    uint64_t fb_scratch_per_wg;   // K_DP_GROUP: ... and its slab size (the fallback's scratch starts at offset 0 like the group kernel's: they never run together)
     bool pack_first;        // K_WFA_LANE_PK on a batch of ASCII rows: pack_rows_kernel first (scratch: to-do | flag bits | packed P | packed T | general kernel)
     size_t pack_bytes;      // ... bytes of the flag bits + both packed arrays
     bool pk;                // the kernel reads the packed rows of the batch itself (no unpack pass)
@@ -396,8 +397,8 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         pl->scratch_total = (size_t)(per * grid);
         return AIM_OK;
     }
-    // NW / SWG medium reads, score-only: G lanes per pair (dp_group.hpp); empty sequences and plen > 2 tlen reach nw_lane / swg_lane (READ_SIZE <= 320) or
-    // dp_strip_kernel (to-do mode) through the to-do list. [fallback kernel's scratch | to-do region]
+    // NW / SWG medium reads: G lanes per pair (dp_group.hpp); empty sequences and plen > 2 tlen reach nw_lane / swg_lane (READ_SIZE <= 320) or
+    // dp_strip_kernel (to-do mode) through the to-do list. [the pairs' direction-bit slabs OR, afterwards, the fallback kernel's scratch | to-do region]
     if (aim::dp_group_supported(p, kn)) {
         Plan fb;
         memset(&fb, 0, sizeof fb);
@@ -412,15 +413,17 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
             return fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
         pl->kid = K_DP_GROUP;
         pl->block = 64;
-        aim::dp_group_plan(p, n_pairs, kn, &pl->grid, &pl->lds);
-        pl->scratch_per_wg = fb.scratch_per_wg;
+        aim::dp_group_plan(p, n_pairs, kn, &pl->grid, &pl->lds, &pl->scratch_per_wg);
+        while (pl->grid > 8 && pl->scratch_per_wg * pl->grid > budget / 2) pl->grid -= 8;
+        if (pl->scratch_per_wg * pl->grid > budget / 2) return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+        pl->fb_scratch_per_wg = fb.scratch_per_wg;
         pl->fb_grid = fb.grid;
         pl->fb_block = fb.block;
         pl->fb_lds = fb.lds;
         pl->strip_k = fb.strip_k;
         pl->pool_cap = fb.pool_cap;
         pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
-        pl->scratch_total = ((fb.scratch_total + 255) & ~(size_t)255) + pl->todo_bytes;
+        pl->scratch_total = ((std::max<size_t>(fb.scratch_total, (size_t)(pl->scratch_per_wg * pl->grid)) + 255) & ~(size_t)255) + pl->todo_bytes;
         return AIM_OK;
     }
     // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
@@ -804,13 +807,14 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         aim::dp_group_launch(p, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
         ka.dbg_lds_bytes = (uint32_t)pl.fb_lds;
+        ka.scratch_per_wave = pl.fb_scratch_per_wg;
         if (pl.strip_k == 0) {
             aim::Knobs kq = kn;
             kq.dpl_seq_lds = 0;
             kq.dpl_no_reg = 0;
             aim::dp_lane_launch(p, kq, pl.fb_grid, pl.fb_lds, false, ka, stream);
         } else {
-            HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.fb_grid * pl.scratch_per_wg, 0, 256, stream));
+            HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.fb_grid * pl.fb_scratch_per_wg, 0, 256, stream));
             ka.pool_cap = pl.pool_cap;
             aim::dp_strip_launch(p, pl.strip_k, pl.fb_grid, pl.fb_block, pl.fb_lds, ka, stream);
         }

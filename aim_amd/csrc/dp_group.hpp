@@ -27,14 +27,20 @@ __host__ __device__ inline int dp_group_lanes(int read_size) { return (read_size
 
 // LDS of one pair slot: pattern | text | the last row's M, I (int16) | 16 B {M, D of cell W - 1, M of the cell above it}
 __host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
-__host__ __device__ inline size_t dp_group_lds_bytes(int rs) { return (size_t)(kWave / dp_group_lanes(rs)) * (size_t)dp_group_slot_bytes(rs) + 64; }
+constexpr int kDpgTileRows = 64;                 // the traceback's window (dp_traceback_swg_bits): 64 rows x 3 lane words x 16 B
+__host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt = false)
+{
+    return (((size_t)(kWave / dp_group_lanes(rs)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
+}
+// BACKTRACE: a pair's slab of direction bits, dp_strip.hpp's layout with K = 32 -- FLW [READ_SIZE + 3 rows][FS lane words of 16 B], then the boundary cells' bytes [row]
+__host__ __device__ inline int dp_group_fs(int rs) { return rs / (2 * kDpgKP) + 2; }
+__host__ __device__ inline size_t dp_group_slab_bytes(int rs) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs) * 16 + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }
 
 inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
 {
     if (kn.no_dp_group || kn.force_dpwave || kn.dpw_legacy) return false;
     if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG) return false;
     if (p.read_size < kDpgMinRs || p.read_size > kDpgMaxRs) return false;
-    if (p.flags & AIM_FLAG_BACKTRACE) return false;
     if (p.algo == AIM_ALGO_SWG && swg_cell_bytes(p) == 1) return false;   // int8 cells wrap by design: the literal kernels
     return dp_strip_exact_ok(p, false);
 }
@@ -42,7 +48,6 @@ inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
 template <int ALGO, bool BT, int KP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void dp_group_kernel(KArgs a, int G)
 {
-    static_assert(!BT, "score-only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     debug_poison_lds(a, smem);
     constexpr bool SWG = (ALGO == AIM_ALGO_SWG);
@@ -57,6 +62,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     unsigned char *ldsP = reinterpret_cast<unsigned char *>(slot), *ldsT = ldsP + seqcap;
     int16_t *rowM = reinterpret_cast<int16_t *>(ldsT + seqcap), *rowI = rowM + rowcap;
     int *tl = reinterpret_cast<int *>(rowI + rowcap);
+    uint32_t *tile = reinterpret_cast<uint32_t *>(smem + (((size_t)P * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15));   // (BT) the traceback's window
+    const int FS = dp_group_fs(rs);
+    const size_t slab = dp_group_slab_bytes(rs);
+    char *slab0 = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
+    uint32_t *FLW = reinterpret_cast<uint32_t *>(slab0 + (size_t)(lane_on ? q : 0) * slab);                 // (BT) this pair's direction bits
+    unsigned char *BF = reinterpret_cast<unsigned char *>(FLW + (size_t)(rs + 3) * FS * 4);
     uint32_t *todo = const_cast<uint32_t *>(a.todo);
     const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
     const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
@@ -104,6 +115,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 *reinterpret_cast<uint32_t *>(ldsT + i) = wt;
             }
         }
+        if (BT && act) {
+            if (SWG) {   // memset(cigar->operations, 'M', 2*READ_SIZE), swg.c:261; row-init boundary cells {M = I = o + h e, D = MAX_SCORE}: the walk only asks whether column 1's D was extended from them
+                uint32_t *o4 = reinterpret_cast<uint32_t *>(a.ops + (uint64_t)pair * 2 * rs);
+                for (int w = g; w < (rs >> 1); w += G) o4[w] = 0x4D4D4D4Du;
+                for (int h = 1 + g; h <= tlen + 1; h += G) BF[h] = (unsigned char)((O + h * E) + O <= MAXS ? 0 : 16);
+            }
+        }
+        if (BT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the tail owner's stores to the same boundary bytes come later in program order: made explicit, dp_strip.hpp)
         __syncthreads();
         const int Rr = min(plen, W - 1);                       // regular columns 1 .. Rr
         const bool has_tail = act && plen >= W;
@@ -165,6 +184,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (g == 0) dfirst = BMprev;
             // ---- pre-carry: I, A, G of this lane's K cells, two per instruction
             dps2 A[KP], Iv[KP], Gv[KP];
+            uint32_t fw[4] = {0u, 0u, 0u, 0u};                 // (BT) the row's direction bits, assembled as the tests become known (layout: dp_traceback_swg_bits)
             dps2 gmin = dps_splat(kInf16);
 #pragma unroll
             for (int j = 0; j < KP; ++j) {
@@ -174,7 +194,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const dps2 f = dps_from(pk_ne01(pc16[j], tch2, ones));
                 const dps2 sub = f * costD + (diag + costM);
                 dps2 ins;
-                if (SWG) ins = dps_min(Mp[j] + OEp, Ip[j] + Ep);
+                if (SWG) {
+                    const dps2 insn = Mp[j] + OEp, inse = Ip[j] + Ep;
+                    ins = dps_min(insn, inse);
+                    if (BT) {   // "I extended": I_up + e < M_up + o + e
+                        const uint32_t sI = __builtin_amdgcn_perm(0u, dps_bits(__builtin_elementwise_sub_sat(inse, insn)), 0x09080c0cu);
+                        fw[j >> 2] |= sI & (0x10100000u << (j & 3));
+                    }
+                }
                 else ins = Mp[j] + GIp;
                 Iv[j] = ins;
                 A[j] = dps_min(sub, ins);
@@ -205,6 +232,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 dps2 s_; s_.x = kInf16; s_.y = Gv[j].x;
                 const dps2 prej = dps_min(c, s_);                      // {pre(2j), pre(2j+1)}
                 c = dps_splat(min((int)prej.y, (int)Gv[j].y));
+                if (BT && SWG) {   // "the next cell's D was extended": pre(v) < G(v)
+                    const uint32_t sD = __builtin_amdgcn_perm(0u, dps_bits(__builtin_elementwise_sub_sat(prej, Gv[j])), 0x0c0c0908u);
+                    fw[j >> 2] |= sD & (0x00001010u << (j & 3));
+                }
                 Do[j] = prej + cD[j];
                 Mp[j] = dps_min(A[j], Do[j]);
                 if (SWG) Ip[j] = Iv[j];
@@ -226,9 +257,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         cM = min(diag_keep + ((pchW == tch) ? 0 : MISMATCH), min(cI, cDd));
                     }
                 }
+                if (BT && tail_owner && h < tlen) {
+                    if (SWG) BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0) | (upD + E < upM + OE ? 4 : 0) | (BI + E < BM + OE ? 8 : 0) | (cM + O <= cDd ? 0 : 16));
+                    else BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0));   // NW: "not D", "not I"
+                }
                 nBM = __builtin_amdgcn_ds_bpermute(own_addr, cM);
                 nBI = __builtin_amdgcn_ds_bpermute(own_addr, cI);
                 nBD = __builtin_amdgcn_ds_bpermute(own_addr, cDd);
+            }
+            // ---- (BT) four direction bits per cell (NW: the first two), one 16-byte store per lane and row
+            if (BT) {
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const uint32_t dA = dps_bits(__builtin_elementwise_sub_sat(A[j], Do[j])), dB = dps_bits(__builtin_elementwise_sub_sat(A[j], Iv[j]));
+                    const uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);
+                    fw[j >> 2] |= w1 & (0x01010101u << (j & 3));
+                }
+                if (act && h <= tlen && nvalid > 0) *reinterpret_cast<uint4 *>(FLW + ((size_t)h * FS + g) * 4) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
             }
             // ---- a pair's last row: its regular part into the slot (score; the tail walk reads it)
             if (__ballot(act && h == tlen) != 0ull) {
@@ -254,6 +299,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const int bM = rowM[0], bI = SWG ? (int)rowI[0] : 0;
                 int upM = tl[0], upD = tl[1];
                 int lastM = 0;
+                int tw_g = -1;                    // (BT) lane word being assembled for the tail cells: row tlen + 1
+                uint32_t tw[4] = {0u, 0u, 0u, 0u};
+                auto tw_flush = [&]() {
+                    if (tw_g >= 0) for (int d = 0; d < 4; ++d) FLW[((size_t)(h + 1) * FS + tw_g) * 4 + d] = tw[d];
+                };
                 for (int v = W; v <= plen; ++v) {
                     int leftM, leftI, diagM;
                     if (v == W) { leftM = bM; leftI = bI; diagM = tl[2]; }
@@ -272,11 +322,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         cI = leftM + GI; cDd = upM + GD;
                         cM = min(diagM + ((pch == tch) ? 0 : MISMATCH), min(cI, cDd));
                     }
+                    if (BT) {   // the direction bits of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array), dp_strip.hpp
+                        const uint32_t nD = cM != cDd ? 1u : 0u, nI = cM != cI ? 1u : 0u, xD = (SWG && upD + E < upM + OE) ? 1u : 0u, xI = (SWG && leftI + E < leftM + OE) ? 1u : 0u;
+                        const int C = v - W;
+                        if (C == 0) BF[h + 1] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | ((!SWG || cM + O <= cDd) ? 0u : 16u));
+                        else {
+                            if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left
+                                const int t = (C - 2) - tw_g * K, j = t >> 1;
+                                tw[j >> 2] |= xD << (8 * (t & 1) + 4 + (j & 3));
+                            }
+                            const int gg = (C - 1) / K, t = (C - 1) - gg * K, j = t >> 1;
+                            if (gg != tw_g) {
+                                tw_flush();
+                                tw_g = gg; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
+                            }
+                            tw[j >> 2] |= (nD << (8 * (t & 1) + (j & 3))) | (nI << (8 * (2 + (t & 1)) + (j & 3))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & 3)));
+                        }
+                    }
                     upM = cM; upD = cDd;
                     lastM = cM;
                 }
+                if (BT) tw_flush();
                 score = lastM;
             } else score = (int)rowM[plen];
+            if (BT) tl[3] = score;
             aim_result_t r;
             r.max_operations = plen + tlen;
             r.begin_offset = plen + tlen - 1;
@@ -284,16 +353,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             r.score = score;
             r.status = AIM_PAIR_OK;
             r.idx = rq.idx;
-            store_result(a, pair, r);
+            if (!BT) store_result(a, pair, r);
+        }
+        if (BT) {   // the tracebacks: the wavefront walks its pairs one after the other (dp_traceback_swg_bits: 64 cells of a diagonal run per step)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int sq = 0; sq < P; ++sq) {
+                const int l0 = sq * G;
+                const int s_act = __builtin_amdgcn_readlane((int)act, l0);
+                if (!s_act) continue;
+                const int s_plen = __builtin_amdgcn_readlane(plen, l0), s_tlen = __builtin_amdgcn_readlane(tlen, l0);
+                const uint32_t s_pair = (uint32_t)__builtin_amdgcn_readlane((int)pair, l0), s_idx = (uint32_t)__builtin_amdgcn_readlane((int)rq.idx, l0);
+                char *sslot = smem + (size_t)sq * (size_t)dp_group_slot_bytes(rs);
+                const unsigned char *sP = reinterpret_cast<const unsigned char *>(sslot), *sT = sP + seqcap;
+                const int *stl = reinterpret_cast<const int *>(sslot + 2 * seqcap + 2 * 2 * rowcap);
+                const uint32_t *sFLW = reinterpret_cast<const uint32_t *>(slab0 + (size_t)sq * slab);
+                const unsigned char *sBF = reinterpret_cast<const unsigned char *>(sFLW + (size_t)(rs + 3) * FS * 4);
+                char *ops = a.ops + (uint64_t)s_pair * 2 * rs;
+                int begin_offset = s_plen + s_tlen - 1;
+                if (!(a.dbg_flags & 1u))
+                    dp_traceback_swg_bits<K, SWG>(a.p, s_plen, s_tlen, FS, sFLW, sBF, sP, sT, tile, kDpgTileRows, ops, lane, begin_offset, false, 0, 0);
+                if (lane == 0) {
+                    aim_result_t r;
+                    r.max_operations = s_plen + s_tlen;
+                    r.begin_offset = begin_offset;
+                    r.end_offset = s_plen + s_tlen;
+                    r.score = stl[3];
+                    r.status = AIM_PAIR_OK;
+                    r.idx = s_idx;
+                    store_result(a, s_pair, r);
+                }
+            }
         }
     }
 }
 
 // [to-do region only] one wavefront per workgroup, two per SIMD (the row body holds ~10 arrays of KP registers)
-inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, size_t *lds)
+inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, size_t *lds, uint64_t *scratch_per_wg)
 {
     const int G = dp_group_lanes(p.read_size), P = kWave / G;
-    *lds = dp_group_lds_bytes(p.read_size);
+    const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    *lds = dp_group_lds_bytes(p.read_size, bt);
+    *scratch_per_wg = bt ? (uint64_t)P * dp_group_slab_bytes(p.read_size) : 256;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
     uint32_t g = resident_grid(kn, per_cu);
     const uint32_t n_units = (n_pairs + (uint32_t)P - 1u) / (uint32_t)P;
@@ -307,8 +408,14 @@ inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &
 void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const int G = dp_group_lanes(p.read_size);
-    if (p.algo == AIM_ALGO_NW) hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_NW, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
-    else hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_SWG, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+    const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    if (p.algo == AIM_ALGO_NW) {
+        if (bt) hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_NW, true, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+        else hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_NW, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+    } else {
+        if (bt) hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_SWG, true, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+        else hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_SWG, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+    }
 }
 #else
 void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);
