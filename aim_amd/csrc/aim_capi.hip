@@ -124,6 +124,7 @@ aim::Knobs read_knobs()
     k.no_nw_reg = env_flag("AIM_NO_NW_REG");
     k.no_swg_reg = env_flag("AIM_NO_SWG_REG");
     k.no_dp_group = env_flag("AIM_NO_DP_GROUP");
+    k.dpg_per_cu = env_int("AIM_DPG_PER_CU", -1);
     k.dbg_flags = env_int("AIM_DEBUG_FLAGS", 0);
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);

@@ -105,6 +105,7 @@ struct Knobs {
     int dbg_flags = 0;            // AIM_DEBUG_FLAGS     diagnostic timing runs (KArgs::dbg_flags)
     bool no_swg_reg = false;      // AIM_NO_SWG_REG=1    SWG short reads: swg_lane_kernel only, no swg_reg_kernel (rows in registers) in front
     bool no_dp_group = false;     // AIM_NO_DP_GROUP=1   NW / SWG medium reads (READ_SIZE 177 .. 1024): nw_lane / swg_lane / dp_strip only, no dp_group_kernel (G lanes per pair) in front
+    int dpg_per_cu = -1;          // AIM_DPG_PER_CU=n    dp_group_kernel: wavefronts per CU (default 8; experiments)
     int nw_reg_per_cu = -1;       // AIM_NW_REG_PER_CU   nw_reg: residency sweep
     int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs
     int group_g = -1;             // AIM_GROUP_G         wfa_group: lanes per pair

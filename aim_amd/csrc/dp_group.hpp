@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const dps2 costD = dps_splat(MISMATCH - (SWG ? MATCH : 0)), costM = dps_splat(SWG ? MATCH : 0);
         uint32_t ones = 0x00010001u;
         opaque(ones);
-        int tailM_M = 0, tailM_D = 0, tail_diag = 0;                    // the tail owner's {M, D} of cell (h, W - 1) and M of (h - 1, W - 1)
+        int tailM_M = 0, tail_diag = 0;                                 // the tail owner's M of cell (h, W - 1) and of (h - 1, W - 1)
+        int upM_prev = SWG ? O + Rr * E : Rr * GD;                      // M[h - 1][W - 1] (row 0: its initial value)
         auto pick = [&](const dps2 (&arr)[KP], int t) {                 // cell t of a packed register row, t per lane: a binary select tree (dp_strip.hpp)
             uint32_t v[KP];
 #pragma unroll
@@ -226,7 +227,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int pre = min(carry_in, lane_pre);
             dps2 c = dps_splat(pre);
             dps2 Do[KP];
-            const int diag_keep = any_tail ? pick(Mp, tail_t) : 0;   // M[h-1][W-1] (before the row is replaced)
 #pragma unroll
             for (int j = 0; j < KP; ++j) {
                 dps2 s_; s_.x = kInf16; s_.y = Gv[j].x;
@@ -242,23 +242,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             BMprev = BM;
             // ---- first tail cell (h, W): the boundary cell of row h + 1 (rows before the last; the last row's tail is walked below)
+            // (its D / R is the in-row chain one column further: the prefix minimum over ALL of the owner lane's cells -- cells beyond the row carry +inf -- plus W steps;
+            //  one select tree per row, for M[h][W-1], instead of three)
             if (any_tail) {
-                const int upM = pick(Mp, tail_t), upD = pick(Do, tail_t);
+                const int upM = pick(Mp, tail_t);
                 int cM = 0, cI = 0, cDd = 0;
                 if (tail_owner && h <= tlen) {
-                    tailM_M = upM; tailM_D = upD; tail_diag = diag_keep;
+                    const int diag_keep = upM_prev;
+                    tailM_M = upM; tail_diag = diag_keep;
                     const int tch = (int)(tch2 & 0xffu);
+                    cDd = (int)c.x + W * GE;
                     if (SWG) {
-                        cDd = min(upM + OE, upD + E);
                         cI = min(BM + OE, BI + E);
                         cM = min(diag_keep + ((pchW == tch) ? MATCH : MISMATCH), min(cI, cDd));
                     } else {
-                        cI = BM + GI; cDd = upM + GD;
+                        cI = BM + GI;
                         cM = min(diag_keep + ((pchW == tch) ? 0 : MISMATCH), min(cI, cDd));
                     }
                 }
+                upM_prev = upM;
                 if (BT && tail_owner && h < tlen) {
-                    if (SWG) BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0) | (upD + E < upM + OE ? 4 : 0) | (BI + E < BM + OE ? 8 : 0) | (cM + O <= cDd ? 0 : 16));
+                    if (SWG) {   // "D extended" of the tail cell = "the next cell's D was extended" of cell W - 1: in this row's bits already
+                        const int tj = tail_t >> 1;
+                        const uint32_t fq = (tj >> 2) == 0 ? fw[0] : ((tj >> 2) == 1 ? fw[1] : ((tj >> 2) == 2 ? fw[2] : fw[3]));
+                        const uint32_t xD = (fq >> (8 * (tail_t & 1) + 4 + (tj & 3))) & 1u;
+                        BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0) | (xD << 2) | (BI + E < BM + OE ? 8 : 0) | (cM + O <= cDd ? 0 : 16));
+                    }
                     else BF[h + 1] = (unsigned char)((cM != cDd ? 1 : 0) | (cM != cI ? 2 : 0));   // NW: "not D", "not I"
                 }
                 nBM = __builtin_amdgcn_ds_bpermute(own_addr, cM);
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                             rowM[v0 + t] = (t & 1) ? Mp[t >> 1].y : Mp[t >> 1].x;
                             if (SWG) rowI[v0 + t] = (t & 1) ? Ip[t >> 1].y : Ip[t >> 1].x;
                         }
-                    if (tail_owner) { tl[0] = tailM_M; tl[1] = tailM_D; tl[2] = tail_diag; }
+                    if (tail_owner) { tl[0] = tailM_M; tl[1] = pick(Do, tail_t); tl[2] = tail_diag; }
                     if (g == 0) { rowM[0] = (int16_t)BM; if (SWG) rowI[0] = (int16_t)BI; }
                 }
             }
@@ -395,7 +404,7 @@ inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
     *lds = dp_group_lds_bytes(p.read_size, bt);
     *scratch_per_wg = bt ? (uint64_t)P * dp_group_slab_bytes(p.read_size) : 256;
-    const uint32_t per_cu = (uint32_t)std::min<size_t>(8, lds_workgroups_per_cu(*lds));
+    const uint32_t per_cu = (uint32_t)std::min<size_t>(kn.dpg_per_cu > 0 ? (size_t)kn.dpg_per_cu : 8, lds_workgroups_per_cu(*lds));
     uint32_t g = resident_grid(kn, per_cu);
     const uint32_t n_units = (n_pairs + (uint32_t)P - 1u) / (uint32_t)P;
     const uint32_t need = ((n_units + 7u) / 8u) * 8u;
