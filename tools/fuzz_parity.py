@@ -49,11 +49,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cells", type=float, default=4e8, help="bound on n * l * l per case (oracle time)")
-    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa", "fused", "dp", "dplane"], default="all",
+    ap.add_argument("--focus", choices=["all", "lane", "genasm", "wfa", "fused", "dp", "dplane", "dpgroup"], default="all",
                     help="'lane': stay inside the one-pair-per-lane kernels' eligibility window (wfa_lane_kernel, wfa_lane_packed_kernel); 'genasm': GenASM only; "
                          "'wfa': the general generator restricted to WFA (wfa_group / wfa_wave / wfa_lane); 'fused': WFA batches through aim_set_submit as PACKED "
                          "rows with the compact CIGAR back (one kernel per batch: wfa_lane_packed / wfa_group + traceback kernel), output text against the oracle's; "
-                         "'dp': NW / SWG long reads (dp_strip_kernel with every cells-per-lane shape, dp_wave_kernel); "
+                         "'dp': NW / SWG long reads (dp_strip_kernel with every cells-per-lane shape, dp_wave_kernel); 'dpgroup': NW / SWG medium reads (dp_group_kernel, its to-do list and both fallbacks); "
                          "'dplane': NW / SWG short reads (nw_reg_kernel + its to-do pass, nw_lane_kernel, swg_lane_kernel): every length relation, outliers, costs")
     a = ap.parse_args()
     rng = random.Random(a.seed)
@@ -133,6 +133,64 @@ def main():
                 err = compare(algo, params, req, pat, txt)
             except Exception as ex:
                 err = "exception: %r" % (ex,)
+            cases += 1
+            kernels[kn] = kernels.get(kn, 0) + 1
+            if err:
+                print(json.dumps(dict(case, ok=False)), flush=True)
+                print("MISMATCH:", err, flush=True)
+                return 1
+            continue
+        if a.focus == "dpgroup":
+            # medium-read NW / SWG (dp_group_kernel: G lanes per pair, READ_SIZE 177 .. 1024 and its neighbours): lengths anywhere inside the row, tails of
+            # every size (plen > tlen: the aliased boundary cells, the last row's tail cells), outliers for the to-do list (empty sequences, plen > 2 tlen) and
+            # its two fallbacks (dp_lane kernels up to READ_SIZE 320, dp_strip in to-do mode above), penalties on both sides of dp_strip_exact_ok()
+            algo = rng.choice(["nw", "swg"])
+            rs = rng.choice([176, 184, 192, 200, 224, 256, 264, 288, 320, 328, 336, 384, 416, 512, 520, 640, 728, 736, 992, 1000, 1024, 1032])
+            l = rng.randint(max(1, rs - rs // 3), rs - 8)
+            e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15])
+            if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
+            cost = {}
+            if algo == "nw" and rng.random() < 0.5: cost = dict(mismatch=rng.randint(1, 9), gap=rng.choice([1, 2, 3, 4, 5, 9, 14, 30]))
+            if algo == "nw" and rng.random() < 0.4: cost = dict(mismatch=rng.randint(1, 9), gap_i=rng.choice([1, 2, 3, 4, 6, 7, 9, 30]), gap_d=rng.choice([1, 2, 3, 5, 6, 7, 9, 30]))
+            if algo == "swg" and rng.random() < 0.5:
+                cost = dict(mismatch=rng.randint(1, 9), gap_o=rng.choice([1, 2, 4, 6, 9, 40]), gap_e=rng.choice([1, 1, 2, 3, 5]))
+                if rng.random() < 0.1: cost["match"] = rng.choice([-2, -1, 0])
+            n = int(min(rng.choice([1, 5, 6, 7, 63, 64, 65, 500, 2000]), max(1, a.max_cells // (l * l))))
+            bt = rng.random() < 0.6
+            ms = rng.choice([1, 20, 60, 200, 600])
+            if algo == "swg":
+                ms = rng.choice([0, 25, 100, 126, 127, 200, 500, 2000])
+                if rng.random() < 0.7: cost["swg_w16"] = True
+            params = engine.make_params(algo, ms, rs, backtrace=bt, **cost)
+            for k in list(os.environ):
+                if k.startswith("AIM_") and k != "AIM_LIB" and not k.startswith("AIM_DEBUG_POISON"): os.environ.pop(k)
+            env = {}
+            if rng.random() < 0.12: env["AIM_NO_DP_GROUP"] = "1"
+            if rng.random() < 0.2: env["AIM_DPG_PER_CU"] = rng.choice(["1", "3", "12"])
+            if rng.random() < 0.1: env["AIM_SCRATCH_GB"] = rng.choice(["0.5", "2"])
+            os.environ.update(env)
+            req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
+            for _ in range(rng.choice([0, 3, 40])):                     # length outliers (contents stay what they were): tails of any size, plen > 2 tlen, empty sequences
+                i = rng.randrange(n)
+                r = rng.random()
+                if r < 0.4: req["text_len"][i] = rng.randint(0, int(req["text_len"][i]))
+                elif r < 0.7: req["pattern_len"][i] = rng.randint(0, int(req["pattern_len"][i]))
+                elif r < 0.85: req["text_len"][i] = max(1, int(req["pattern_len"][i]) - rng.randint(1, 70))
+                else: req["text_len"][i] = max(1, (int(req["pattern_len"][i]) + 1) // 2 + rng.randint(-1, 1))
+            if n > 8 and rng.random() < 0.3:                            # unrelated texts: every cell on the gap / mismatch branches
+                for i in range(0, n, rng.choice([2, 7, 50])):
+                    k = int(req["text_len"][i])
+                    txt[i, :k] = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(k)), dtype=np.uint8)
+            if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")
+            kn = lib.aim_kernel_name(C.byref(params)).decode()
+            case = dict(algo=algo, l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, backtrace=int(bt), cost=cost, env=env)
+            try:
+                err = compare(algo, params, req, pat, txt, allow_nomem="AIM_SCRATCH_GB" in env)
+            except Exception as ex:
+                err = "exception: %r" % (ex,)
+                if "AIM_SCRATCH_GB" in env and "error -3" in err:
+                    skipped += 1
+                    continue
             cases += 1
             kernels[kn] = kernels.get(kn, 0) + 1
             if err:
