@@ -94,7 +94,13 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_reg_kernel"                           # round 4: rows in registers up to READ_SIZE 128 (112 with CIGAR)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 120, backtrace=True))) == b"nw_reg_kernel"          # round 5: READ_SIZE 120 / 128 with CIGAR too (l = 100, e = 10 %)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 160, backtrace=True))) == b"nw_reg_kernel"         # (l = 150: the pattern row in LDS, 12 dwords of direction bits)
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184))) == b"nw_lane_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184))) == b"dp_group_kernel"                         # round 5: medium reads, G lanes per pair (READ_SIZE 177 .. 1024)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1024, backtrace=True))) == b"dp_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032))) == b"dp_strip_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 336, backtrace=True))) == b"dp_group_kernel"      # (int16 cells by MAX_SCORE)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336, swg_w16=True))) == b"dp_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_strip_kernel" or lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_wave_kernel"   # (int8 cells wrap by design: the literal kernels)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184, gap=90))) == b"nw_lane_kernel"                  # (dp_strip_exact_ok: an int16 store could wrap)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_reg_kernel"                          # round 5: M and I rows in registers up to READ_SIZE 128
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 112, backtrace=True))) == b"swg_reg_kernel"       # (int16 cells too)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 160, swg_w16=True))) == b"swg_reg_kernel"            # (l = 150, int16 cells: the pattern row in LDS, M and I in 154 registers)
@@ -233,7 +239,14 @@ def test_round4_plan_shapes(built):
             assert l.startswith("genasm_wave_kernel") and "grid=%d " % grid in l and "lds=4160" in l, l
         assert plan(engine.make_params("nw", 4, 128), 1 << 20).startswith("nw_reg_kernel")
         assert plan(engine.make_params("nw", 4, 128, backtrace=True), 1 << 20).startswith("nw_reg_kernel")     # round 5: 62 registers = the 8 dwords of direction bits a row has
+        l = plan(engine.make_params("nw", 4, 184, backtrace=True), 1 << 20)                                   # round 5: dp_group_kernel, 6 lanes per pair = 10 pairs per wavefront; its to-do list goes to nw_lane_kernel
+        assert l.startswith("dp_group_kernel") and "lanes_per_pair=6" in l and "grid=2048" in l and "fb_block=64" in l, l
+        l = plan(engine.make_params("swg", 200, 736, backtrace=True), 1 << 16)                                # ... READ_SIZE > 320: to dp_strip_kernel in to-do mode
+        assert l.startswith("dp_group_kernel") and "lanes_per_pair=23" in l and "fb_block=64" in l, l
+        os.environ["AIM_NO_DP_GROUP"] = "1"
         assert plan(engine.make_params("nw", 4, 184, backtrace=True), 1 << 20).startswith("nw_lane_kernel")
+        assert plan(engine.make_params("swg", 200, 736, backtrace=True), 1 << 16).startswith("dp_strip_kernel")
+        os.environ.pop("AIM_NO_DP_GROUP")
         assert plan(engine.make_params("nw", 4, 48), 1 << 20).startswith("nw_reg_kernel") and plan(engine.make_params("swg", 4, 88), 1 << 20).startswith("swg_reg_kernel")
         assert plan(engine.make_params("nw", 4, 112, backtrace=True), 1 << 20).startswith("nw_reg_kernel")
         assert plan(engine.make_params("nw", 4, 112, gap=60), 1 << 20).startswith("nw_lane_kernel")     # costs too large for INF = 16 000 to stay out of reach

@@ -1538,7 +1538,7 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
             s.configure(params, n)
             s.push(0, req, pat, txt); s.launch(); s.pull(0)
             if rs > 176:
-                assert s.plan_describe(0).startswith("nw_lane_kernel"), s.plan_describe(0)
+                assert s.plan_describe(0).startswith("dp_group_kernel"), s.plan_describe(0)
                 continue
             assert s.plan_describe(0).startswith("nw_reg_kernel"), s.plan_describe(0)
             fb = s.fallback_pairs(0)
@@ -1551,6 +1551,66 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
     monkeypatch.delenv("AIM_NO_NW_REG")
     res1, ops1 = engine.align(params, req, pat, txt)
     assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
+
+
+# ------------------------------------------------------------------ medium reads: G lanes per pair (dp_group.hpp, round 5)
+@pytest.mark.parametrize("algo", ["nw", "swg"])
+@pytest.mark.parametrize("bt", [False, True])
+@pytest.mark.parametrize("l,err", [(180, 0.02), (200, 0.05), (250, 0.02), (250, 0.10), (300, 0.05), (320, 0.02), (400, 0.05), (500, 0.02), (700, 0.05), (960, 0.03), (990, 0.02)])
+def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
+    """dp_group_kernel (READ_SIZE 177 .. 1024: G consecutive lanes own a pair, dp_strip's packed row body with the prefix minimum as ONE wave scan over
+    (pair rank, value) keys) against the oracle: every length relation -- plen < / == / > tlen incl. long tails (the aliased boundary cell of every row,
+    the last row's tail cells; nw.c:109-153, swg.c:121-171 over the flat table) --, the pairs it leaves to its to-do list (empty sequences, plen > 2 tlen)
+    through both fallbacks (nw_lane / swg_lane up to READ_SIZE 320, dp_strip in to-do mode above), non-ACGT bytes, other costs (NW: GAP_I != GAP_D),
+    and equality with the kernels it replaced (AIM_NO_DP_GROUP=1)."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes(algo, l, err)
+    n = 1500 if l <= 400 else 400
+    req, pat, txt = engine.gen_pairs(8800 + l, 0, n, l, err, rs)
+    for i in range(3, n, 17):                                                   # tails of every size
+        req["text_len"][i] = max(1, int(req["text_len"][i]) - (i % 61))
+    for i in range(5, n, 29):
+        req["pattern_len"][i] = max(1, int(req["pattern_len"][i]) - (i % 43))
+    req["pattern_len"][11] = min(rs, l); req["text_len"][11] = l // 2 + 3       # plen just below 2 tlen
+    req["pattern_len"][12] = 0                                                  # the to-do list: empty sequences, plen > 2 tlen
+    req["text_len"][13] = 0
+    req["pattern_len"][14] = l; req["text_len"][14] = l // 3
+    req["pattern_len"][15] = 1; req["text_len"][15] = 1
+    req["pattern_len"][16] = 2; req["text_len"][16] = min(rs, l)
+    pat[20, l // 2] = ord("N"); txt[21, l // 3] = ord("N")
+    d = req["pattern_len"].astype(int) - req["text_len"].astype(int)
+    assert (d < 0).any() and (d == 0).any() and (d == 1).any() and (d >= 2).any() and (d > 32).any()
+    costs = ((dict(), dict(mismatch=2, gap_i=5, gap_d=3)) if algo == "nw" else (dict(swg_w16=True), dict(swg_w16=True, mismatch=5, gap_o=2, gap_e=3)))
+    for cost in costs:
+        params = engine.make_params(algo, ms, rs, backtrace=bt, **cost)
+        _compare(algo, params, req, pat, txt)
+        with engine.DeviceSet(1) as s:
+            s.configure(params, n)
+            s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
+            if rs > 1024:
+                assert s.plan_describe(0).startswith("dp_strip_kernel"), s.plan_describe(0)
+                continue
+            assert s.plan_describe(0).startswith("dp_group_kernel"), s.plan_describe(0)
+            out = int(((req["pattern_len"] < 1) | (req["text_len"] < 1) | (req["pattern_len"] > 2 * req["text_len"])).sum())
+            assert s.fallback_pairs(0) == out and out >= 3, (s.fallback_pairs(0), out)
+    params = engine.make_params(algo, ms, rs, backtrace=bt, **costs[0])
+    res1, ops1 = engine.align(params, req, pat, txt, check=False)
+    monkeypatch.setenv("AIM_NO_DP_GROUP", "1")
+    res2, ops2 = engine.align(params, req, pat, txt, check=False)
+    assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
+
+
+def test_dp_group_kernel_every_lane_count_and_few_pairs(gpu):
+    """Every lanes-per-pair value G = 6 .. 32 (READ_SIZE 184 .. 1024 in steps of 32: 10 .. 2 pairs per wavefront, idle lanes behind the last pair), with
+    fewer pairs than a wavefront holds and a last unit that is not full, NW and SWG with CIGAR."""
+    from aim_amd import engine
+    for rs in range(184, 1025, 56):
+        l = rs - 16
+        for algo, kw in (("nw", dict()), ("swg", dict(swg_w16=True))):
+            for n in (1, 64 // ((rs + 31) // 32) + 1, 37):
+                req, pat, txt = engine.gen_pairs(100 + rs + n, 0, n, l, 0.03, rs)
+                params = engine.make_params(algo, 60, rs, backtrace=True, **kw)
+                _compare(algo, params, req, pat, txt)
 
 
 # ------------------------------------------------------------------ NW with GAP_I != GAP_D (VERDICT r04 item 1)

@@ -54,6 +54,12 @@ CONFIGS = {
     "nw_l150_e1_score": dict(algo="nw", l=150, e=0.01, n=1 << 20, kw=dict()),
     "nw_l150_e1_cigar": dict(algo="nw", l=150, e=0.01, n=1 << 20, kw=dict(backtrace=True)),
     "nw_l150_e5_score": dict(algo="nw", l=150, e=0.05, n=1 << 20, kw=dict()),
+    "nw_l250_e2_score": dict(algo="nw", l=250, e=0.02, n=399360, kw=dict()),
+    "nw_l250_e2_cigar": dict(algo="nw", l=250, e=0.02, n=99328, kw=dict(backtrace=True)),
+    "swg_l250_e2_w16_score": dict(algo="swg", l=250, e=0.02, n=399360, kw=dict(swg_w16=True)),
+    "swg_l250_e2_w16_cigar": dict(algo="swg", l=250, e=0.02, n=99328, kw=dict(backtrace=True, swg_w16=True)),
+    "nw_l500_e2_score": dict(algo="nw", l=500, e=0.02, n=99328, kw=dict()),
+    "swg_l500_e5_cigar": dict(algo="swg", l=500, e=0.05, n=24576, kw=dict(backtrace=True)),
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar_n2048": dict(algo="swg", l=10000, e=0.01, n=2048, kw=dict(backtrace=True)),
