@@ -38,7 +38,7 @@ __host__ __device__ inline size_t dp_group_slab_bytes(int rs) { return (((size_t
 
 inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
 {
-    if (kn.no_dp_group || kn.force_dpwave || kn.dpw_legacy) return false;
+    if (kn.no_dp_group || kn.force_dpwave || kn.dpw_legacy || kn.strip_k > 0 || kn.dpw_nw > 0) return false;   // (the long-read kernels' own knobs ask for those kernels)
     if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG) return false;
     if (p.read_size < kDpgMinRs || p.read_size > kDpgMaxRs) return false;
     if (p.algo == AIM_ALGO_SWG && swg_cell_bytes(p) == 1) return false;   // int8 cells wrap by design: the literal kernels

@@ -400,6 +400,8 @@ DP_KERNELS = [dict(), dict(AIM_DPW_LEGACY="1"), dict(AIM_STRIP_K="32"), dict(AIM
 def _dp_kernel_name(env, params):
     from aim_amd import capi
     int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
+    if not env and not int8 and 177 <= params.read_size <= 1024:
+        return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave)
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
 
 
@@ -1605,7 +1607,7 @@ def test_dp_group_kernel_every_lane_count_and_few_pairs(gpu):
     fewer pairs than a wavefront holds and a last unit that is not full, NW and SWG with CIGAR."""
     from aim_amd import engine
     for rs in range(184, 1025, 56):
-        l = rs - 16
+        l = (rs - 8) * 100 // 104
         for algo, kw in (("nw", dict()), ("swg", dict(swg_w16=True))):
             for n in (1, 64 // ((rs + 31) // 32) + 1, 37):
                 req, pat, txt = engine.gen_pairs(100 + rs + n, 0, n, l, 0.03, rs)
