@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);
                     fw[j >> 2] |= w1 & (0x01010101u << (j & 3));
                 }
-                if (act && h <= tlen && nvalid > 0) *reinterpret_cast<uint4 *>(FLW + ((size_t)h * FS + g) * 4) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+                if (act && h <= tlen && nvalid > 0 && !(a.dbg_flags & 4u)) *reinterpret_cast<uint4 *>(FLW + ((size_t)h * FS + g) * 4) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
             }
             // ---- a pair's last row: its regular part into the slot (score; the tail walk reads it)
             if (__ballot(act && h == tlen) != 0ull) {
