@@ -33,7 +33,7 @@ __host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt = false)
     return (((size_t)(kWave / dp_group_lanes(rs)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
 }
 // BACKTRACE: a pair's slab of direction bits, dp_strip.hpp's layout with K = 32 -- FLW [READ_SIZE + 3 rows][FS lane words of 16 B], then the boundary cells' bytes [row]
-__host__ __device__ inline int dp_group_fs(int rs) { return rs / (2 * kDpgKP) + 2; }
+__host__ __device__ inline int dp_group_fs(int rs) { return dp_group_lanes(rs); }   // (exactly the pair's lanes: a row of the slab is one contiguous run of 16-byte words, rows follow each other without gaps)
 __host__ __device__ inline size_t dp_group_slab_bytes(int rs) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs) * 16 + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }
 
 inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
