@@ -27,7 +27,7 @@ __host__ __device__ inline int dp_group_lanes(int read_size) { return (read_size
 
 // LDS of one pair slot: pattern | text | the last row's M, I (int16) | 16 B {M, D of cell W - 1, M of the cell above it}
 __host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
-constexpr int kDpgTileRows = 64;                 // the traceback's window (dp_traceback_swg_bits): 64 rows x 3 lane words x 16 B
+constexpr int kDpgTileRows = 64;                 // the traceback's window (dp_traceback_swg_bits): 64 rows x 3 lane words x 16 B = 3 KB (128 rows measured slower: 3.53 -> 3.65 ms at NW l = 300, LDS residency at READ_SIZE 192)
 __host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt = false)
 {
     return (((size_t)(kWave / dp_group_lanes(rs)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
