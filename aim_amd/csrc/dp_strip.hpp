@@ -285,6 +285,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         if (atomicCAS(&pool_locks[i], 0u, 1u) == 0u) got = (int)i;
                     if (got < 0) __builtin_amdgcn_s_sleep(32);
                 }
+                __threadfence();   // acquire, device scope: this XCD's L2 / this CU's L1 drop whatever they still hold of the table (the previous holder may have run on another XCD)
                 tl[4] = got;
             }
             __syncthreads();
@@ -641,8 +642,15 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
 
         if (BT && literal && wv == 0 && !(a.dbg_flags & 1u)) dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, false, ops, lane, begin_offset, status);
         if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)
+            // A pool table is shared by workgroups on DIFFERENT XCDs, whose L2s are not coherent with each other inside a kernel: without a write-back of this XCD's
+            // dirty lines BEFORE the lock opens, they can reach HBM after the next holder's own (evicted) lines and be read back by its walk -- seen once in ~400
+            // batches of 445 pairs (READ_SIZE 1032, a dozen literal pairs each) as a spurious AIM_PAIR_SWG_NO_OP. __threadfence() = release at device scope
+            // (buffer_wbl2 sc1 + wait); literal pairs are outliers and cost milliseconds each, the fence microseconds.
             __syncthreads();
-            if (tid == 0) atomicExch(&pool_locks[pool_slot], 0u);
+            if (tid == 0) {
+                __threadfence();
+                atomicExch(&pool_locks[pool_slot], 0u);
+            }
             TM = tb; TI = tb + plane; TD = tb + 2 * plane;
         }
 #ifdef AIM_STRIP_STAMPS

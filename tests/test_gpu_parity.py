@@ -1555,6 +1555,29 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
     assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
 
 
+def test_dp_strip_pool_tables_are_shared_safely_across_xcds(gpu):
+    """The literal path of dp_strip_kernel (plen > 2 tlen) takes its int16 planes from a small POOL of tables shared by all workgroups (round 5). Workgroups on
+    different XCDs have L2s that are not coherent with each other inside a kernel: without a device-scope release (write-back) before the lock opens, a previous
+    holder's dirty lines could land in HBM over the next holder's and come back into its walk -- a spurious AIM_PAIR_SWG_NO_OP / wrong CIGAR in ~7 % of such
+    batches (found by fuzz_parity --focus dpgroup, NOTES R5.5). Every ninth pair literal, the rest streaming direction bits around them; 25 launches."""
+    import random
+    from aim_amd import engine
+    from oracle import oracle
+    for algo, kw, ms in (("swg", dict(swg_w16=True), 0), ("nw", dict(), 40)):
+        l, e, rs, n = 948, 0.01, 1032, 445
+        params = engine.make_params(algo, ms, rs, backtrace=True, **kw)
+        rng = random.Random(5)
+        req, pat, txt = engine.gen_pairs(777, 0, n, l, e, rs)
+        for i in range(0, n, 9):
+            req["text_len"][i] = rng.randint(200, int(req["pattern_len"][i]) // 2 - 1)
+        ores, oops, _ = oracle.align_batch(_oracle_params(oracle, params, algo), req["pattern_len"], req["text_len"], pat, txt, nthreads=16)
+        want = engine.format_output(ores, oops, True)
+        for rep in range(25):
+            res, ops = engine.align(params, req, pat, txt, check=False)
+            assert np.array_equal(res["status"], ores["status"]) and np.array_equal(res["score"], ores["score"]), (algo, rep)
+            assert engine.format_output(res, ops, True) == want, (algo, rep)
+
+
 # ------------------------------------------------------------------ medium reads: G lanes per pair (dp_group.hpp, round 5)
 @pytest.mark.parametrize("algo", ["nw", "swg"])
 @pytest.mark.parametrize("bt", [False, True])
