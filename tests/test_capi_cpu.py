@@ -152,6 +152,35 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
     assert G(1000, 0.05, AIM_GROUP_WLDS="0", AIM_GROUP_G="64")[2] == 14              # 10.7 KB
 
 
+def test_dp_group_plan_scratch_and_lds(built):
+    """dp_group_kernel's plan (dp_group.hpp, round 5): with CIGAR every pair of a wavefront owns a slab of [READ_SIZE + 3][G] 16-byte lane words + a byte per boundary cell;
+    the to-do region sits behind the larger of (slabs, the fallback kernel's scratch); LDS = the pairs' slots + the traceback's 3-KB window."""
+    import ctypes as C
+    from aim_amd import capi, engine
+    lib = capi.load()
+    env = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("AIM_") and k != "AIM_LIB"}
+    try:
+        for rs in (192, 336, 736, 1024):
+            G = (rs + 31) // 32
+            P = 64 // G
+            slot = 2 * ((rs + 79) & ~15) + 4 * ((rs + 47) & ~7) + 16
+            for bt in (False, True):
+                p = engine.make_params("nw", 40, rs, backtrace=bt)
+                buf = C.create_string_buffer(1024)
+                assert lib.aim_plan_describe(C.byref(p), 1 << 16, buf, 1024) == 0
+                line = buf.value.decode()
+                assert line.startswith("dp_group_kernel") and "lanes_per_pair=%d " % G in line, line
+                lds = int(re.search(r"lds=(\d+)", line).group(1)); grid = int(re.search(r"grid=(\d+)", line).group(1))
+                assert lds == ((P * slot + 15) & ~15) + (64 * 3 * 16 if bt else 0) + 64, (rs, bt, lds)
+                assert grid == min(2048, ((((1 << 16) + P - 1) // P + 7) // 8) * 8)
+                total = lib.aim_scratch_bytes(C.byref(p), 1 << 16)
+                slab = (((rs + 3) * G * 16 + (rs + 3) + 64) + 255) & ~255
+                todo = ((16 + (1 << 16)) * 4 + 255) & ~255
+                assert total >= (grid * P * slab if bt else 0) + todo and total < (1 << 33), (rs, bt, total)
+    finally:
+        os.environ.update(env)
+
+
 def test_scratch_bound_default_and_override(built):
     """scratch_budget_bytes: without a device the planning queries use 16 GB; AIM_SCRATCH_GB overrides; plans are
     need-capped (the headline's scratch does not depend on the bound), config 4's table slabs scale with it."""
