@@ -1638,6 +1638,31 @@ def test_dp_group_kernel_every_lane_count_and_few_pairs(gpu):
                 _compare(algo, params, req, pat, txt)
 
 
+@pytest.mark.parametrize("algo", ["nw", "swg"])
+def test_dp_group_kernel_many_units_per_wavefront(gpu, monkeypatch, algo):
+    """A persistent wavefront takes one unit of 64 / G pairs after the other: its LDS slots, its slabs of direction bits and the traceback's window are reused.
+    The batches of the other tests fit the resident grid in one unit per wavefront; here the plan is made for a device of 2 CUs (AIM_CHIP_CUS: 16 wavefronts), so every
+    wavefront works through a dozen units with pairs of different lengths, tails and outliers in between."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_CHIP_CUS", "2")
+    for l, err, n in ((250, 0.03, 1200), (420, 0.02, 700), (900, 0.02, 300)):
+        ms, rs = engine.launcher_sizes(algo, l, err)
+        req, pat, txt = engine.gen_pairs(660 + l, 0, n, l, err, rs)
+        rng = np.random.default_rng(l)
+        for i in range(0, n, 3):                                               # lengths all over the row, tails of every size, a few outliers
+            req["pattern_len"][i] = int(rng.integers(max(1, l // 3), l))
+        for i in range(1, n, 5):
+            req["text_len"][i] = int(rng.integers(max(1, l // 2), l))
+        req["text_len"][7] = 0; req["pattern_len"][8] = l; req["text_len"][8] = l // 4
+        kw = dict(swg_w16=True) if algo == "swg" else dict()
+        for bt in (False, True):
+            params = engine.make_params(algo, ms, rs, backtrace=bt, **kw)
+            _compare(algo, params, req, pat, txt)
+            with engine.DeviceSet(1) as s:
+                s.configure(params, n)
+                assert s.plan_describe(0).startswith("dp_group_kernel") and "grid=16 " in s.plan_describe(0), s.plan_describe(0)
+
+
 # ------------------------------------------------------------------ NW with GAP_I != GAP_D (VERDICT r04 item 1)
 @pytest.mark.parametrize("gi,gd,mism", [(2, 7, 3), (7, 3, 5), (1, 6, 2)])
 @pytest.mark.parametrize("bt", [False, True])

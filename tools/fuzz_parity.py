@@ -167,6 +167,7 @@ def main():
             env = {}
             if rng.random() < 0.12: env["AIM_NO_DP_GROUP"] = "1"
             if rng.random() < 0.2: env["AIM_DPG_PER_CU"] = rng.choice(["1", "3", "12"])
+            if rng.random() < 0.15: env["AIM_CHIP_CUS"] = rng.choice(["1", "2", "8"])     # a small resident grid: many units per wavefront (LDS slots, slabs and the window reused)
             if rng.random() < 0.1: env["AIM_SCRATCH_GB"] = rng.choice(["0.5", "2"])
             os.environ.update(env)
             req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
