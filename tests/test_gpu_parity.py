@@ -1578,6 +1578,30 @@ def test_dp_strip_pool_tables_are_shared_safely_across_xcds(gpu):
             assert engine.format_output(res, ops, True) == want, (algo, rep)
 
 
+@pytest.mark.parametrize("algo,l,err,kw", [("nw", 100, 0.05, {}), ("swg", 100, 0.05, {}), ("swg", 100, 0.02, dict(swg_w16=True)), ("nw", 150, 0.02, {}),
+                                           ("swg", 150, 0.02, dict(swg_w16=True)), ("nw", 70, 0.05, {})])
+def test_register_kernels_many_groups_per_wavefront(gpu, monkeypatch, algo, l, err, kw):
+    """nw_reg_kernel / swg_reg_kernel take groups of 64 candidate pairs through LDS queues (two of them in swg_reg: plen <= tlen / plen > tlen) and run on 64 QUEUED pairs at a
+    time; the remainder of a queue moves to its front. With the resident grid of a whole chip the batches of the other tests give a wavefront one group: here the plan is made for
+    one CU (AIM_CHIP_CUS=1: 8 wavefronts), so every wavefront drains ~18 groups with tails and short outliers in between."""
+    from aim_amd import engine
+    monkeypatch.setenv("AIM_CHIP_CUS", "1")
+    ms, rs = engine.launcher_sizes(algo, l, err)
+    n = 9000
+    req, pat, txt = engine.gen_pairs(31 + l, 0, n, l, err, rs)
+    rng = np.random.default_rng(l)
+    for i in range(0, n, 7):
+        req["text_len"][i] = max(1, int(req["text_len"][i]) - int(rng.integers(0, 14)))
+    for i in range(3, n, 11):
+        req["pattern_len"][i] = max(1, int(req["pattern_len"][i]) - int(rng.integers(0, 30)))
+    for bt in (False, True):
+        params = engine.make_params(algo, ms, rs, backtrace=bt, **kw)
+        _compare(algo, params, req, pat, txt)
+        with engine.DeviceSet(1) as s:
+            s.configure(params, n)
+            assert s.plan_describe(0).startswith(algo + "_reg_kernel") and "grid=8 " in s.plan_describe(0), s.plan_describe(0)
+
+
 # ------------------------------------------------------------------ medium reads: G lanes per pair (dp_group.hpp, round 5)
 @pytest.mark.parametrize("algo", ["nw", "swg"])
 @pytest.mark.parametrize("bt", [False, True])

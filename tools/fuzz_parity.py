@@ -116,6 +116,7 @@ def main():
             if rng.random() < 0.1: env["AIM_NO_SWG_REG"] = "1"
             if rng.random() < 0.2: env["AIM_NW_REG_PER_CU"] = rng.choice(["1", "3", "16"])
             if rng.random() < 0.2: env["AIM_DPL_PER_CU"] = rng.choice(["1", "3", "12"])
+            if rng.random() < 0.15: env["AIM_CHIP_CUS"] = rng.choice(["1", "2"])     # a small resident grid: many groups of 64 pairs per wavefront (the queues' carry-over)
             os.environ.update(env)
             req, pat, txt = engine.gen_pairs(rng.randint(1, 1 << 30), 0, n, l, e, rs)
             if algo == "swg" and n > 8 and rng.random() < 0.4:          # unrelated texts: cells climb to MAX_SCORE + min(h, v) e, int8 cells wrap, the walk may find no operation
