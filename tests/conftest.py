@@ -65,9 +65,12 @@ def judge_cases():
     (judge_r02_cases.json: dynamic-bounds / READ_SIZE-80 lane shapes, l = 150, MAX_SCORE 10, MRAM-variant overflow) and 20 in
     round 3 (judge_r03_cases.json: score-unit loop 4/6/2 and 6/2/2, READ_SIZE 136 ... 184 with CIGAR, rows of 96, NW / SWG at
     cfg4's real size) and 13 in round 4 (judge_r04_cases.json: NW with GAP_I != GAP_D, the READ_SIZE 80 / 128 register shapes,
-    WFA-adaptive at l = 10 000 / 4 000 / 2 000). Rows where the reference aborts are in judge_abort_cases()."""
+    WFA-adaptive at l = 10 000 / 4 000 / 2 000) and 31 in round 5 (judge_r05_cases.json: dp_group_kernel's lengths, swg_reg with
+    other costs, READ_SIZE 144 ... 176, NW bits on dp_strip, the lane kernels' other penalty sets, and eight `tails_v1` inputs --
+    long tails and the literal path). Rows where the reference aborts are in judge_abort_cases()."""
     cases = []
-    for name in ("judge_r01_cases.json", "judge_r02_cases.json", "judge_r03_cases.json", "judge_r04_cases.json"):
+    for name in ("judge_r01_cases.json", "judge_r02_cases.json", "judge_r03_cases.json", "judge_r04_cases.json",
+                 "judge_r05_cases.json"):
         cases += [c for c in json.load(open(os.path.join(GOLDEN, name)))["cases"] if "abort" not in c]
     return cases
 
@@ -87,14 +90,37 @@ def judge_costs(case):
     return {k: case[k] for k in ("mismatch", "gap_o", "gap_e", "gap", "gap_i", "gap_d") if k in case}
 
 
+def tails_v1(data):
+    """judge r05's transform of a gen_dataset file (Next round item 1): pair i (0-based), pattern p / text t without
+    the marker byte, in this order -- i % 5 == 3: t loses its last i % 61 characters; i % 11 == 7: p loses its last i % 43;
+    i % 97 == 13: t = t[:len(p) // 3] (never below one character)."""
+    lines = data.split(b"\n")[:-1]
+    out = []
+    for i in range(len(lines) // 2):
+        p, t = lines[2 * i][1:], lines[2 * i + 1][1:]
+        if i % 5 == 3:
+            t = t[:max(1, len(t) - i % 61)]
+        if i % 11 == 7:
+            p = p[:max(1, len(p) - i % 43)]
+        if i % 97 == 13:
+            t = t[:max(1, len(p) // 3)]
+        out += [lines[2 * i][:1] + p, lines[2 * i + 1][:1] + t]
+    return b"\n".join(out) + b"\n"
+
+
 def judge_case_input(case):
-    """Regenerate a judge case's input file exactly as `python -m aim_amd.gen_dataset -n N -l L -e E -s SEED` writes it."""
+    """Regenerate a judge case's input file exactly as `python -m aim_amd.gen_dataset -n N -l L -e E -s SEED` writes it (and, for
+    the rows that name one, the judge's transform of that file)."""
     from aim_amd import engine
     g = case["gen"]
     edits = int(-(-g["l"] * g["e"] // 1))
     row = (g["l"] + edits + 1 + 7) // 8 * 8
     req, pat, txt = engine.gen_pairs(g["s"], 0, g["n"], g["l"], g["e"], row)
     data = engine.pairs_to_text(req, pat, txt)
+    if case.get("transform") == "tails_v1":
+        data = tails_v1(data)
+    else:
+        assert "transform" not in case, case["transform"]
     assert hashlib.md5(data).hexdigest() == case["input_md5"], "generator drifted from the judge's input for " + case["name"]
     return data
 
