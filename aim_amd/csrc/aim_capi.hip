@@ -126,6 +126,9 @@ aim::Knobs read_knobs()
     k.no_dp_group = env_flag("AIM_NO_DP_GROUP");
     k.dpg_per_cu = env_int("AIM_DPG_PER_CU", -1);
     k.dbg_flags = env_int("AIM_DEBUG_FLAGS", 0);
+#ifndef AIM_DIAG_BUILD   // bits 1 / 4 / 8 make kernels skip work (a traceback walk, the direction-bit stores, the bits themselves) and return WRONG results with status OK:
+    k.dbg_flags &= 2;    // they exist in diagnostic builds only (python -m aim_amd.build --variant diag --flags "-DAIM_DIAG_BUILD=1"). Bit 2 changes the route, not the result.
+#endif
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);

@@ -31,7 +31,8 @@ struct KArgs {
     const uint32_t *todo; // nullptr: units are pairs 0..n_pairs-1; else {count @0, pair ids @16..} written by wfa_lane
     uint32_t dbg_poison_lds;    // debugging aid (AIM_DEBUG_POISON_LDS): 0 = off, else 0x100 | byte every workgroup fills its
     uint32_t dbg_lds_bytes;     // dynamic LDS with at kernel entry (results must not depend on it)
-    uint32_t dbg_flags;         // diagnostic runs only (AIM_DEBUG_FLAGS; results are WRONG with any bit set): 1 = dp_strip skips the traceback walk; 2 = nw_reg leaves pairs with tail cells to the to-do list (A/B, results stay right); 4 = dp_group does not store its direction bits
+    uint32_t dbg_flags;         // AIM_DEBUG_FLAGS. Bit 2 (results stay right): nw_reg leaves pairs with tail cells to the to-do list. DIAGNOSTIC BUILDS ONLY (-DAIM_DIAG_BUILD, results are
+                                // WRONG): 1 = dp_strip / dp_group / nw_reg / swg_reg skip the traceback walk; 4 = dp_group / nw_reg / swg_reg do not store their direction bits (and do not walk)
     // Fused batch I/O (round 3; aim_hip.h "pipelined batches"): kernels that can, consume the packed image of a batch
     // directly and emit the compact CIGAR themselves -- no unpack pass, no ops rows, no run-length pass.
     const uint32_t *packedP;    // [n][ceil(read_size/16)] dwords, 2 bits per base, or nullptr (ASCII rows in patterns / texts)

@@ -40,6 +40,17 @@
 
 namespace aim {
 
+typedef uint32_t aim_u32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte piece of a sequence row (rows start on 8-byte boundaries)
+// dword q & 3 of a row's 16-byte unit of direction bits: bitwise selects under v_bfe_i32 masks (a `q & 1 ? a : b` tree over the elements of a vector is
+// taken for a dynamic index and the vector is put into scratch)
+__device__ __forceinline__ uint32_t band_pick(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int q)
+{
+    uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe(q, 0, 1), m2 = (uint32_t)__builtin_amdgcn_sbfe(q, 1, 1);
+    asm volatile("" : "+v"(m1), "+v"(m2));
+    const uint32_t lo = (w1 & m1) | (w0 & ~m1), hi = (w3 & m1) | (w2 & ~m1);
+    return (hi & m2) | (lo & ~m2);
+}
+
 constexpr int kRegWin = 16;        // registers (32 indices) in which a row may start
 constexpr int kNwTail = 8;         // tail cells of the LAST row a pair may have beyond (tlen, W): plen <= tlen + 1 + kNwTail (round 5)
 constexpr int kRegInf = 16000;     // the value left of a row's start
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int RSK = 2 * NPK;          // indices of a row of registers
     constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
     constexpr bool PL = NPK > 62;             // the (shifted) pattern row lives in LDS as bytes, not in NPK more registers (READ_SIZE 144 .. 176)
-    constexpr int NDQ = NPK > 64 ? 12 : 8;    // dwords of direction bits per row and lane (8 registers per dword), in 16-byte units
+    constexpr int NDQ = (NPK + 7) / 8;        // dwords of direction bits a row has per lane (8 registers per dword); four of them are kept (the band, below)
     constexpr bool TAILS = true;              // last-row tail cells in this kernel (with CIGAR too: their direction bits stay in a register, see the walk)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
@@ -97,10 +108,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // comparison (the minima, the direction bits and their tie order) is unchanged; the score is un-tilted once at the end. |T| <= GAP_I * tlen +
     // GAP_D * plen < 8 000 (nw_reg_supported), INF = 16 000 stays out of reach.
     const dps2 x2 = dps_splat(MISMATCH), c2 = dps_splat(-(GAP_I + GAP_D));
-    // direction table: 8 dwords per row and lane (dword q: registers 8q .. 8q + 7; register 8q + r at bit r of every byte: byte 0 / 1 = "not D" of its low / high
-    // half, byte 2 / 3 = "not I"); 4 dwords = one 16-byte unit, units lane-interleaved
+    // direction bits: a row has NDQ dwords per lane (dword q: registers 8q .. 8q + 7 = indices 16q .. 16q + 15; register 8q + r at bit r of every byte: byte 0 / 1 =
+    // "not D" of its low / high half, byte 2 / 3 = "not I"). Round 6: only a BAND of four consecutive dwords around the diagonal is kept -- ONE 16-byte unit per row
+    // and lane, lane-interleaved, dword q in slot q & 3. Rows are right-aligned, so the path's index at row h is RSK - 1 - (tlen - h) up to the pair's own drift:
+    // wave-uniform up to the spread of the lanes' lengths. The window q0(h) .. q0(h) + 3 (64 indices, at least +-24 about the wavefront's centre line) is a function
+    // of the row alone; a walk that leaves it sends its pair to the to-do list (nw_lane_kernel), like cfg4's band in dp_strip.hpp. (Until round 5: all 8 / 12 dwords,
+    // 3.5 GB of stores per 1 Mi pairs at l = 100 and one dependent HBM round trip per step of the walk -- a third of the kernel's time, profiles/r06/reg_cigar_split.txt.)
     uint32_t *tbw = reinterpret_cast<uint32_t *>(tb);
-#define TBW(h, q) tbw[((size_t)((h) * (NDQ / 4) + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
+    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+#define TBU(h) (reinterpret_cast<aim_u32x4 *>(tbw) + ((size_t)(h) * kWave + lane))
+    // ... and, for pairs with tail cells (plen >= tlen + 2) only, a second unit per row: dwords 0 .. 2, the row's FIRST columns (s0 + 8 <= 39). Their walk starts in the
+    // last row's tail, and a step up or diagonally from a tail cell leaves it at a flat index W h + v with v > W -- which is cell (h + 1, v - W) of the table, one of
+    // the next row's first eight columns (quirk N1; half of all tail pairs at e = 5 % pass through such cells).
+#define TBU2(h) (reinterpret_cast<aim_u32x4 *>(tbw) + ((size_t)((h) + rs + 2) * kWave + lane))
 
     // Pairs are taken through a small LDS queue: groups of 64 consecutive pairs are classified (this kernel's / to-do list) and the
     // kernel's own are queued; the row loop runs on 64 QUEUED pairs at a time. (Without it the to-do pairs' lanes idle through the whole
@@ -152,6 +172,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int pe = plen >= W ? W : plen;                 // the rows' last column
         const int ntail = mine ? plen - pe : 0;              // tail cells of the last row (score-only)
         const int s0 = mine ? RSK - 1 - pe : 0;              // index of column 0 (0 .. 31)
+        // BACKTRACE: the band's centre line (index at row 0, wave-uniform): midway between the lanes' extreme corner diagonals -- a pair's path runs between the
+        // diagonal through (0, 0), index s0 + h, and the one through (tlen, pe), index RSK - 1 - tlen + h
+        int bandc = 0;
+        if (BT) {
+            const int dlo = mine ? min(s0, RSK - 1 - tlen) : 0x7fffffff, dhi = mine ? max(s0, RSK - 1 - tlen) : -0x7fffffff;
+            bandc = (wave_min_i32(dlo) - wave_min_i32(-dhi)) >> 1;
+        }
+        auto band_q0 = [&](int h) { return min(max((bandc + h - 24) >> 4, 0), NDQ > 4 ? NDQ - 4 : 0); };   // first dword of row h's window
+        const bool wtail = BT && __ballot(ntail > 0) != 0ull;   // a pair of this wavefront has tail cells
         const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);   // (idle lanes: pair 0's rows, read and ignored)
         const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
         // the text row goes to LDS, transposed [dword][lane] (one conflict-free ds_read per ROW of the table), the pattern row into
@@ -220,16 +249,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // isW lanes: B(h) = cell (h - 1, W) = the previous row's last cell (row 1: the row-init value GAP_I, set above), re-tilted for (h, 0)
             const uint32_t binj = (((src[NPK - 1] >> 16) + kW) & 0xffffu) * 0x00010001u;
             uint32_t rprev = (uint32_t)kRegInf << 16;         // the register left of this one: m[index - 1] in its HIGH half
-            uint32_t dirw[NDQ];                               // BACKTRACE: the row's direction bits
-#pragma unroll
-            for (int k = 0; k < NDQ; ++k) dirw[k] = 0u;
+            uint32_t dcur = 0u;                               // BACKTRACE: the direction bits of the current dword (8 registers)
+            aim_u32x4 unit = {0u, 0u, 0u, 0u};                // ... and the row's window of four dwords (dword q in slot q & 3)
+            const int q0 = BT ? band_q0(h) : 0;               // wave-uniform
+            aim_u32x4 unit2 = {0u, 0u, 0u, 0u};               // dwords 0 .. 2 (pairs with tail cells)
             uint32_t pword = 0u;                              // PL: the pattern dword of the current two registers
             uint32_t oldprev = (uint32_t)kRegInf << 16;
             // (BACKTRACE updates the row in place: the NEXT register's diagonal is taken before this register is overwritten -- as a plain read-later the compiler kept a
             //  v_mov copy per register and row; the score-only variant alternates between two arrays and needs neither)
             uint32_t dnext = __builtin_amdgcn_alignbit(src[J0], oldprev, 16);
-#pragma unroll
-            for (int j = J0; j < NPK; ++j) {
+            // one register (two cells). BITS: with its direction bits (BACKTRACE, registers of the dwords the row keeps: one wave-uniform branch per dword of 8 registers --
+            // round 6; until then every register's bits were made: 0.65 of nw l = 100's 3.6 ms)
+            auto reg = [&](int j, auto bits_tag) __attribute__((always_inline)) {
+                constexpr bool BITS = decltype(bits_tag)::value;
                 const uint32_t oldj = src[j];
                 const dps2 diag = dps_from(BT ? dnext : __builtin_amdgcn_alignbit(oldj, oldprev, 16));   // {R_{h-1}[2j - 1], R_{h-1}[2j]}
                 if (BT) {
@@ -250,8 +282,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 // hand: the second minimum writes the HIGH half of the register that holds lo (dst_unused:UNUSED_PRESERVE) and the next register's
                 // first minimum reads it from there -- as C the compiler keeps lo and hi in two registers and packs them with a v_perm.
                 uint32_t t1, res;   // (ONE asm statement: the compiler pads every asm statement with an s_nop)
-                if (!BT) {
-                    asm("v_min_i16_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+                if (!BITS) {
+                    if (BT) asm volatile("v_min_i16_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+                        "v_min_i16_sdwa %0, %2, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
+                        : "=&v"(res) : "v"(rprev), "v"(dps_bits(A)));
+                    else asm("v_min_i16_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
                         "v_min_i16_sdwa %0, %2, %0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_0"
                         : "=&v"(res) : "v"(rprev), "v"(dps_bits(A)));
                 } else {
@@ -268,27 +303,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     // (dword q: byte 0 / 1 = "not D" of the low / high halves, byte 2 / 3 = "not I").
                     uint32_t cj = __builtin_amdgcn_perm(sI, sD, 0x0b0a0908u);
                     opaque(cj);   // (volatile, like the chain above: the bits are made HERE -- left to itself the compiler makes all 58 registers' bits at the end of the row, with every register's sub / ins / A / chain live until then: ~400 VGPRs)
-                    dirw[j >> 3] |= cj & (0x01010101u << (j & 7));
-                    if ((j & 7) == 7 || j == NPK - 1) {
-                        if (((j >> 3) & 3) == 3 && (j >> 3) < NDQ - 1 && mine && h <= tlen) {   // a unit of four dwords leaves as soon as it is complete (its registers are free for the rest of the row)
-                            typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                            const int q0 = (j >> 3) - 3;
-                            aim_u32x4 w0 = {dirw[q0], dirw[q0 + 1], dirw[q0 + 2], dirw[q0 + 3]};
-                            __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, q0)));
-                        }
-                    }
+                    dcur |= cj & (0x01010101u << (j & 7));
                 }
                 dst[j] = res;
                 rprev = res;
                 oldprev = oldj;
-
+            };
+#pragma unroll
+            for (int k = J0 >> 3; k < NDQ; ++k) {             // dword k: registers 8k .. 8k + 7
+                const bool inw = BT && ((k >= q0 && k < q0 + 4) || (k < 3 && wtail));   // kept by the row (the band), or one of the first three and a pair of the wavefront has tail cells: wave-uniform
+                if (inw) {
+#pragma unroll
+                    for (int j = (8 * k > J0 ? 8 * k : J0); j < 8 * k + 8 && j < NPK; ++j) reg(j, std::true_type{});
+                    if (k >= q0 && k < q0 + 4) unit[k & 3] = dcur;
+                    if (k < 3) unit2[k] = dcur;
+                    dcur = 0u;
+                } else {
+#pragma unroll
+                    for (int j = (8 * k > J0 ? 8 * k : J0); j < 8 * k + 8 && j < NPK; ++j) reg(j, std::false_type{});
+                }
             }
             if (h == tlen) score = (int)(int16_t)(dst[NPK - 1] >> 16) + GAP_I * tlen + GAP_D * pe;   // R_tlen[pe], un-tilted
-            if (BT && mine && h <= tlen) {                     // the row's direction bits: two 16-byte stores per lane
-                typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
-                aim_u32x4 w1 = {dirw[NDQ - 4], dirw[NDQ - 3], dirw[NDQ - 2], dirw[NDQ - 1]};   // the last unit (the earlier ones left mid-row)
-                if (NPK <= 32) { aim_u32x4 w0 = {dirw[0], dirw[1], dirw[2], dirw[3]}; __builtin_nontemporal_store(w0, reinterpret_cast<aim_u32x4 *>(&TBW(h, 0))); }
-                __builtin_nontemporal_store(w1, reinterpret_cast<aim_u32x4 *>(&TBW(h, NDQ - 4)));
+            if (BT && mine && h <= tlen && !(a.dbg_flags & 4u)) {
+                __builtin_nontemporal_store(unit, TBU(h));   // the row's window: one 16-byte store per lane
+                if (ntail > 0) __builtin_nontemporal_store(unit2, TBU2(h));
             }
         };
         // plen >= tlen + 2 (score-only): the last row's tail cells v = W + c, c = 1 .. ntail, right after that row (nw.c:137-145 with the flat indices resolved: the
@@ -364,11 +402,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             continue;
         }
-        // nw_traceback (nw.c:67-107) over the direction bits (see the header): one dependent load per step; 'X' / 'M' from the sequences.
-        // Ops staged in LDS (the text image is dead by now), copied out in 16-byte pieces.
+        // nw_traceback (nw.c:67-107) over the direction bits (see the header); 'X' / 'M' from the sequences. Ops staged in LDS (the text image is dead by
+        // now), copied out in 16-byte pieces. Round 6: the rows' units are fetched EIGHT ROWS AT A TIME (independent loads, one round trip) and the walk runs
+        // through them row by row -- the walk never returns to a row it has left, so the unrolled row index is static. (Until round 5: one dependent HBM load per
+        // step, ~100 round trips of ~1 us per pair: 0.97 of the kernel's 3.6 ms at l = 100.)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (mine) {
+        bool lost = false;                                     // the walk left the band: the pair goes to the to-do list
+        if (mine && !(a.dbg_flags & 5u)) {
             int begin_offset = plen + tlen - 1;
             const int end_offset = plen + tlen;
             char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
@@ -377,48 +418,96 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
-            while (h > 0 && v > 0) {
-                // the cell the reference reads at flat index W h + v. v <= W: cell (h, v) of the table. v > W (a pair with tail cells; the walk got here
-                // from the last row's tail): the flat index lies in row h + 1 -- the last row's tail cell v - W (h == tlen: its bits are in `tailbits`,
-                // its characters its own), or cell (h + 1, v - W) of the table, which overwrote the tail cell of row h (that cell's characters)
-                uint32_t code;
-                int pi = v - 1, ti = h - 1;
-                if (v > W && h == tlen) code = (tailbits >> (2 * (v - W))) & 3u;
-                else {
-                    const int hh = v > W ? h + 1 : h, vv = v > W ? v - W : v;
-                    if (v > W) { pi = vv - 1; ti = hh - 1; }
-                    const int i = vv + s0, j = i >> 1;
-                    const uint32_t word = TBW(hh, j >> 3) >> (8 * (i & 1) + (j & 7));
-                    code = (word & 1u) | ((word >> 15) & 2u);
+            // one step of the walk on a cell's code (bit 0 "not D", bit 1 "not I"; a macro: as a lambda capturing h, v and the cursor by reference the closure was kept in scratch)
+#define NW_STEP(code_, pch_, tch_) do { const uint32_t cd_ = (code_);                                                                       \
+                if (!(cd_ & 1u)) { OPS(sentinel) = 'D'; --sentinel; --v; }                                                                    \
+                else if (!(cd_ & 2u)) { OPS(sentinel) = 'I'; --sentinel; --h; }                                                               \
+                else { OPS(sentinel) = ((pch_) != (tch_)) ? 'X' : 'M'; --sentinel; --h; --v; } } while (0)
+            // The walk's characters without a dependent global load per step (two per 'M' / 'X' step until round 6: what was left of the walk's time once the
+            // direction bits came eight rows at a time): the PATTERN row is staged in LDS, in the ops area's own layout (row byte i at OPS(i)) -- the cursor
+            // never reaches a pattern byte that is still to be read (cursor - (v - 1) = h >= 1 at every step) --, the TEXT characters of a batch's eight rows
+            // come with the batch (row h needs t[h - 1] only).
+            for (int b = 0; 16 * b < rs; ++b) {
+                const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
+                *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // A pair with tail cells starts in the last row's tail: the cell the reference reads at flat index W h + v with v > W is the tail cell v - W (h == tlen:
+            // its bits are in `tailbits`, its characters its own). Above the last row such an index is cell (h + 1, v - W) of the table -- the row's first columns,
+            // far outside the band: to-do list.
+            constexpr int NB = 8;                             // rows per batch
+            aim_u32x4 u[NB];                                  // the units of rows h0 .. h0 - NB + 1 ...
+            uint32_t tc[NB];                                  // ... and those rows' text characters
+            int h0 = -1;
+            while (h > 0 && v > 0 && !lost) {
+                while (h > 0 && v > W) {                      // (pairs with tail cells, until the walk is back inside the table's own columns: one dependent load per step)
+                    if (h == tlen) NW_STEP((tailbits >> (2 * (v - W))) & 3u, OPS(v - 1), tbytes[h - 1]);
+                    else {
+                        const int vv = v - W, i = vv + s0;    // cell (h + 1, v - W); its characters are that cell's own
+                        const aim_u32x4 w = __builtin_nontemporal_load(TBU2(h + 1));
+                        const uint32_t word = band_pick(w[0], w[1], w[2], 0u, i >> 4) >> (8 * (i & 1) + ((i >> 1) & 7));
+                        NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(vv - 1), tbytes[h]);
+                    }
                 }
-                if (!(code & 1u)) { OPS(sentinel) = 'D'; --sentinel; --v; }
-                else if (!(code & 2u)) { OPS(sentinel) = 'I'; --sentinel; --h; }
-                else { OPS(sentinel) = (pb[pi] != tbytes[ti]) ? 'X' : 'M'; --sentinel; --h; --v; }
+                if (!(h > 0 && v > 0)) break;
+                if (h != h0) {                                // the first batch: rows h .. h - NB + 1
+                    h0 = h;
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) { u[r] = __builtin_nontemporal_load(TBU(max(h0 - r, 1))); tc[r] = tbytes[max(h0 - r, 1) - 1]; }
+                }
+                aim_u32x4 un[NB];                             // the NEXT batch is asked for before this one is walked: its round trip hides behind the steps
+                uint32_t tn[NB];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= W from here on)
+                        const int i = v + s0, q = i >> 4;
+                        const int qw = band_q0(h);
+                        if (q < qw || q >= qw + 4) { lost = true; break; }
+                        const uint32_t word = band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 7));
+                        NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(v - 1), tc[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NB; ++r) { u[r] = un[r]; tc[r] = tn[r]; }
+                h0 -= NB;
             }
-            while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
-            while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
-            begin_offset = sentinel + 1;
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(smem);
-                uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
-                for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q * kWave + lane];
+            if (!lost) {
+                while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+                while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
+                begin_offset = sentinel + 1;
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+                    uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                    for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q * kWave + lane];
+                }
+                aim_result_t res;
+                res.max_operations = plen + tlen;
+                res.begin_offset = begin_offset;
+                res.end_offset = end_offset;
+                res.score = score;
+                res.status = AIM_PAIR_OK;
+                res.idx = rq.idx;
+                store_result(a, pair, res);
             }
+#undef NW_STEP
 #undef OPS
-            aim_result_t res;
-            res.max_operations = plen + tlen;
-            res.begin_offset = begin_offset;
-            res.end_offset = end_offset;
-            res.score = score;
-            res.status = AIM_PAIR_OK;
-            res.idx = rq.idx;
-            store_result(a, pair, res);
+        }
+        {   // pairs whose walk left the band: nw_lane_kernel aligns them again behind this kernel (one atomic per wavefront that holds one)
+            const unsigned long long lm = __ballot(lost);
+            if (lm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(lm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (lost) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))] = pair;
+            }
         }
     }
-#undef TBW
+#undef TBU
 }
 
 // bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
-inline size_t nw_reg_slab_bytes(int npk, int read_size) { return (size_t)(read_size + 2) * (npk > 64 ? 12 : 8) * 4 * kWave; }   // 8 (12) dwords of direction bits per row and lane
+inline size_t nw_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * 2 * 16 * kWave; }   // per row and lane one 16-byte unit of direction bits (the band) + one for the first columns (pairs with tail cells)
 
 
 // =====================================================================================================================================
@@ -482,7 +571,7 @@ __host__ __device__ inline size_t swg_reg_lds_bytes(const aim_params_t &p, int n
     const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 61 ? 2 : 1), o = (size_t)2 * p.read_size * kWave;   // (npk > 61: text image + pattern image)
     return ((bt && o > t) ? o : t) + 1024;
 }
-inline size_t swg_reg_slab_bytes(int npk, int read_size) { return (size_t)(read_size + 2) * swg_reg_units(npk) * 16 * kWave; }
+inline size_t swg_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * (16 + 4) * kWave; }   // per row and lane one 16-byte unit of direction bits (the band) + dword 0 (pairs with tail cells)
 
 // the D chain of one register: Dprev / Aprev carry the left neighbour's D and A + o + e in their HIGH halves, aoe = {A.lo + oe, A.hi + oe}
 __device__ __forceinline__ uint32_t swg_chain(uint32_t Dprev, uint32_t Aprev, uint32_t aoe, uint32_t e2)
@@ -513,7 +602,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int OE = a.p.gap_o + a.p.gap_e, GAP_E = a.p.gap_e, MISMATCH = a.p.mismatch, MAXS = a.p.max_score;
     uint32_t *todo = const_cast<uint32_t *>(a.todo);                     // OUT: pairs left to swg_lane_kernel ({count @0, pair ids @16..})
     uint32_t *tbw = BT ? reinterpret_cast<uint32_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave) : nullptr;
-#define TBW(h, q) tbw[((size_t)((h) * NU + ((q) >> 2)) * kWave + lane) * 4 + ((q) & 3)]
+    // (round 6: ONE 16-byte unit per row and lane -- the band of four consecutive dwords = 32 columns around the diagonal, dword q in slot q & 3; see nw_reg_kernel)
+    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+#define TBU(h) (reinterpret_cast<aim_u32x4 *>(tbw) + ((size_t)(h) * kWave + lane))
+    // ... and, for pairs with tail cells (plen >= tlen + 2), dword 0 of every row (columns 1 .. 8) in a plane of its own: a step up or diagonally from a tail
+    // cell continues at cell (h + 1, v - W), one of the next row's first eight columns (see nw_reg_kernel)
+#define TBD0(h) (tbw + ((size_t)(rs + 2) * kWave * 4 + (size_t)(h) * kWave + lane))
     const uint32_t n_groups = (a.n_pairs + kWave - 1) / kWave;
     uint32_t ones = 0x00010001u;
     opaque(ones);
@@ -598,6 +692,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         uint32_t hot = (ISW && jl >= JW) ? 1u << (jl - JW) : 0u;
         opaque(hot);
         const int hmax = -wave_min_i32(mine ? -tlen : 0);
+        // BACKTRACE: the band's centre line relative to index h - 1 (wave-uniform). Rows are LEFT-aligned (column v at index v - 1): a pair's path runs between the
+        // diagonal through (0, 0), index h - 1, and the one through (tlen, pe), index h - 1 + (pe - tlen). The window of row h is the four dwords from q0(h) on:
+        // 32 indices, at least +-12 about the centre; direction bits are MADE for the window's registers only (4 bits per cell cost 9 of a register's 24
+        // instructions), and a walk that leaves the window sends its pair to the to-do list (swg_lane_kernel).
+        int bandc = 0;
+        if (BT) {
+            const int dd = pe - tlen;
+            bandc = (wave_min_i32(mine ? min(dd, 0) : 0) - wave_min_i32(mine ? -max(dd, 0) : 0)) >> 1;
+        }
+        auto band_q0 = [&](int h) { return min(max((bandc + h - 13) >> 3, 0), NQ > 4 ? NQ - 4 : 0); };
+        const bool wtail = BT && ISW && __ballot(mine && lw && plen > pe) != 0ull;   // a pair of this wavefront has tail cells
         // registers the rows run over: the last four are skipped when no lane's columns reach them (score-only; a wave-uniform test per register: a column
         // never reads a higher index, so stale values there harm nobody). l = 100 at READ_SIZE 112: 50 of 53.
         const int njrun = BT ? NPK : -wave_min_i32(mine ? -((pe + 1) >> 1) : 0);
@@ -611,13 +716,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 uint32_t oldprev = MbOldH;                    // M[h-1][0] in the high half
                 uint32_t Ml = 0u, Dl = 0u;                    // ISW: {M, D} of the row's last cell
                 uint32_t dword = 0u;
-                typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
                 aim_u32x4 unit = {0u, 0u, 0u, 0u};
+                const int q0 = BT ? band_q0(h) : 0;           // wave-uniform
                 uint32_t diag = __builtin_amdgcn_alignbit(M[0], oldprev, 16);           // {M[h-1][index - 1]} of register 0's cells
                 uint32_t pword = 0u;                                                    // PL: the pattern dword of the current two registers
-#pragma unroll
-                for (int j = 0; j < NPK; ++j) {
-                    if (!BT && j >= NPK - 4 && j >= njrun) continue;
+                // one register (two cells). BITS: with its four direction bits per cell (BACKTRACE, registers of the dwords the row keeps: ONE wave-uniform branch per dword
+                // of four registers; a branch per register left two wavefronts per SIMD waiting on 37 taken branches per row)
+                auto reg = [&](int j, auto bits_tag) __attribute__((always_inline)) {
+                    constexpr bool BITS = decltype(bits_tag)::value;
                     // everything that reads the OLD row's register j is taken first -- the next register's diagonal too -- so that the new value
                     // can be written over it (in place: as a plain read-later the compiler kept a v_mov copy per register and row)
                     uint32_t insn = add2(M[j], oe2);
@@ -639,7 +745,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     uint32_t m = min2(A, d);
                     opaque(m);   // (made HERE, inside the `h <= tlen` region: otherwise the compiler sinks the 53 minima behind the region's end -- legal, min(min(A, d), d) is what a
                                  //  lane outside it needs -- and keeps every register's d alive until then: 256 VGPRs + 33 AGPRs = one wavefront per SIMD)
-                    if (BT) {
+                    if (BITS) {
                         const uint32_t aleft = __builtin_amdgcn_alignbit(aoe, Aprev, 16);       // {A + o + e} of both cells' left neighbours
                         const uint32_t dA = sub2(A, d), dB = sub2(mm, ins), dC = sub2(d, aleft), dD = sub2(inse, insn);
                         uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);               // bytes {A.lo, A.hi, B.lo, B.hi} sign -> 0x00 / 0xff
@@ -649,14 +755,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         const uint32_t k1 = 0x01010101u << (j & 3), k2 = 0x10101010u << (j & 3);
                         dword = (w1 & k1) | (dword & ~k1);
                         dword = (w2 & k2) | (dword & ~k2);
-                        if ((j & 3) == 3 || j == NPK - 1) {
-                            unit[(j >> 2) & 3] = dword;
-                            dword = 0u;
-                            if (((j >> 2) & 3) == 3 || j == NPK - 1) {   // a 16-byte unit leaves as soon as it is complete
-                                __builtin_nontemporal_store(unit, reinterpret_cast<aim_u32x4 *>(&TBW(h, (j >> 2) & ~3)));
-                                unit = aim_u32x4{0u, 0u, 0u, 0u};
-                            }
-                        }
                     }
                     if (ISW && j >= JW) {
                         const uint32_t wmk = (uint32_t)__builtin_amdgcn_sbfe((int)hot, j - JW, 1);   // all ones in the lanes whose cell (h, W) lies in register j
@@ -669,7 +767,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     Dprev = d;
                     Aprev = aoe;
                     diag = dnext;
+                };
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) {                // dword k: registers 4k .. 4k + 3
+                    const bool inw = BT && ((k >= q0 && k < q0 + 4) || (ISW && k == 0 && wtail));   // kept by the row (the band), or dword 0 and a pair of the wavefront has tail cells: wave-uniform
+                    if (inw) {
+#pragma unroll
+                        for (int j = 4 * k; j < 4 * k + 4 && j < NPK; ++j) reg(j, std::true_type{});
+                        if (k >= q0 && k < q0 + 4) unit[k & 3] = dword;
+                        if (ISW && k == 0 && lw && plen > pe && !(a.dbg_flags & 4u)) __builtin_nontemporal_store(dword, TBD0(h));
+                        dword = 0u;
+                    } else {
+#pragma unroll
+                        for (int j = 4 * k; j < 4 * k + 4 && j < NPK; ++j) {
+                            if (!BT && j >= NPK - 4 && j >= njrun) continue;   // (score-only: the last four registers are skipped when no lane's columns reach them)
+                            reg(j, std::false_type{});
+                        }
+                    }
                 }
+                if (BT && mine && !(a.dbg_flags & 4u)) __builtin_nontemporal_store(unit, TBU(h));   // the row's window: one 16-byte store per lane
                 MbOldH = MbH;
                 if (ISW) {                                    // plen > tlen: the next row's boundary cell is this row's cell (h, W); else o + (h + 1) e, wrapped, D stays MAX_SCORE
                     MbH = lw ? (lhi ? (Ml & 0xffff0000u) : (Ml << 16)) : MbH + eH;
@@ -744,12 +860,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         int begin_offset = plen + tlen - 1;
         const int end_offset = plen + tlen;
+        bool lost = false;                                    // the walk left the band: the pair goes to the to-do list
         if (BT) {
-            // swg_traceback (swg.c:45-119) over the direction bits: one dependent load per step; 'X' / 'M' from the sequences. Ops staged in LDS (the
-            // text image is dead by now), copied out in 16-byte pieces.
+            // swg_traceback (swg.c:45-119) over the direction bits; 'X' / 'M' from the sequences. Ops staged in LDS (the text image is dead by now), copied out in
+            // 16-byte pieces. Round 6: the rows' units are fetched eight rows at a time and the walk runs through them row by row (see nw_reg_kernel).
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
-            if (mine && !bad) {
+            if (mine && !bad && !(a.dbg_flags & 5u)) {
                 char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
                 const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
                 unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem);
@@ -758,39 +875,77 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 int h = tlen, v = plen;
                 int layer = 0;                                // 0: M, 1: I, 2: D
                 const int Wc = tlen + 1;
-                while (h > 0 && v > 0) {
-                    // the cell the reference reads at flat index W h + v. v <= W: cell (h, v) of the table. v > W (a pair with tail cells; the walk got here
-                    // from the last row's tail): the flat index lies in row h + 1 -- the last row's tail cell v - W (h == tlen: its bits are in `tailbits`,
-                    // its characters its own), or cell (h + 1, v - W) of the table, which overwrote the tail cell of row h (that cell's characters)
-                    uint32_t bits;                            // bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended
-                    int pi = v - 1, ti = h - 1;
-                    if (v > Wc && h == tlen) {
-                        const uint32_t nb = tailbits >> (4 * ((v - Wc) & 7));
-                        bits = (nb & 1u) | ((nb & 2u) << 15) | ((nb & 4u) << 2) | ((nb & 8u) << 17);
-                    } else {
-                        const int hh = v > Wc ? h + 1 : h, vv = v > Wc ? v - Wc : v;
-                        if (v > Wc) { pi = vv - 1; ti = hh - 1; }
-                        const int i = vv - 1, j = i >> 1;
-                        bits = TBW(hh, j >> 2) >> (8 * (i & 1) + (j & 3));
-                    }
-                    if (layer == 2) { OPS(sentinel) = 'D'; --sentinel; if (!(bits & 0x10u)) layer = 0; --v; }
-                    else if (layer == 1) { OPS(sentinel) = 'I'; --sentinel; if (!(bits & 0x100000u)) layer = 0; --h; }
-                    else if (!(bits & 1u)) layer = 2;
-                    else if (!(bits & 0x10000u)) layer = 1;
-                    else { OPS(sentinel) = (pb[pi] != tbytes[ti]) ? 'X' : 'M'; --sentinel; --h; --v; }
+                // one step of the walk on a cell's bits (bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended; a macro, see nw_reg_kernel)
+#define SWG_STEP(bits_, pch_, tch_) do { const uint32_t bq_ = (bits_);                                                                      \
+                    if (layer == 2) { OPS(sentinel) = 'D'; --sentinel; if (!(bq_ & 0x10u)) layer = 0; --v; }                                  \
+                    else if (layer == 1) { OPS(sentinel) = 'I'; --sentinel; if (!(bq_ & 0x100000u)) layer = 0; --h; }                         \
+                    else if (!(bq_ & 1u)) layer = 2;                                                                                          \
+                    else if (!(bq_ & 0x10000u)) layer = 1;                                                                                    \
+                    else { OPS(sentinel) = ((pch_) != (tch_)) ? 'X' : 'M'; --sentinel; --h; --v; } } while (0)
+                // the pattern row staged in LDS in the ops area's own layout, the text characters of a batch's rows with the batch (see nw_reg_kernel)
+                for (int b = 0; 16 * b < rs; ++b) {
+                    const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
+                    *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
-                while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
-                begin_offset = sentinel + 1;
-                {
+                // A pair with tail cells starts in the last row's tail: flat index W h + v with v > W is the tail cell v - W (h == tlen: its bits are in `tailbits`,
+                // its characters its own); above the last row it is cell (h + 1, v - W) of the table -- the row's first columns, far outside the band: to-do list.
+                constexpr int NB = 8;                         // rows per batch
+                aim_u32x4 u[NB];                              // the units of rows h0 .. h0 - NB + 1 ...
+                uint32_t tc[NB];                              // ... and those rows' text characters
+                int h0 = -1;
+                while (h > 0 && v > 0 && !lost) {
+                    while (h > 0 && v > Wc) {                 // (pairs with tail cells, until the walk is back inside the table's own columns: one dependent load per step)
+                        if (h == tlen) {
+                            const uint32_t nb = tailbits >> (4 * ((v - Wc) & 7));
+                            SWG_STEP((nb & 1u) | ((nb & 2u) << 15) | ((nb & 4u) << 2) | ((nb & 8u) << 17), OPS(v - 1), tbytes[h - 1]);
+                        } else {
+                            const int vv = v - Wc, i = vv - 1;  // cell (h + 1, v - W), columns 1 .. 8: dword 0; its characters are that cell's own
+                            SWG_STEP(__builtin_nontemporal_load(TBD0(h + 1)) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(vv - 1), tbytes[h]);
+                        }
+                    }
+                    if (!(h > 0 && v > 0)) break;
+                    if (h != h0) {                            // the first batch: rows h .. h - NB + 1
+                        h0 = h;
+#pragma unroll
+                        for (int r = 0; r < NB; ++r) { u[r] = __builtin_nontemporal_load(TBU(max(h0 - r, 1))); tc[r] = tbytes[max(h0 - r, 1) - 1]; }
+                    }
+                    aim_u32x4 un[NB];                         // the NEXT batch is asked for before this one is walked
+                    uint32_t tn[NB];
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) {
+                        while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= Wc from here on)
+                            const int i = v - 1, q = i >> 3;
+                            const int qw = band_q0(h);
+                            if (q < qw || q >= qw + 4) { lost = true; break; }
+                            SWG_STEP(band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(v - 1), tc[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) { u[r] = un[r]; tc[r] = tn[r]; }
+                    h0 -= NB;
+                }
+                if (!lost) {
+                    while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+                    while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
+                    begin_offset = sentinel + 1;
                     const uint4 *src = reinterpret_cast<const uint4 *>(smem);
                     uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
                     for (int qq = begin_offset >> 4; qq <= (end_offset - 1) >> 4; ++qq) dst[qq] = src[qq * kWave + lane];
                 }
+#undef SWG_STEP
 #undef OPS
             }
+            const unsigned long long lm = __ballot(lost);
+            if (lm) {   // pairs whose walk left the band: swg_lane_kernel aligns them again behind this kernel
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(lm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (lost) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(lm & mask_below)] = pair;
+            }
         }
-        if (mine && !bad) {
+        if (mine && !bad && !lost) {
             aim_result_t res;
             res.max_operations = plen + tlen;
             res.begin_offset = begin_offset;
@@ -843,7 +998,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (qn[0] >= (uint32_t)kWave) run(std::false_type{}, queue, qn[0]);    // (each variant is inlined once)
         else if (second) run(std::true_type{}, queue + 128, qn[1]);
     }
-#undef TBW
+#undef TBU
 }
 
 // Kernels are instantiated in ONE translation unit (tu_dp_reg.hip defines AIM_TU_DP_REG); every other includer sees the declaration only.

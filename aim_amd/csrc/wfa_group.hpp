@@ -266,12 +266,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         }
         __builtin_amdgcn_sched_barrier(0);
 
+#ifdef AIM_GROUP_COUNT_TRIPS    // diagnostic builds only (tools/group_trips.py): what the WAVEFRONT executes -- score steps, trips of the k-loop, trips of
+        // extend's while loop -- counted once per trip by whichever lane is the first active one, summed over the lanes at the end and
+        // reported through the result of the wavefront's first pair (max_operations = k-trips, begin_offset = extend trips, end_offset = score steps)
+        int dbg_kt = 0, dbg_et = 0, dbg_st = 0;
+#define AIM_GTRIP(c) do { const unsigned long long ex_ = __ballot(1); if (lane == __ffsll((long long)ex_) - 1) ++(c); } while (0)
+#else
+#define AIM_GTRIP(c) do { } while (0)
+#endif
         // ---- affine_wfa_extend on packed words (wfa.c:186-208) -----------------------------------------------------
         auto extend = [&](int k, int off) -> int {
             int v = off - k, h = off;
             if (off < 0 || v < 0) return off;
             int rem = min(plen - v, tlen - h);
             while (rem > 0) {
+                AIM_GTRIP(dbg_et);
                 // 32 bases per trip: the trip count of a wavefront is its longest run, and every pair has one diagonal on
                 // which runs average 1/e bases (same box, 16 -> 32 bases: l=100 e=5 % +3.3 %, l=150 e=2 % +6 %, cfg3 +2-3 %).
                 // Word wp + 2 may lie one dword past the pair's packed image (the next array, or the workgroup's 64-B LDS
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
         int klo = 0, khi = 0, flags = GF_PRESENT | GF_INULL | GF_DNULL;
         // Every later wavefront is extended by the lane that computes it (below); score 0 has no compute step.
         int part = 0x7fffffff;                     // min over my diagonals of the distance to the end (for the reduction)
-        int dist0 = 0x7fffffff, dist1 = 0x7fffffff; // that distance on my first and second diagonal of the current row
+        int dist0 = 0x7fffffff, dist1 = 0x7fffffff, dist2 = 0x7fffffff; // that distance on my first, second and third diagonal of the current row
         // history region of this pair (BACKTRACE): descriptor table + pool
         char *hreg = BT ? hist_base + (size_t)(active ? pair : 0u) * (size_t)c.hist_pair_bytes : nullptr;
         TbRow *htab = reinterpret_cast<TbRow *>(hreg + sizeof(TbHead));
@@ -335,14 +344,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     const int mind = min(max(plen, tlen), group_min<G>(part));
                     int kfirst = 0x7fffffff, klast = -0x7fffffff;
                     // A live row was computed by the previous score step over the same [klo, khi] with the same lanes: the distances of
-                    // my first two diagonals are still in registers (dist0, dist1); only rows wider than 2 G are read back from LDS.
+                    // my first three diagonals are still in registers (dist0 .. dist2; round 6: the third -- 58 % of cfg3's steps have a pair wider than 2 G); only rows wider than 3 G are read back from LDS.
                     {
-                        const int k0 = klo + g, k1 = k0 + G;
-                        const bool c0 = k0 <= khi && dist0 - mind <= 50, c1 = k1 <= khi && dist1 - mind <= 50;
-                        kfirst = c0 ? k0 : (c1 ? k1 : kfirst);
-                        klast = c1 ? k1 : (c0 ? k0 : klast);
+                        const int k0 = klo + g, k1 = k0 + G, k2 = k1 + G;
+                        const bool c0 = k0 <= khi && dist0 - mind <= 50, c1 = k1 <= khi && dist1 - mind <= 50, c2 = k2 <= khi && dist2 - mind <= 50;
+                        kfirst = c0 ? k0 : (c1 ? k1 : (c2 ? k2 : kfirst));
+                        klast = c2 ? k2 : (c1 ? k1 : (c0 ? k0 : klast));
                     }
-                    for (int k = klo + g + 2 * G; k <= khi; k += G) {
+                    for (int k = klo + g + 3 * G; k <= khi; k += G) {
                         const int off = mrow[H(k)];
                         if ((max(plen - (off - k), tlen - off) - mind) <= 50) { kfirst = min(kfirst, k); klast = max(klast, k); }
                     }
@@ -374,6 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
             }
             AIM_GSTAMP(1);   // reduce + descriptors + end test
             if (__ballot(!done) == 0ull) break;
+            AIM_GTRIP(dbg_st);
             ++score;
             sm = sm + 1 == c.ring_m ? 0 : sm + 1;
             i_x = back(X); i_oe = back(OE); i_e = back(E);
@@ -429,9 +439,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                     int16_t *om = mrow_at(sm), *oi = islot(score), *od = dslot(score);
                     part = 0x7fffffff;
                     int trip = 0;
+                    // What an ABSENT component reads as is -10 (the reference's un-computed default), what an out-of-range fetch reads as is NULL:
+                    // when a component is absent every fetch that feeds it is out of range (its sources are null: ranges 1 .. -1), so the
+                    // "out of range" value of those fetches is made -10 once per step instead of one more select per cell and component (round 6).
+                    const int nul_i = i_out_null ? -10 : kGrpNull, nul_d = d_out_null ? -10 : kGrpNull, nul_s = m_sub_null ? -10 : kGrpNull;
                     // homes advance with k: one conditional subtraction per step instead of a modulo per address (3 per trip)
-                    auto wrap_up = [&](int h_) { if constexpr (MODW) return h_ >= wl ? h_ - wl : h_; else return h_ & wmask; };
-                    auto wrap_dn = [&](int h_) { if constexpr (MODW) return h_ < 0 ? h_ + wl : h_; else return h_ & wmask; };
+                    // (MODW: the unsigned minimum of h and h -+ wl is the one that lies in [0, wl): two instructions, no compare + select)
+                    auto wrap_up = [&](int h_) { if constexpr (MODW) return (int)min((uint32_t)h_, (uint32_t)(h_ - wl)); else return h_ & wmask; };
+                    auto wrap_dn = [&](int h_) { if constexpr (MODW) return (int)min((uint32_t)h_, (uint32_t)(h_ + wl)); else return h_ & wmask; };
                     int hk = H(lo + g);
                     for (int k = lo + g; k <= hi_run; k += G, ++trip, hk = wrap_up(hk + G)) {   // affine_wfa_compute_offsets, wfa.c:231-266, + affine_wfa_extend
                         // The five source cells are fetched TOGETHER and unconditionally (every row is a valid LDS row of
@@ -440,21 +455,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         // exec-masked branch and one LDS round trip EACH: five dependent round trips per cell. (Round 4: I and D are
                         // COMPUTED unconditionally too and only their stores are predicated -- as `if (!i_out_null) { ... }` blocks the
                         // compiler sank two of the five loads into the blocks, i.e. back into a second round trip.)
+                        AIM_GTRIP(dbg_kt);
                         const int hkm = wrap_dn(hk - 1), hkp = wrap_up(hk + 1);
                         const int raw_mo_m1 = r_mo[hkm], raw_ie_m1 = r_ie[hkm], raw_mo_p1 = r_mo[hkp], raw_de_p1 = r_de[hkp],
                                   raw_ms = r_ms[hk];
                         const int ins_g = (!m_o_null && o_lo <= k - 1 && k - 1 <= o_hi) ? raw_mo_m1 : kGrpNull;
                         const int ins_i = (!i_e_null && e_lo <= k - 1 && k - 1 <= e_hi) ? raw_ie_m1 : kGrpNull;
                         // (offsets are <= READ_SIZE <= 16 368 or kGrpNull: the reference's int16 store of offset + 1 never wraps, so no cast is spelled out)
-                        const int ins_v = (ins_g == kGrpNull && ins_i == kGrpNull) ? kGrpNull : max(ins_g, ins_i) + 1;
-                        const int ins = i_out_null ? -10 : ins_v;
+                        const int ins = (ins_g == kGrpNull && ins_i == kGrpNull) ? nul_i : max(ins_g, ins_i) + 1;   // i_out_null: both are NULL -> -10
                         if (!i_out_null) oi[hk] = (int16_t)ins;
-                        const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? raw_mo_p1 : kGrpNull;
-                        const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? raw_de_p1 : kGrpNull;
-                        const int del = d_out_null ? -10 : max(del_g, del_d);
+                        const int del_g = (!m_o_null && o_lo <= k + 1 && k + 1 <= o_hi) ? raw_mo_p1 : nul_d;
+                        const int del_d = (!d_e_null && e_lo <= k + 1 && k + 1 <= e_hi) ? raw_de_p1 : nul_d;
+                        const int del = max(del_g, del_d);                                                            // d_out_null: both are nul_d = -10
                         if (!d_out_null) od[hk] = (int16_t)del;
-                        int sub = -10;
-                        if (!m_sub_null) sub = (sub_lo <= k && k <= sub_hi) ? raw_ms + 1 : kGrpNull;
+                        const int sub = (sub_lo <= k && k <= sub_hi) ? raw_ms + 1 : nul_s;                            // m_sub_null: range 1 .. -1 -> -10
                         // M[s][k] as the reference stores it (int16), then affine_wfa_extend (wfa.c:186-208) on that value: a
                         // diagonal's extension depends on nothing but its own offset, so it is applied before the one store
                         const int ext = extend(k, max(del, max(sub, ins)));
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
                         if (BT) hrow[hnarrow ? hk : k] = make_uint2((uint32_t)(uint16_t)ext | ((uint32_t)(uint16_t)ins << 16), (uint32_t)(uint16_t)del);   // I / D: -10 when absent (never selected)
                         const int dist = max(plen - (ext - k), tlen - ext);
                         part = min(part, dist);
-                        if (REDUCE) { dist0 = trip == 0 ? dist : dist0; dist1 = trip == 1 ? dist : dist1; }
+                        if (REDUCE) { dist0 = trip == 0 ? dist : dist0; dist1 = trip == 1 ? dist : dist1; dist2 = trip == 2 ? dist : dist2; }
                     }
                 }
                 AIM_GSTAMP(3);   // compute + extend loop
@@ -495,9 +509,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
 #ifdef AIM_GROUP_COUNT_WIDTHS
                 r.max_operations = dbg_wsum; r.begin_offset = dbg_w32; r.end_offset = dbg_w64;
 #endif
+#ifdef AIM_GROUP_COUNT_TRIPS
+                r.max_operations = r.begin_offset = r.end_offset = 0;
+#endif
                 store_result(a, pair, r);
             }
         }
+#ifdef AIM_GROUP_COUNT_TRIPS
+        if (!BT) {
+            int kt = dbg_kt, et = dbg_et, st = dbg_st;
+            for (int o = 32; o; o >>= 1) { kt += __shfl_xor(kt, o); et += __shfl_xor(et, o); st += __shfl_xor(st, o); }
+            __builtin_amdgcn_s_waitcnt(0);   // (after the pairs' own result stores)
+            if (lane == 0 && unit * PPW < a.n_pairs && a.res != nullptr && !(a.p.flags & AIM_FLAG_RES8)) {
+                aim_result_t *r0 = a.res + (size_t)unit * PPW;
+                r0->max_operations = kt; r0->begin_offset = et; r0->end_offset = st;
+            }
+        }
+#endif
         have = nhave;
         unit = nunit;
         AIM_GSTAMP(7);   // backtrace + result

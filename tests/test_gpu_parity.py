@@ -1786,6 +1786,45 @@ def test_swg_rows_in_registers_kernel(gpu, monkeypatch, l, err, bt):
     assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
 
 
+@pytest.mark.parametrize("algo,l", [("nw", 100), ("swg", 100), ("nw", 150), ("swg", 150), ("nw", 60), ("swg", 40)])
+def test_register_kernels_walk_that_leaves_the_band_goes_to_the_todo_list(gpu, algo, l):
+    """Round 6: with CIGAR nw_reg_kernel / swg_reg_kernel keep direction bits only for a band of four dwords (64 / 32 columns) around the wavefront's centre
+    line, fetch them eight rows at a time, and send a pair whose walk leaves the band to the to-do list (nw_lane / swg_lane), as dp_strip does for cfg4. With
+    cheap gaps a text that is the pattern shifted by a third of its length (a block missing in front, other bases appended: lengths stay equal) is aligned
+    along a diagonal ~l/3 off the corner-to-corner one; related pairs in the same wavefronts stay inside. Scores and CIGARs against the oracle, both kinds; the
+    to-do list holds shifted pairs only."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes(algo, l, 0.02)
+    n = 4000
+    req, pat, txt = engine.gen_pairs(6100 + l, 0, n, l, 0.02, rs)
+    rng = np.random.default_rng(l)
+    shift = max(l * 45 // 100, 21)                                            # the window reaches at most 40 (NW) / 20 (SWG) columns to one side of the centre line
+    shifted = np.zeros(n, dtype=bool)
+    for i in range(0, n, 3):
+        pl = int(req["pattern_len"][i])
+        t = np.concatenate([pat[i, shift:pl], rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=shift).astype(np.uint8)])
+        txt[i, :] = 0
+        txt[i, :pl] = t
+        req["text_len"][i] = pl
+        shifted[i] = True
+    cost = dict(mismatch=5, gap=1) if algo == "nw" else dict(mismatch=6, gap_o=1, gap_e=1)
+    kw = dict(swg_w16=True) if algo == "swg" else {}
+    params = engine.make_params(algo, 60 if algo == "swg" else ms, rs, backtrace=True, **cost, **kw)
+    res, ops, ores = _compare(algo, params, req, pat, txt)
+    assert np.median(ores["score"][shifted]) <= 3 * shift                      # the shifted pairs ARE aligned through the gaps (2 * shift gap columns), not along the main diagonal
+    with engine.DeviceSet(1) as s:
+        s.configure(params, n)
+        s.push(0, req, pat, txt); s.launch(); s.pull(0)
+        assert s.plan_describe(0).startswith(algo + "_reg_kernel"), s.plan_describe(0)
+        fb = s.fallback_pairs(0)
+    assert fb <= shifted.sum() + n // 50, (fb, int(shifted.sum()))
+    if shift > (40 if algo == "nw" else 20):
+        assert fb >= 0.9 * shifted.sum(), (fb, int(shifted.sum()))
+    # the same batch score-only never needs the band
+    params = engine.make_params(algo, 60 if algo == "swg" else ms, rs, backtrace=False, **cost, **kw)
+    _compare(algo, params, req, pat, txt)
+
+
 def test_swg_register_kernel_sends_wrapping_pairs_to_the_literal_kernel(gpu):
     """int8 cells (MAX_SCORE 25, l = 100): unrelated sequences drive cells past 127 (S2 + S3); the register kernel must notice (sign of the OR of
     every stored M) and leave exactly such pairs to swg_lane_kernel -- bit-exact either way, incl. AIM_PAIR_SWG_NO_OP where the oracle has it."""

@@ -128,6 +128,15 @@ def main():
                 if rng.random() < 0.5: req["pattern_len"][i] = rng.randint(0, int(req["pattern_len"][i]))
                 else: req["text_len"][i] = rng.randint(0, int(req["text_len"][i]))
             if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")
+            if rng.random() < 0.3:                                      # shifted texts: paths off the corner-to-corner diagonal (round 6: the register kernels keep direction bits for a band only)
+                for i in range(0, n, rng.choice([1, 3, 17])):
+                    pl, sh = int(req["pattern_len"][i]), rng.randint(1, max(1, l // 2))
+                    if pl <= sh + 1 or pl > rs: continue
+                    t = np.concatenate([pat[i, sh:pl], np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(sh)), dtype=np.uint8)])
+                    if rng.random() < 0.5: t = np.concatenate([t[pl - sh:], t[:pl - sh]])   # ... or shifted the other way
+                    txt[i, :] = 0
+                    txt[i, :pl] = t
+                    req["text_len"][i] = pl
             kn = lib.aim_kernel_name(C.byref(params)).decode()
             case = dict(algo=algo, l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, backtrace=int(bt), cost=cost, env=env)
             try:
@@ -184,6 +193,15 @@ def main():
                     k = int(req["text_len"][i])
                     txt[i, :k] = np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(k)), dtype=np.uint8)
             if n > 3 and rng.random() < 0.3: pat[rng.randrange(n), rng.randrange(max(1, l // 2))] = ord("N")
+            if rng.random() < 0.3:                                      # shifted texts: paths off the corner-to-corner diagonal (round 6: the register kernels keep direction bits for a band only)
+                for i in range(0, n, rng.choice([1, 3, 17])):
+                    pl, sh = int(req["pattern_len"][i]), rng.randint(1, max(1, l // 2))
+                    if pl <= sh + 1 or pl > rs: continue
+                    t = np.concatenate([pat[i, sh:pl], np.frombuffer(bytes(rng.choice(b"ACGT") for _ in range(sh)), dtype=np.uint8)])
+                    if rng.random() < 0.5: t = np.concatenate([t[pl - sh:], t[:pl - sh]])   # ... or shifted the other way
+                    txt[i, :] = 0
+                    txt[i, :pl] = t
+                    req["text_len"][i] = pl
             kn = lib.aim_kernel_name(C.byref(params)).decode()
             case = dict(algo=algo, l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, backtrace=int(bt), cost=cost, env=env)
             try:
