@@ -130,6 +130,7 @@ aim::Knobs read_knobs()
     k.dbg_flags &= 2;    // they exist in diagnostic builds only (python -m aim_amd.build --variant diag --flags "-DAIM_DIAG_BUILD=1"). Bit 2 changes the route, not the result.
 #endif
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
+    k.reg_phase = env_int("AIM_REG_PHASE", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
@@ -404,31 +405,42 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
     // NW / SWG medium reads: G lanes per pair (dp_group.hpp); empty sequences and plen > 2 tlen reach nw_lane / swg_lane (READ_SIZE <= 320) or
     // dp_strip_kernel (to-do mode) through the to-do list. [the pairs' direction-bit slabs OR, afterwards, the fallback kernel's scratch | to-do region]
     if (aim::dp_group_supported(p, kn)) {
+        // (a budget that holds neither this plan nor its fallback is not an error: the plans below -- dp_strip / dp_lane alone -- are tried next)
         Plan fb;
         memset(&fb, 0, sizeof fb);
+        bool ok = true;
         if (p.read_size <= 320) {
             aim::Knobs kq = kn;
             kq.dpl_seq_lds = 0;   // the to-do pass: every lane loads its own pair's rows from global memory (the listed pairs are not consecutive)
             kq.dpl_no_reg = 0;
-            if (!aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds))
-                return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
+            ok = aim::dp_lane_plan(p, n_pairs, budget / 2, kq, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.seq_lds);
             fb.strip_k = 0;
-        } else if (!aim::dp_strip_plan(p, n_pairs, budget / 2, kn, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.strip_k, &fb.pool_cap))
-            return fail(AIM_ENOMEM, "scratch budget (AIM_SCRATCH_GB) or LDS too small for read_size %d", p.read_size);
-        pl->kid = K_DP_GROUP;
-        pl->block = 64;
-        aim::dp_group_plan(p, n_pairs, kn, &pl->grid, &pl->lds, &pl->scratch_per_wg);
-        while (pl->grid > 8 && pl->scratch_per_wg * pl->grid > budget / 2) pl->grid -= 8;
-        if (pl->scratch_per_wg * pl->grid > budget / 2) return fail(AIM_ENOMEM, "scratch budget too small for read_size %d", p.read_size);
-        pl->fb_scratch_per_wg = fb.scratch_per_wg;
-        pl->fb_grid = fb.grid;
-        pl->fb_block = fb.block;
-        pl->fb_lds = fb.lds;
-        pl->strip_k = fb.strip_k;
-        pl->pool_cap = fb.pool_cap;
-        pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
-        pl->scratch_total = ((std::max<size_t>(fb.scratch_total, (size_t)(pl->scratch_per_wg * pl->grid)) + 255) & ~(size_t)255) + pl->todo_bytes;
-        return AIM_OK;
+        } else
+            ok = aim::dp_strip_plan(p, n_pairs, budget / 2, kn, &fb.grid, &fb.block, &fb.lds, &fb.scratch_per_wg, &fb.scratch_total, &fb.strip_k, &fb.pool_cap);
+        if (ok) {
+            uint32_t grid = 0;
+            size_t lds = 0;
+            uint64_t per = 0;
+            aim::dp_group_plan(p, n_pairs, kn, &grid, &lds, &per);
+            while (grid > 8 && per * grid > budget / 2) grid -= 8;
+            ok = per * grid <= budget / 2;
+            if (ok) {
+                pl->kid = K_DP_GROUP;
+                pl->block = 64;
+                pl->grid = grid;
+                pl->lds = lds;
+                pl->scratch_per_wg = per;
+                pl->fb_scratch_per_wg = fb.scratch_per_wg;
+                pl->fb_grid = fb.grid;
+                pl->fb_block = fb.block;
+                pl->fb_lds = fb.lds;
+                pl->strip_k = fb.strip_k;
+                pl->pool_cap = fb.pool_cap;
+                pl->todo_bytes = aim::wfa_lane_todo_bytes(n_pairs);
+                pl->scratch_total = ((std::max<size_t>(fb.scratch_total, (size_t)(pl->scratch_per_wg * pl->grid)) + 255) & ~(size_t)255) + pl->todo_bytes;
+                return AIM_OK;
+            }
+        }
     }
     // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
     if (p.read_size > 320 || kn.force_dpwave) {
@@ -793,6 +805,7 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         uint32_t *todo_d = reinterpret_cast<uint32_t *>((char *)d_scratch + (pl.scratch_total - pl.todo_bytes));
         HIP_TRY(hipMemsetAsync(todo_d, 0, 64, stream));
         ka.todo = todo_d;
+        ka.slot_w = (uint32_t)(kn.reg_phase >= 0 ? kn.reg_phase : p.read_size / 5);   // (dp_reg.hpp: reg_phase_shift)
         if (p.algo == AIM_ALGO_SWG) aim::swg_reg_launch(p, pl.grid, pl.lds, ka, stream);
         else aim::nw_reg_launch(p, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());
@@ -818,7 +831,6 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
             kq.dpl_no_reg = 0;
             aim::dp_lane_launch(p, kq, pl.fb_grid, pl.fb_lds, false, ka, stream);
         } else {
-            HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.fb_grid * pl.fb_scratch_per_wg, 0, 256, stream));
             ka.pool_cap = pl.pool_cap;
             aim::dp_strip_launch(p, pl.strip_k, pl.fb_grid, pl.fb_block, pl.fb_lds, ka, stream);
         }
@@ -829,7 +841,6 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         break;
     case K_DP_STRIP:
         // [slabs | lock words | pool tables of the literal path]: the locks are free at every launch
-        HIP_TRY(hipMemsetAsync((char *)d_scratch + (size_t)pl.grid * pl.scratch_per_wg, 0, 256, stream));
         ka.pool_cap = pl.pool_cap;
         aim::dp_strip_launch(p, pl.strip_k, pl.grid, pl.block, pl.lds, ka, stream);
         break;

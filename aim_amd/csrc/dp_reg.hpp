@@ -51,6 +51,10 @@ __device__ __forceinline__ uint32_t band_pick(uint32_t w0, uint32_t w1, uint32_t
     return (hi & m2) | (lo & ~m2);
 }
 
+// The walk's ops are staged in LDS one contiguous row per lane: stride 2 * READ_SIZE rounded to an ODD multiple of 16 bytes (lanes spread over the banks, 16-byte pieces
+// stay aligned), 16 bytes of headroom in front (the cursor may come to rest at index -1).
+__host__ __device__ inline int reg_ops_stride(int read_size) { const int s = 2 * read_size; return ((s >> 4) & 1) ? s : s + 16; }
+
 constexpr int kRegWin = 16;        // registers (32 indices) in which a row may start
 constexpr int kNwTail = 8;         // tail cells of the LAST row a pair may have beyond (tlen, W): plen <= tlen + 1 + kNwTail (round 5)
 constexpr int kRegInf = 16000;     // the value left of a row's start
@@ -80,7 +84,7 @@ __host__ __device__ inline size_t nw_reg_lds_bytes(const aim_params_t &p)   // t
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
     const int npk = nw_reg_npk(p.read_size, bt);
-    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 62 ? 2 : 1), o = (size_t)2 * p.read_size * kWave;   // (npk > 62: text image + pattern image)
+    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 62 ? 2 : 1), o = (size_t)reg_ops_stride(p.read_size) * kWave + 32;   // (npk > 62: text image + pattern image)
     return ((bt && o > t) ? o : t) + 512;
 }
 
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int NWD = (RSK + 3) / 4;    // dwords of a sequence row that cover them
     constexpr bool PL = NPK > 62;             // the (shifted) pattern row lives in LDS as bytes, not in NPK more registers (READ_SIZE 144 .. 176)
     constexpr int NDQ = (NPK + 7) / 8;        // dwords of direction bits a row has per lane (8 registers per dword); four of them are kept (the band, below)
+    constexpr bool kBandBits = false;         // direction bits made for the band's dwords only (see do_row)
     constexpr bool TAILS = true;              // last-row tail cells in this kernel (with CIGAR too: their direction bits stay in a register, see the walk)
     const int lane = threadIdx.x;
     const int rs = a.p.read_size, rsw = rs >> 2;
@@ -311,7 +316,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             };
 #pragma unroll
             for (int k = J0 >> 3; k < NDQ; ++k) {             // dword k: registers 8k .. 8k + 7
-                const bool inw = BT && ((k >= q0 && k < q0 + 4) || (k < 3 && wtail));   // kept by the row (the band), or one of the first three and a pair of the wavefront has tail cells: wave-uniform
+                // (Bits are made for EVERY dword and only the kept ones leave: making them for the kept dwords alone -- one wave-uniform branch per dword, as swg_reg_kernel
+                //  does for its four bits per cell -- measured SLOWER here (2.50 against 2.38 ms per 1 Mi pairs without stores and walk): the two bits are 6 of a register's
+                //  17 instructions, and 14 taken branches per row cost two wavefronts per SIMD more than 22 x 6 instructions. kBandBits = true builds that variant.)
+                const bool inw = BT && (!kBandBits || (k >= q0 && k < q0 + 4) || (k < 3 && wtail));
                 if (inw) {
 #pragma unroll
                     for (int j = (8 * k > J0 ? 8 * k : J0); j < 8 * k + 8 && j < NPK; ++j) reg(j, std::true_type{});
@@ -414,17 +422,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int end_offset = plen + tlen;
             char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
             const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
-            unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem);
-#define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
+            unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem) + lane * reg_ops_stride(rs) + 16;   // this lane's row (reg_ops_stride)
+#define OPS(i) ops_l[(i)]
             int sentinel = end_offset - 1;
             int h = tlen, v = plen;
-            // one step of the walk on a cell's code (bit 0 "not D", bit 1 "not I"; a macro: as a lambda capturing h, v and the cursor by reference the closure was kept in scratch)
-#define NW_STEP(code_, pch_, tch_) do { const uint32_t cd_ = (code_);                                                                       \
-                if (!(cd_ & 1u)) { OPS(sentinel) = 'D'; --sentinel; --v; }                                                                    \
-                else if (!(cd_ & 2u)) { OPS(sentinel) = 'I'; --sentinel; --h; }                                                               \
-                else { OPS(sentinel) = ((pch_) != (tch_)) ? 'X' : 'M'; --sentinel; --h; --v; } } while (0)
+            // One step of the walk on a cell's code (bit 0 "not D", bit 1 "not I"), WITHOUT branches: the walk is a chain of ~130 dependent steps per pair on all 64
+            // lanes, and as three divergent branches per step it cost as many instructions as a seventh of the fill.
+#define NW_STEP(code_, pch_, tch_) do { const uint32_t cd_ = (code_); const bool nd_ = (cd_ & 1u) != 0u, ni_ = (cd_ & 2u) != 0u;                  \
+                OPS(sentinel) = !nd_ ? 'D' : (!ni_ ? 'I' : (((pch_) != (tch_)) ? 'X' : 'M'));                                                     \
+                --sentinel; h -= nd_ ? 1 : 0; v -= (nd_ && !ni_) ? 0 : 1; } while (0)
             // The walk's characters without a dependent global load per step (two per 'M' / 'X' step until round 6: what was left of the walk's time once the
-            // direction bits came eight rows at a time): the PATTERN row is staged in LDS, in the ops area's own layout (row byte i at OPS(i)) -- the cursor
+            // direction bits came eight rows at a time): the PATTERN row is staged in LDS, in the ops row itself (row byte i at OPS(i)) -- the cursor
             // never reaches a pattern byte that is still to be read (cursor - (v - 1) = h >= 1 at every step) --, the TEXT characters of a batch's eight rows
             // come with the batch (row h needs t[h - 1] only).
             for (int b = 0; 16 * b < rs; ++b) {
@@ -432,8 +440,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
             }
             // A pair with tail cells starts in the last row's tail: the cell the reference reads at flat index W h + v with v > W is the tail cell v - W (h == tlen:
-            // its bits are in `tailbits`, its characters its own). Above the last row such an index is cell (h + 1, v - W) of the table -- the row's first columns,
-            // far outside the band: to-do list.
+            // its bits are in `tailbits`, its characters its own). Above the last row such an index is cell (h + 1, v - W) of the table: one of the next row's first
+            // eight columns (TBU2).
             constexpr int NB = 8;                             // rows per batch
             aim_u32x4 u[NB];                                  // the units of rows h0 .. h0 - NB + 1 ...
             uint32_t tc[NB];                                  // ... and those rows' text characters
@@ -460,10 +468,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {
+                    const int qw = band_q0(h0 - r);           // the row's window (per lane: the lanes' rows differ)
                     while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= W from here on)
                         const int i = v + s0, q = i >> 4;
-                        const int qw = band_q0(h);
-                        if (q < qw || q >= qw + 4) { lost = true; break; }
+                        if ((uint32_t)(q - qw) >= 4u) { lost = true; break; }
                         const uint32_t word = band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 7));
                         NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(v - 1), tc[r]);
                     }
@@ -477,9 +485,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
                 begin_offset = sentinel + 1;
                 {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(ops_l);
                     uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
-                    for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q * kWave + lane];
+                    for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q];
                 }
                 aim_result_t res;
                 res.max_operations = plen + tlen;
@@ -568,7 +576,7 @@ __host__ __device__ inline int swg_reg_units(int npk) { return ((npk + 3) / 4 + 
 __host__ __device__ inline size_t swg_reg_lds_bytes(const aim_params_t &p, int npk)   // text image / ops staging + the two pair queues (1 KB)
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 61 ? 2 : 1), o = (size_t)2 * p.read_size * kWave;   // (npk > 61: text image + pattern image)
+    const size_t t = (size_t)((2 * npk + 3) / 4) * kWave * 4 * (npk > 61 ? 2 : 1), o = (size_t)reg_ops_stride(p.read_size) * kWave + 32;   // (npk > 61: text image + pattern image)
     return ((bt && o > t) ? o : t) + 1024;
 }
 inline size_t swg_reg_slab_bytes(int npk, int read_size) { (void)npk; return (size_t)(read_size + 2) * (16 + 4) * kWave; }   // per row and lane one 16-byte unit of direction bits (the band) + dword 0 (pairs with tail cells)
@@ -869,19 +877,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (mine && !bad && !(a.dbg_flags & 5u)) {
                 char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
                 const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
-                unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem);
-#define OPS(i) ops_l[((((i) >> 4) * kWave + lane) << 4) + ((i) & 15)]
+                unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem) + lane * reg_ops_stride(rs) + 16;   // this lane's row (reg_ops_stride)
+#define OPS(i) ops_l[(i)]
                 int sentinel = end_offset - 1;
                 int h = tlen, v = plen;
                 int layer = 0;                                // 0: M, 1: I, 2: D
                 const int Wc = tlen + 1;
-                // one step of the walk on a cell's bits (bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended; a macro, see nw_reg_kernel)
+                // One step of swg_traceback on a cell's bits (bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended), without branches (see nw_reg_kernel):
+                // in layer D / I the step emits the gap and stays or returns to M; in layer M it changes layer (nothing emitted: the byte written at the cursor is
+                // overwritten by the next step) or emits 'M' / 'X'.
 #define SWG_STEP(bits_, pch_, tch_) do { const uint32_t bq_ = (bits_);                                                                      \
-                    if (layer == 2) { OPS(sentinel) = 'D'; --sentinel; if (!(bq_ & 0x10u)) layer = 0; --v; }                                  \
-                    else if (layer == 1) { OPS(sentinel) = 'I'; --sentinel; if (!(bq_ & 0x100000u)) layer = 0; --h; }                         \
-                    else if (!(bq_ & 1u)) layer = 2;                                                                                          \
-                    else if (!(bq_ & 0x10000u)) layer = 1;                                                                                    \
-                    else { OPS(sentinel) = ((pch_) != (tch_)) ? 'X' : 'M'; --sentinel; --h; --v; } } while (0)
+                    const bool inD_ = layer == 2, inI_ = layer == 1, inM_ = layer == 0;                                                       \
+                    const bool toD_ = inM_ && !(bq_ & 1u), toI_ = inM_ && (bq_ & 1u) && !(bq_ & 0x10000u), dg_ = inM_ && (bq_ & 1u) && (bq_ & 0x10000u); \
+                    OPS(sentinel) = inD_ ? 'D' : (inI_ ? 'I' : (((pch_) != (tch_)) ? 'X' : 'M'));                                             \
+                    sentinel -= (inD_ || inI_ || dg_) ? 1 : 0; v -= (inD_ || dg_) ? 1 : 0; h -= (inI_ || dg_) ? 1 : 0;                        \
+                    layer = inD_ ? ((bq_ & 0x10u) ? 2 : 0) : inI_ ? ((bq_ & 0x100000u) ? 1 : 0) : toD_ ? 2 : toI_ ? 1 : 0; } while (0)
                 // the pattern row staged in LDS in the ops area's own layout, the text characters of a batch's rows with the batch (see nw_reg_kernel)
                 for (int b = 0; 16 * b < rs; ++b) {
                     const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
@@ -915,10 +925,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
 #pragma unroll
                     for (int r = 0; r < NB; ++r) {
+                        const int qw = band_q0(h0 - r);       // the row's window (per lane: the lanes' rows differ)
                         while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= Wc from here on)
                             const int i = v - 1, q = i >> 3;
-                            const int qw = band_q0(h);
-                            if (q < qw || q >= qw + 4) { lost = true; break; }
+                            if ((uint32_t)(q - qw) >= 4u) { lost = true; break; }
                             SWG_STEP(band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(v - 1), tc[r]);
                         }
                     }
@@ -930,9 +940,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
                     while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
                     begin_offset = sentinel + 1;
-                    const uint4 *src = reinterpret_cast<const uint4 *>(smem);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(ops_l);
                     uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
-                    for (int qq = begin_offset >> 4; qq <= (end_offset - 1) >> 4; ++qq) dst[qq] = src[qq * kWave + lane];
+                    for (int qq = begin_offset >> 4; qq <= (end_offset - 1) >> 4; ++qq) dst[qq] = src[qq];
                 }
 #undef SWG_STEP
 #undef OPS

@@ -189,8 +189,9 @@ __device__ __forceinline__ bool dp_traceback_swg_bits(const aim_params_t &p, int
         else if (!nI) layer = 1;
         else {   // diagonal move: the cell equals its diagonal + MATCH or + MISMATCH according to the characters IT was computed with -- canonical cell (R, C) was
                  // last written as cell (R, C) of the table (C >= 1, R <= tlen) or as the tail cell (R - 1, W + C) (column 0; row tlen + 1)
-            const bool as_tail = C == 0 || R > tlen;
-            put(ldsP[as_tail ? W + C - 1 : C - 1] != ldsT[as_tail ? R - 2 : R - 1] ? 'X' : 'M');
+            //   ... or, beyond row tlen + 1 (plen > 2 tlen), as the last row's tail cell (R - tlen) W + C
+            const int pi = R > tlen ? (R - tlen) * W + C - 1 : (C == 0 ? W - 1 : C - 1), ti = R > tlen ? tlen - 1 : (C == 0 ? R - 2 : R - 1);
+            put(ldsP[pi] != ldsT[ti] ? 'X' : 'M');
             --h; --v; --R; if (C > 0) --C; else { --R; C = W - 1; }
         }
     }
@@ -230,25 +231,17 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
     const lds_int_p Bl = cons + kStripMaxWaves;                                                        // [kStripDepth] boundary cells {M, I, D, seq} by row (a ring: a strip
                                                                                                        // may still be waiting for B(h) when the owner posts B(h+1))
     const lds_int_p tl = Bl + 4 * kStripDepth;                                                                       // last row's tail inputs {M, D of cell W-1, diag} + score
-    // table slab: canonical rows of stride S, layers as planes (dp_wave.hpp); S leaves room for a whole K-cell group that starts
-    // inside the row, so that every lane stores 16-byte vectors (cells beyond the row are written and never read)
-    const int S = dp_strip_stride(rs, K);
-    const size_t plane = (size_t)S * (size_t)(rs + 3);
-    // NW: one int16 plane per workgroup (TM). SWG (round 5): the workgroup's slab holds FOUR DIRECTION BITS per cell -- FLW [row][FS lanes][NQS dwords] + the
-    // boundary cells' bytes BF [row] -- and no value plane; the three int16 planes the literal path needs (a pair with plen > 2 tlen: an outlier) come from a
-    // small POOL of tables behind the slabs, taken under a lock (strip_pool_acquire): 61 MB instead of 613 MB per resident pair at READ_SIZE 10 112.
+    // The workgroup's slab holds FOUR DIRECTION BITS per cell (NW: two of them) -- FLW [row][FS lanes][NQS dwords] + the boundary cells' bytes BF [row] -- and no
+    // value plane. (Round 5 kept a POOL of int16 tables behind the slabs, taken under a lock, for pairs with plen > 2 tlen, which ONE lane filled literally; round 6
+    // computes those pairs' tail cells like everybody else's -- the last row's tail loop below -- and the pool, its lock and the cross-XCD release / acquire it needed are gone.)
     constexpr int NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;       // dwords of direction bits per lane and row (a 12-byte word is stored as 16)
     int16_t *tb = reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
-    int16_t *TM = tb, *TI = tb + plane, *TD = tb + 2 * plane;      // (the literal path: re-pointed at a pool table; NW: one plane of it)
     const int FS = rs / K + 2;                    // lanes per row that can hold a column
     uint32_t *FLW = reinterpret_cast<uint32_t *>(tb);             // SWG strip path: direction bits
     unsigned char *BF = reinterpret_cast<unsigned char *>(FLW + (size_t)(rs + 3) * FS * NQS);   // ... and the boundary cells' bytes, [row]
-    uint32_t *pool_locks = reinterpret_cast<uint32_t *>(a.scratch + (uint64_t)gridDim.x * a.scratch_per_wave);   // SWG: [64] lock words, then pool_cap tables of 3 planes
-    int16_t *pool_tables = reinterpret_cast<int16_t *>(reinterpret_cast<char *>(pool_locks) + 256);
     const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
     const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
     const int GE = SWG ? E : GD;                 // step of the in-row chain
-    const bool exact_ok = dp_strip_exact_ok(a.p, false);
     const int v0 = 1 + (wv * kWave + lane) * K;  // first column of this lane
 
     // to-do mode (a.todo set: the pairs dp_group_kernel left, dp_group.hpp): the units are the listed pairs
@@ -274,35 +267,11 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             uint32_t *o4 = reinterpret_cast<uint32_t *>(ops);
             for (int w = tid; w < (rs >> 1); w += NT) o4[w] = 0x4D4D4D4Du;
         }
-        const bool literal = !exact_ok || plen > 2 * tlen || (min(plen, W - 1) > nw * kWave * K);
-
-        int pool_slot = -1;
-        if (literal) {   // the int16 planes of the literal path (SWG three, NW one): a table of the pool (workgroups wait for a free one; holders always finish)
-            if (tid == 0) {
-                int got = -1;
-                while (got < 0) {
-                    for (uint32_t i = 0; i < a.pool_cap && got < 0; ++i)
-                        if (atomicCAS(&pool_locks[i], 0u, 1u) == 0u) got = (int)i;
-                    if (got < 0) __builtin_amdgcn_s_sleep(32);
-                }
-                __threadfence();   // acquire, device scope: this XCD's L2 / this CU's L1 drop whatever they still hold of the table (the previous holder may have run on another XCD)
-                tl[4] = got;
-            }
-            __syncthreads();
-            pool_slot = tl[4];
-            TM = pool_tables + (size_t)pool_slot * (SWG ? 3 : 1) * plane; TI = TM + plane; TD = TM + 2 * plane;
-        }
-        if (literal) {
-            if (tid == 0) { score = dp_literal_fill<SWG, false>(a.p, plen, tlen, gP, gT, TM, TI, TD); tl[3] = score; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SWG's ops prefill by all threads completes before the traceback patches it
-            __syncthreads();
-            score = tl[3];
-        }
         // ---------------------------------------------------------------------------------------- strip pipeline
         // With CIGAR the direction bits are made only by the strips AROUND THE DIAGONAL (a band of +- 32 K columns about the two diagonals through the table's
         // corners: two or three of config 4's eight strips per row) -- the four tests cost ~25 % of a row and sit on the pipeline's critical path, and the walk
         // of related reads never leaves the band. When it does (the walk checks C - R at every step), the pair is filled again with every strip's bits.
-        for (int attempt = 0; !literal && attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 2; ++attempt) {
             constexpr bool BAND = BT && K == 20;      // (the shapes with registers to spare for a second copy of the row: K = 24 / 32 and 16 x 12 spill with it)
             const bool full_bits = !BAND || attempt == 1 || nw == 1;
             const int band_m = 32 * K, band_d0 = min(0, plen - tlen), band_d1 = max(0, plen - tlen);
@@ -573,12 +542,18 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     const int bM = BM, bI = BI;   // every wavefront read B(tlen) at the start of the last row
                     int upM = tl[0], upD = tl[1];
                     int lastM = 0;
-                    int tw_g = -1;                    // lane word (direction bits) being assembled for the tail cells
+                    int tw_g = -1, tw_R = -1;         // lane word (direction bits) being assembled for the tail cells, and its canonical row
                     uint32_t tw[4] = {0u, 0u, 0u, 0u};
                     auto tw_flush = [&]() {
-                        if (tw_g >= 0 && lane == 0) for (int d = 0; d < NQS; ++d) FLW[((size_t)(h + 1) * FS + tw_g) * NQS + d] = tw[d];
+                        if (tw_g >= 0 && lane == 0) for (int d = 0; d < NQS; ++d) FLW[((size_t)tw_R * FS + tw_g) * NQS + d] = tw[d];
                     };
-                    for (int v = W; v <= plen; ++v) {
+                    // (Round 6: ANY plen. The cell "above" tail cell v is flat index W tlen + v - W: a regular cell of the last row while v - W < W, one of the tail cells
+                    //  themselves beyond that -- plen > 2 tlen, the pairs that until now were filled by ONE lane out of a table of their own (dp_literal_fill) -- so the
+                    //  tail cells join the row's LDS image as they are made, and their direction bits sit at the canonical position of their flat index, row
+                    //  tlen + v / W, column v mod W, where the walk looks for them.)
+                    int Rt = tlen + 1, C = 0;         // canonical position of flat index W tlen + v
+                    for (int v = W; v <= plen; ++v, ++C) {
+                        if (C == W) { C = 0; ++Rt; }
                         int leftM, leftI, diagM;
                         if (v == W) { leftM = bM; leftI = bI; diagM = tl[2]; }
                         else {
@@ -598,21 +573,21 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                         }
                         if (BT) {   // the direction bits of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array); NW: "not D", "not I" only
                             const uint32_t nD = cM != cDd ? 1u : 0u, nI = cM != cI ? 1u : 0u, xD = (SWG && upD + E < upM + OE) ? 1u : 0u, xI = (SWG && leftI + E < leftM + OE) ? 1u : 0u;
-                            const int C = v - W;
-                            if (C == 0) { if (lane == 0) BF[h + 1] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | ((!SWG || cM + O <= cDd) ? 0u : 16u)); }
+                            if (C == 0) { if (lane == 0) BF[Rt] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | ((!SWG || cM + O <= cDd) ? 0u : 16u)); }
                             else {
                                 if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left (column 1's: BF bit 4, set with column 0)
                                     const int t = (C - 2) - tw_g * K, j = t >> 1;
                                     tw[j >> 2] |= xD << (8 * (t & 1) + 4 + (j & 3));
                                 }
                                 const int g = (C - 1) / K, t = (C - 1) - g * K, j = t >> 1;
-                                if (g != tw_g) {
+                                if (g != tw_g || Rt != tw_R) {
                                     tw_flush();
-                                    tw_g = g; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
+                                    tw_g = g; tw_R = Rt; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
                                 }
                                 tw[j >> 2] |= (nD << (8 * (t & 1) + (j & 3))) | (nI << (8 * (2 + (t & 1)) + (j & 3))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & 3)));
                             }
                         }
+                        if (v < plen && lane == 0) { rowM[v] = (int16_t)cM; if (SWG) rowI[v] = (int16_t)cI; }   // (read back W cells on; same-wave LDS traffic is ordered)
                         upM = cM; upD = cDd;
                         lastM = cM;
                     }
@@ -640,19 +615,6 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
             begin_offset = plen + tlen - 1;
         }
 
-        if (BT && literal && wv == 0 && !(a.dbg_flags & 1u)) dp_traceback<SWG>(a.p, literal, plen, tlen, S, TM, TI, TD, rowM, false, ops, lane, begin_offset, status);
-        if (pool_slot >= 0) {   // the literal path's table goes back to the pool (after the walk's last read)
-            // A pool table is shared by workgroups on DIFFERENT XCDs, whose L2s are not coherent with each other inside a kernel: without a write-back of this XCD's
-            // dirty lines BEFORE the lock opens, they can reach HBM after the next holder's own (evicted) lines and be read back by its walk -- seen once in ~400
-            // batches of 445 pairs (READ_SIZE 1032, a dozen literal pairs each) as a spurious AIM_PAIR_SWG_NO_OP. __threadfence() = release at device scope
-            // (buffer_wbl2 sc1 + wait); literal pairs are outliers and cost milliseconds each, the fence microseconds.
-            __syncthreads();
-            if (tid == 0) {
-                __threadfence();
-                atomicExch(&pool_locks[pool_slot], 0u);
-            }
-            TM = tb; TI = tb + plane; TD = tb + 2 * plane;
-        }
 #ifdef AIM_STRIP_STAMPS
         __syncthreads();         // the traceback is done with the ops row: the stamps go there (the CIGAR of a diagnostic build is void)
         if (BT && lane == 0) {
@@ -715,16 +677,12 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     StripShape sh;
     if (!dp_strip_shape(p, kn, &sh, n_pairs)) return false;
     *k_out = sh.k;
-    const uint64_t S = (uint64_t)dp_strip_stride((int)rs, sh.k);
-    // Round 5: four direction bits per cell (NW uses two; NQS dwords per lane and row) + one byte per row, and a POOL of int16 tables (SWG three planes,
-    // NW one) for the literal path behind the slabs; score-only launches touch the pool on the literal path only.
+    // Round 5: four direction bits per cell (NW uses two; NQS dwords per lane and row) + one byte per row.
     const uint64_t nq = (uint64_t)((sh.k / 2 + 3) / 4), nqs = nq == 3 ? 4 : nq, fs = rs / (uint64_t)sh.k + 2;
     uint64_t per = (rs + 3) * fs * nqs * 4 + (rs + 3) + 64;
     if (!(p.flags & AIM_FLAG_BACKTRACE)) per = 256;
     per = (per + 255) & ~255ull;
-    const uint64_t table = (swg ? 3 : 1) * S * (rs + 3) * 2;       // one pool table (the literal path's int16 planes)
-    if (budget < 256 + table + per) return false;
-    budget -= 256 + table;                                         // (at least one table; more as the budget allows)
+    if (budget < per) return false;
     const int nw = sh.nw;
     *block = (uint32_t)(kWave * nw);
     const uint64_t seqcap = (rs + 79) & ~15ull, rowcap = (rs + 47) & ~7ull;
@@ -744,12 +702,7 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     *grid = g;
     *scratch_per_wg = per;
     *scratch_total = (size_t)(per * g);
-    {   // [slabs | 256 B of lock words | pool tables]: up to 8 tables where the budget admits them
-        uint64_t tables = 1;
-        while (tables < 8 && tables < g && per * g + 256 + (tables + 1) * table <= budget + table) ++tables;
-        *pool_tables = (uint32_t)tables;
-        *scratch_total += (size_t)(256 + tables * table);
-    }
+    *pool_tables = 0;   // (round 5's pool of literal-path tables: gone, see the kernel)
     return true;
 }
 

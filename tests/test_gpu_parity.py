@@ -1568,11 +1568,33 @@ def test_nw_row_in_registers_kernel(gpu, monkeypatch, l, err, bt):
     assert np.array_equal(res1, res2) and (not bt or engine.format_output(res1, ops1, True) == engine.format_output(res2, ops2, True))
 
 
-def test_dp_strip_pool_tables_are_shared_safely_across_xcds(gpu):
-    """The literal path of dp_strip_kernel (plen > 2 tlen) takes its int16 planes from a small POOL of tables shared by all workgroups (round 5). Workgroups on
-    different XCDs have L2s that are not coherent with each other inside a kernel: without a device-scope release (write-back) before the lock opens, a previous
-    holder's dirty lines could land in HBM over the next holder's and come back into its walk -- a spurious AIM_PAIR_SWG_NO_OP / wrong CIGAR in ~7 % of such
-    batches (found by fuzz_parity --focus dpgroup, NOTES R5.5). Every ninth pair literal, the rest streaming direction bits around them; 25 launches."""
+@pytest.mark.parametrize("algo", ["nw", "swg"])
+@pytest.mark.parametrize("l,n", [(1000, 96), (400, 300), (2500, 24)])
+def test_long_pattern_tails_wrap_the_flat_table_more_than_once(gpu, algo, l, n):
+    """Round 6: plen > 2 tlen -- the last row's tail cells v = W .. plen reach back W cells into the tail itself (flat index W tlen + v - W), and
+    the walk passes canonical rows beyond tlen + 1. dp_strip_kernel computes them in its tail loop (they join the row's LDS image; their direction bits sit at row
+    tlen + v / W, column v mod W) instead of handing the pair to one lane and a pooled table. Texts cut to a third, a fifth, a fiftieth of the pattern and to one
+    character, next to ordinary pairs; READ_SIZE 1064 / 2576 reach dp_strip directly, READ_SIZE 424 through dp_group's to-do list. Scores and CIGARs against the oracle."""
+    from aim_amd import engine
+    ms, rs = engine.launcher_sizes(algo, l, 0.03)
+    req, pat, txt = engine.gen_pairs(6600 + l, 0, n, l, 0.03, rs)
+    for i in range(n):
+        pl = int(req["pattern_len"][i])
+        if i % 4 == 1: req["text_len"][i] = max(1, pl // 3)
+        elif i % 4 == 2: req["text_len"][i] = max(1, pl // (5 if i % 8 == 2 else 50))
+        elif i % 16 == 3: req["text_len"][i] = 1 + (i // 16) % 3
+    for bt in (True, False):
+        params = engine.make_params(algo, ms, rs, backtrace=bt, swg_w16=(algo == "swg"))
+        _compare(algo, params, req, pat, txt)
+    params = engine.make_params(algo, ms, rs, backtrace=True, mismatch=2, **(dict(gap_i=5, gap_d=1) if algo == "nw" else dict(gap_o=1, gap_e=2, swg_w16=True)))
+    _compare(algo, params, req, pat, txt)
+
+
+def test_dp_strip_batches_with_long_pattern_tails_are_stable_launch_to_launch(gpu):
+    """Round 5 filled pairs with plen > 2 tlen on ONE lane out of a small POOL of int16 tables shared by all workgroups under a lock, and 7 % of such batches came back
+    wrong until the lock got a device-scope release / acquire (XCD L2s are not coherent inside a kernel; NOTES R5.5 -- this was the regression test). Round 6 computes
+    those pairs' tail cells in the strip kernel itself: no pool, no lock, nothing shared between workgroups. The batch that showed the race (READ_SIZE 1032 through
+    dp_group's to-do list into dp_strip: every ninth pair's text cut below half its pattern) must give the oracle's output on every one of 10 launches."""
     import random
     from aim_amd import engine
     from oracle import oracle
@@ -1585,7 +1607,7 @@ def test_dp_strip_pool_tables_are_shared_safely_across_xcds(gpu):
             req["text_len"][i] = rng.randint(200, int(req["pattern_len"][i]) // 2 - 1)
         ores, oops, _ = oracle.align_batch(_oracle_params(oracle, params, algo), req["pattern_len"], req["text_len"], pat, txt, nthreads=16)
         want = engine.format_output(ores, oops, True)
-        for rep in range(25):
+        for rep in range(10):
             res, ops = engine.align(params, req, pat, txt, check=False)
             assert np.array_equal(res["status"], ores["status"]) and np.array_equal(res["score"], ores["score"]), (algo, rep)
             assert engine.format_output(res, ops, True) == want, (algo, rep)
@@ -1797,12 +1819,14 @@ def test_register_kernels_walk_that_leaves_the_band_goes_to_the_todo_list(gpu, a
     ms, rs = engine.launcher_sizes(algo, l, 0.02)
     n = 4000
     req, pat, txt = engine.gen_pairs(6100 + l, 0, n, l, 0.02, rs)
-    rng = np.random.default_rng(l)
     shift = max(l * 45 // 100, 21)                                            # the window reaches at most 40 (NW) / 20 (SWG) columns to one side of the centre line
     shifted = np.zeros(n, dtype=bool)
     for i in range(0, n, 3):
+        # pattern = A^shift + B, text = B + C^shift (B random): the only long common subsequence is B, `shift` diagonals off the corner-to-corner line -- random flanks
+        # would let a gap-cheap alignment wander along the main diagonal instead (the LCS of two random reads is ~0.65 l)
         pl = int(req["pattern_len"][i])
-        t = np.concatenate([pat[i, shift:pl], rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=shift).astype(np.uint8)])
+        pat[i, :shift] = ord("A")
+        t = np.concatenate([pat[i, shift:pl], np.full(shift, ord("C"), dtype=np.uint8)])
         txt[i, :] = 0
         txt[i, :pl] = t
         req["text_len"][i] = pl
@@ -1811,7 +1835,7 @@ def test_register_kernels_walk_that_leaves_the_band_goes_to_the_todo_list(gpu, a
     kw = dict(swg_w16=True) if algo == "swg" else {}
     params = engine.make_params(algo, 60 if algo == "swg" else ms, rs, backtrace=True, **cost, **kw)
     res, ops, ores = _compare(algo, params, req, pat, txt)
-    assert np.median(ores["score"][shifted]) <= 3 * shift                      # the shifted pairs ARE aligned through the gaps (2 * shift gap columns), not along the main diagonal
+    assert np.median(ores["score"][shifted]) <= 2 * shift + 2 + 2 * l // 20     # the shifted pairs ARE aligned through the gaps (2 * shift gap columns + their own few edits), not along the main diagonal
     with engine.DeviceSet(1) as s:
         s.configure(params, n)
         s.push(0, req, pat, txt); s.launch(); s.pull(0)
@@ -1819,7 +1843,7 @@ def test_register_kernels_walk_that_leaves_the_band_goes_to_the_todo_list(gpu, a
         fb = s.fallback_pairs(0)
     assert fb <= shifted.sum() + n // 50, (fb, int(shifted.sum()))
     if shift > (40 if algo == "nw" else 20):
-        assert fb >= 0.9 * shifted.sum(), (fb, int(shifted.sum()))
+        assert fb >= 0.8 * shifted.sum(), (fb, int(shifted.sum()))
     # the same batch score-only never needs the band
     params = engine.make_params(algo, 60 if algo == "swg" else ms, rs, backtrace=False, **cost, **kw)
     _compare(algo, params, req, pat, txt)

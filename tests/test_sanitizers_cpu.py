@@ -10,7 +10,9 @@ import pytest
 from conftest import ROOT, judge_case_input, judge_cases, md5
 
 SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
-ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98")
+# (use_sigaltstack=0: with the HIP runtime in the process ASan cannot unmap its per-thread alternate signal stacks at thread exit and aborts in AsanThread::Destroy --
+#  its own bookkeeping, not a finding; leaks are not checked: the HIP runtime keeps its allocations until exit)
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97:use_sigaltstack=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98")
 
 
 @pytest.fixture(scope="session")

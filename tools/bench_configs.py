@@ -65,6 +65,9 @@ CONFIGS = {
     "swg_l10000_e1_cigar_n2048": dict(algo="swg", l=10000, e=0.01, n=2048, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict(backtrace=True)),
     "nw_l1000_e5_cigar": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
+    # every text truncated to a third of its pattern (plen > 2 tlen: the last row's tail wraps around the flat table more than once; until round 6 ONE lane filled such a pair)
+    "nw_l1000_literal": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True), text_div=3),
+    "swg_l1000_literal": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True), text_div=3),
     "swg_l1000_e5_score": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict()),
     "nw_l1000_e5_score": dict(algo="nw", l=1000, e=0.05, n=1 << 12, kw=dict()),
     "swg_l10000_e1_score_n256": dict(algo="swg", l=10000, e=0.01, n=256, kw=dict()),
@@ -89,6 +92,8 @@ def run(name, cfg, reps=3):
     ms, rs = engine.launcher_sizes(cfg["algo"], cfg["l"], cfg["e"], **cost)
     params = engine.make_params(cfg["algo"], ms, rs, **cfg["kw"], **cost)
     req, pat, txt = engine.gen_pairs(42, 0, cfg["n"], cfg["l"], cfg["e"], rs)
+    if cfg.get("text_div"):
+        req["text_len"] = np.maximum(1, req["pattern_len"] // cfg["text_div"])
     with engine.DeviceSet(1) as s:
         s.configure(params, cfg["n"])
         best = None
