@@ -1,4 +1,4 @@
-// dp_group.hpp -- NW / SWG on MEDIUM reads (READ_SIZE 177 .. 1024: between the per-lane register kernels of dp_reg.hpp and the multi-wavefront strips
+// dp_group.hpp -- NW / SWG on MEDIUM reads (READ_SIZE 177 .. 1024, round 6: score-only to 1536, with CIGAR also 1440 .. 2048 -- dp_group_rs_ok: between the per-lane register kernels of dp_reg.hpp and the multi-wavefront strips
 // of dp_strip.hpp): G CONSECUTIVE LANES OWN A PAIR, 64 / G pairs per wavefront, every lane K = 32 consecutive cells of its pair's row in registers as
 // packed int16 pairs -- dp_strip.hpp's row body (previous row in registers, two cells per vector instruction, the in-row gap chain as a prefix minimum)
 // with the strip boundaries INSIDE the wavefront: what crosses a lane boundary travels by DPP, the prefix minimum over a pair's lanes is ONE wave scan on
@@ -9,7 +9,7 @@
 // Same results as nw_compute / swg_compute (NW/DPU-WRAM/dpu/nw.c:109-153, SWG/DPU-WRAM/dpu/swg.c:121-171) by dp_strip.hpp's argument (dp_strip_exact_ok:
 // no int16 store of the reference can wrap, so the prefix-minimum form equals its cell-by-cell arithmetic), including the flat table's aliasing for
 // plen > tlen: cell (h, W) is the boundary cell of row h + 1 (computed by the lane that owns column W - 1, handed to the pair's lanes by ds_bpermute),
-// and the last row's tail cells are walked by the pair's first lane over the row's LDS image. Pairs outside (a sequence empty, plen > 2 tlen) go to the
+// and the last row's tail cells are walked by the pair's first lane over the row's LDS image. Pairs outside (a sequence empty) go to the
 // to-do list: dp_lane.hpp's kernels (READ_SIZE <= 320) or dp_strip_kernel in to-do mode drain it behind this kernel.
 #pragma once
 
@@ -20,27 +20,37 @@
 
 namespace aim {
 
-constexpr int kDpgKP = 16;                    // packed registers per lane and row (32 columns)
-constexpr int kDpgMinRs = 177, kDpgMaxRs = 1024;
+constexpr int kDpgMinRs = 177;
+// Packed registers per lane and row (KP; 2 KP columns) and the READ_SIZE range: 16 everywhere up to READ_SIZE 1024, and with CIGAR (the direction bits' lane words are
+// dp_traceback_swg_bits' 16-byte layout for 32 columns); round 6: score-only READ_SIZE 1025 .. 1280 / .. 1536 with 20 / 24 registers -- two pairs of <= 32 lanes per
+// wavefront where dp_strip ran one wavefront per pair (NW l = 1000: 1 980 GCUPS) -- and with CIGAR READ_SIZE 1440 .. 2048 with ONE pair of 45 .. 64 lanes per wavefront
+// (dp_strip's two-wavefront strips with the walk on one of them: 900 / 730 GCUPS at l = 2000).
+__host__ __device__ inline int dp_group_kp(int read_size, bool bt) { return (bt || read_size <= 1024) ? 16 : (read_size <= 1280 ? 20 : 24); }
+__host__ __device__ inline bool dp_group_rs_ok(int read_size, bool bt)
+{
+    if (read_size < kDpgMinRs) return false;
+    return bt ? (read_size <= 1024 || (read_size >= 1440 && read_size <= 2048)) : read_size <= 1536;
+}
 
-__host__ __device__ inline int dp_group_lanes(int read_size) { return (read_size + 2 * kDpgKP - 1) / (2 * kDpgKP); }   // G: lanes per pair (6 .. 32)
+__host__ __device__ inline int dp_group_lanes(int read_size, bool bt) { const int k = 2 * dp_group_kp(read_size, bt); return (read_size + k - 1) / k; }   // G: lanes per pair (6 .. 64)
 
 // LDS of one pair slot: pattern | text | the last row's M, I (int16) | 16 B {M, D of cell W - 1, M of the cell above it}
 __host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
 constexpr int kDpgTileRows = 64;                 // the traceback's window (dp_traceback_swg_bits): 64 rows x 3 lane words x 16 B = 3 KB (128 rows measured slower: 3.53 -> 3.65 ms at NW l = 300, LDS residency at READ_SIZE 192)
 __host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt = false)
 {
-    return (((size_t)(kWave / dp_group_lanes(rs)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
+    return (((size_t)(kWave / dp_group_lanes(rs, bt)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
 }
 // BACKTRACE: a pair's slab of direction bits, dp_strip.hpp's layout with K = 32 -- FLW [READ_SIZE + 3 rows][FS lane words of 16 B], then the boundary cells' bytes [row]
-__host__ __device__ inline int dp_group_fs(int rs) { return dp_group_lanes(rs); }   // (exactly the pair's lanes: a row of the slab is one contiguous run of 16-byte words, rows follow each other without gaps)
+__host__ __device__ inline int dp_group_fs(int rs) { return dp_group_lanes(rs, true); }   // (exactly the pair's lanes: a row of the slab is one contiguous run of 16-byte words, rows follow each other without gaps)
 __host__ __device__ inline size_t dp_group_slab_bytes(int rs) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs) * 16 + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }
 
 inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
 {
     if (kn.no_dp_group || kn.force_dpwave || kn.dpw_legacy || kn.strip_k > 0 || kn.dpw_nw > 0) return false;   // (the long-read kernels' own knobs ask for those kernels)
     if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG) return false;
-    if (p.read_size < kDpgMinRs || p.read_size > kDpgMaxRs) return false;
+    if (!dp_group_rs_ok(p.read_size, (p.flags & AIM_FLAG_BACKTRACE) != 0)) return false;
+    if (p.algo == AIM_ALGO_SWG && !(p.flags & AIM_FLAG_BACKTRACE) && p.read_size > 1280) return false;   // (SWG with 24 registers per lane spills inside the row: dp_strip_kernel)
     if (p.algo == AIM_ALGO_SWG && swg_cell_bytes(p) == 1) return false;   // int8 cells wrap by design: the literal kernels
     return dp_strip_exact_ok(p, false);
 }
@@ -86,7 +96,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (valid) rq = load_request(a, pair);
         int plen = rq.pattern_len, tlen = rq.text_len;
         // not this kernel's: an empty sequence, aliasing beyond one row (plen > 2 tlen), lengths beyond the rows (the literal kernels report those)
-        const bool outl = valid && (plen < 1 || tlen < 1 || plen > 2 * tlen || plen > rs || tlen > rs);
+        const bool outl = valid && (plen < 1 || tlen < 1 || plen > rs || tlen > rs);   // (until round 6 also plen > 2 tlen: the last row's tail cells below take any plen now)
         {
             const unsigned long long m = __ballot(outl && g == 0), below = (1ull << lane) - 1ull;
             if (m) {
@@ -308,12 +318,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const int bM = rowM[0], bI = SWG ? (int)rowI[0] : 0;
                 int upM = tl[0], upD = tl[1];
                 int lastM = 0;
-                int tw_g = -1;                    // (BT) lane word being assembled for the tail cells: row tlen + 1
+                int tw_g = -1, tw_R = -1;         // (BT) lane word being assembled for the tail cells, and its canonical row (dp_strip.hpp: row tlen + v / W, column v mod W)
                 uint32_t tw[4] = {0u, 0u, 0u, 0u};
                 auto tw_flush = [&]() {
-                    if (tw_g >= 0) for (int d = 0; d < 4; ++d) FLW[((size_t)(h + 1) * FS + tw_g) * 4 + d] = tw[d];
+                    if (tw_g >= 0) for (int d = 0; d < 4; ++d) FLW[((size_t)tw_R * FS + tw_g) * 4 + d] = tw[d];
                 };
-                for (int v = W; v <= plen; ++v) {
+                int Rt = tlen + 1, C = 0;
+                for (int v = W; v <= plen; ++v, ++C) {
+                    if (C == W) { C = 0; ++Rt; }
                     int leftM, leftI, diagM;
                     if (v == W) { leftM = bM; leftI = bI; diagM = tl[2]; }
                     else {
@@ -333,21 +345,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                     if (BT) {   // the direction bits of this cell: column C = v - W of row tlen + 1 (C = 0: the boundary array), dp_strip.hpp
                         const uint32_t nD = cM != cDd ? 1u : 0u, nI = cM != cI ? 1u : 0u, xD = (SWG && upD + E < upM + OE) ? 1u : 0u, xI = (SWG && leftI + E < leftM + OE) ? 1u : 0u;
-                        const int C = v - W;
-                        if (C == 0) BF[h + 1] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | ((!SWG || cM + O <= cDd) ? 0u : 16u));
+                        if (C == 0) BF[Rt] = (unsigned char)(nD | (nI << 1) | (xD << 2) | (xI << 3) | ((!SWG || cM + O <= cDd) ? 0u : 16u));
                         else {
                             if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left
                                 const int t = (C - 2) - tw_g * K, j = t >> 1;
                                 tw[j >> 2] |= xD << (8 * (t & 1) + 4 + (j & 3));
                             }
                             const int gg = (C - 1) / K, t = (C - 1) - gg * K, j = t >> 1;
-                            if (gg != tw_g) {
+                            if (gg != tw_g || Rt != tw_R) {
                                 tw_flush();
-                                tw_g = gg; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
+                                tw_g = gg; tw_R = Rt; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
                             }
                             tw[j >> 2] |= (nD << (8 * (t & 1) + (j & 3))) | (nI << (8 * (2 + (t & 1)) + (j & 3))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & 3)));
                         }
                     }
+                    if (v < plen) { rowM[v] = (int16_t)cM; if (SWG) rowI[v] = (int16_t)cI; }   // (plen > 2 tlen: read back W cells on, as the cell "above")
                     upM = cM; upD = cDd;
                     lastM = cM;
                 }
@@ -400,8 +412,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // [to-do region only] one wavefront per workgroup, two per SIMD (the row body holds ~10 arrays of KP registers)
 inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, size_t *lds, uint64_t *scratch_per_wg)
 {
-    const int G = dp_group_lanes(p.read_size), P = kWave / G;
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    const int G = dp_group_lanes(p.read_size, bt), P = kWave / G;
     *lds = dp_group_lds_bytes(p.read_size, bt);
     *scratch_per_wg = bt ? (uint64_t)P * dp_group_slab_bytes(p.read_size) : 256;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(kn.dpg_per_cu > 0 ? (size_t)kn.dpg_per_cu : 8, lds_workgroups_per_cu(*lds));
@@ -416,15 +428,21 @@ inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &
 #ifdef AIM_TU_DP_GROUP
 void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
-    const int G = dp_group_lanes(p.read_size);
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
+    const int G = dp_group_lanes(p.read_size, bt), kp = dp_group_kp(p.read_size, bt);
+#define AIM_DPG(ALGO, BT_, KP_) hipLaunchKernelGGL((dp_group_kernel<ALGO, BT_, KP_>), dim3(grid), dim3(kWave), lds, s, ka, G)
     if (p.algo == AIM_ALGO_NW) {
-        if (bt) hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_NW, true, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
-        else hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_NW, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+        if (bt) AIM_DPG(AIM_ALGO_NW, true, 16);
+        else if (kp == 16) AIM_DPG(AIM_ALGO_NW, false, 16);
+        else if (kp == 20) AIM_DPG(AIM_ALGO_NW, false, 20);
+        else AIM_DPG(AIM_ALGO_NW, false, 24);
     } else {
-        if (bt) hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_SWG, true, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
-        else hipLaunchKernelGGL((dp_group_kernel<AIM_ALGO_SWG, false, kDpgKP>), dim3(grid), dim3(kWave), lds, s, ka, G);
+        if (bt) AIM_DPG(AIM_ALGO_SWG, true, 16);
+        else if (kp == 16) AIM_DPG(AIM_ALGO_SWG, false, 16);
+        else if (kp == 20) AIM_DPG(AIM_ALGO_SWG, false, 20);
+        else AIM_DPG(AIM_ALGO_SWG, false, 24);
     }
+#undef AIM_DPG
 }
 #else
 void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s);

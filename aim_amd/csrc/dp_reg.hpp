@@ -144,7 +144,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             aim_request_t rc;
             rc.pattern_len = rc.text_len = 0; rc.padding = 0; rc.idx = 0;
             if (act) rc = load_request(a, cand);
-            // this kernel's pairs: plen <= tlen + 1, or (score-only, round 5) at most kNwTail tail cells beyond (h, W) -- those of the rows before the last are
+            // this kernel's pairs: plen <= tlen + 1, or (round 5; with CIGAR too) at most kNwTail tail cells beyond (h, W) -- those of the rows before the last are
             // overwritten by the next row before anything else reads them, so the rows run over the columns 0 .. W like a plen == tlen + 1 pair's and the LAST
             // row's tail cells are computed once, when that row is done (tail_cells below) -- and a row start inside the window
             const int cpe = rc.pattern_len > rc.text_len ? rc.text_len + 1 : rc.pattern_len;   // columns the rows run over
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int W = tlen + 1;
         const bool isW = mine && plen >= W;                  // cell (h, W) is the next row's boundary cell
         const int pe = plen >= W ? W : plen;                 // the rows' last column
-        const int ntail = mine ? plen - pe : 0;              // tail cells of the last row (score-only)
+        const int ntail = mine ? plen - pe : 0;              // tail cells of the last row
         const int s0 = mine ? RSK - 1 - pe : 0;              // index of column 0 (0 .. 31)
         // BACKTRACE: the band's centre line (index at row 0, wave-uniform): midway between the lanes' extreme corner diagonals -- a pair's path runs between the
         // diagonal through (0, 0), index s0 + h, and the one through (tlen, pe), index RSK - 1 - tlen + h
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (ntail > 0) __builtin_nontemporal_store(unit2, TBU2(h));
             }
         };
-        // plen >= tlen + 2 (score-only): the last row's tail cells v = W + c, c = 1 .. ntail, right after that row (nw.c:137-145 with the flat indices resolved: the
+        // plen >= tlen + 2: the last row's tail cells v = W + c, c = 1 .. ntail, right after that row (nw.c:137-145 with the flat indices resolved: the
         // cell on the left is the previous tail cell, the cell "above" is cell (tlen, c) of this same row, the diagonal one cell (tlen, c - 1)); `row` is row tlen
         // of the lanes concerned. Fields of the row at per-lane indices: binary select trees over VALUES (a chain of `idx == j ?` selects would be taken for a
         // dynamic index and put the row into scratch).
@@ -538,8 +538,8 @@ inline size_t nw_reg_slab_bytes(int npk, int read_size) { (void)npk; return (siz
 //     (and reads, as its cell "above", its own previous value: the stored row), row 1's boundary is the row initialisation's (it is written after the
 //     column's). The cells right of it (plen >= tlen + 2) read the CURRENT row's first cells and are overwritten by the next row before anything
 //     else reads them: only the LAST row's matter (they hold the score), so the rows run over the columns 1 .. W like those of a plen == tlen + 1 pair and
-//     the last row's tail cells W + 1 .. plen are computed once, after the loop, from the final row (at most kSwgTail of them; score-only -- with CIGAR such
-//     pairs stay on the to-do list). Cell (h, W) sits at a per-lane index: pairs with plen > tlen are queued separately and only THEIR wavefronts pick
+//     the last row's tail cells W + 1 .. plen are computed once, after the loop, from the final row (at most kSwgTail of them; with CIGAR their four
+//     direction bits stay in a register, `tailbits`). Cell (h, W) sits at a per-lane index: pairs with plen > tlen are queued separately and only THEIR wavefronts pick
 //     {M, D} out of the last kSwgWin registers after every row (two v_cndmask per register); the queues' remainders share a last, mixed batch.
 //   * BACKTRACE: FOUR BITS per cell, decided at fill time (every cell the walk compares with still holds the value the fill read, as in nw_reg_kernel):
 //     "M != D" (A < D), "M != I" (M_diag + cost < I), "D != M_left + o + e" (D < A_left + o + e: the gap was extended; needs o > 0) and
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             aim_request_t rc;
             rc.pattern_len = rc.text_len = 0; rc.padding = 0; rc.idx = 0;
             if (act) rc = load_request(a, cand);
-            // this kernel's pairs: at most kSwgTail tail cells in the last row (with CIGAR: none), the rows' end inside the window, both sequences inside the
+            // this kernel's pairs: at most kSwgTail tail cells in the last row (score-only and with CIGAR), the rows' end inside the window, both sequences inside the
             // row / the staged text image
             const int cpe = rc.pattern_len > rc.text_len ? rc.text_len + 1 : rc.pattern_len;
             const bool take = act && rc.pattern_len >= 1 && rc.text_len >= 1 && rc.pattern_len <= rc.text_len + 1 + kSwgTail && cpe >= RSK - 2 * kSwgWin + 1 &&

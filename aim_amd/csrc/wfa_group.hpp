@@ -326,7 +326,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AIM_GROUP_MI
             uint4 *orow = reinterpret_cast<uint4 *>(a.ops + (uint64_t)pair * 2 * rs);
             const uint4 mm = make_uint4(0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du, 0x4D4D4D4Du);
             // (only the pieces that can hold a printed operation: begin_offset >= min(plen, tlen) - MAX_SCORE / e, wfa_lane.hpp)
-            const int p_lo = max(0, min(plen, tlen) - a.p.max_score / max(1, a.p.gap_e)) >> 4, p_hi = min((plen + tlen + 15) >> 4, (2 * rs) / 16);
+            // (gap_e == 0: gaps cost nothing to extend and MAX_SCORE bounds no length -- the whole row is written)
+            const int p_lo = a.p.gap_e > 0 ? max(0, min(plen, tlen) - a.p.max_score / a.p.gap_e) >> 4 : 0, p_hi = min((plen + tlen + 15) >> 4, (2 * rs) / 16);
             for (int j = p_lo + g; j < p_hi; j += G) orow[j] = mm;
         }
         fence();

@@ -33,9 +33,9 @@ ISSUE_PEAK_GINSTR = 1024 * 2.4e9 / 1e9          # 1 024 SIMDs x one wavefront in
 CONFIGS = {
     "cfg2": dict(algo="wfa", l=100, e=0.01, n=1 << 22, bt=False, reduce=True, bound="hbm", pmc="wfa_lane",
                  name="WFA-adaptive score-only l=100 e=1%"),
-    "cfg3": dict(algo="wfa", l=1000, e=0.05, n=1 << 16, bt=True, reduce=True, bound="issue", pmc="wfa_group",
+    "cfg3": dict(algo="wfa", l=1000, e=0.05, n=1 << 18, bt=True, reduce=True, bound="issue", pmc="wfa_group",
                  name="WFA-adaptive with CIGAR l=1000 e=5%"),
-    "cfg4": dict(algo="swg", l=10000, e=0.01, n=256, bt=True, reduce=False, bound="valu", pmc="dp_strip",
+    "cfg4": dict(algo="swg", l=10000, e=0.01, n=1024, bt=True, reduce=False, bound="valu", pmc="dp_strip",
                  name="SWG affine-gap with CIGAR l=10000 e=1%"),
     # cfg5 (round 5): 16 384 pairs per GPU as FOUR batches of 4 096 on four streams -- what the host CLI's --slots 4 does. One
     # synthetic pair in ~4 000 loses the diagonal and keeps one wavefront busy for ~27 ms next to a batch that takes ~8: a single straggler-free batch

@@ -147,7 +147,11 @@ int aim_set_push(aim_set_t *set, uint32_t device, uint32_t n_pairs, const void *
  * every device of the set and waits for all of them. */
 int aim_set_launch(aim_set_t *set);
 /* The device->host gathers of host.c:316-326: results[n_pairs] and, with
- * AIM_FLAG_BACKTRACE, ops[n_pairs][2*read_size] (may be NULL otherwise). */
+ * AIM_FLAG_BACKTRACE, ops[n_pairs][2*read_size] (may be NULL otherwise).
+ * CONTRACT OF AN OPS ROW: ops[i][begin_offset, end_offset) holds pair i's edit operations -- the bytes edit_cigar_print reads
+ * (host.c:347-349). The REST of the row is unspecified: the reference's memset(operations, 'M', 2*READ_SIZE) (wfa.c:465,
+ * swg.c:261) is only performed where an operation can be printed, so a caller that compares or copies whole rows sees
+ * whatever its buffer held before (tests run with AIM_DEBUG_POISON_OPS to keep every kernel honest about that). */
 int aim_set_pull(aim_set_t *set, uint32_t device, void *results /* aim_result_t[] or, with AIM_FLAG_RES8,
                  aim_result8_t[] */, char *ops);
 /* The three phase timers host.c prints ("CPU-DPU", "DPU Kernel", "DPU-CPU",

@@ -413,8 +413,10 @@ DP_KERNELS = [dict(), dict(AIM_DPW_LEGACY="1"), dict(AIM_STRIP_K="32"), dict(AIM
 def _dp_kernel_name(env, params):
     from aim_amd import capi
     int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
-    if not env and not int8 and 177 <= params.read_size <= 1024:
-        return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave)
+    bt = bool(params.flags & capi.FLAG_BACKTRACE)
+    rs_ok = 177 <= params.read_size <= 1024 or (1440 <= params.read_size <= 2048 if bt else params.read_size <= (1536 if params.algo == capi.ALGO_NW else 1280))
+    if not env and not int8 and rs_ok:
+        return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave); round 6: dp_group_rs_ok's ranges
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
 
 
@@ -1640,16 +1642,18 @@ def test_register_kernels_many_groups_per_wavefront(gpu, monkeypatch, algo, l, e
 # ------------------------------------------------------------------ medium reads: G lanes per pair (dp_group.hpp, round 5)
 @pytest.mark.parametrize("algo", ["nw", "swg"])
 @pytest.mark.parametrize("bt", [False, True])
-@pytest.mark.parametrize("l,err", [(180, 0.02), (200, 0.05), (250, 0.02), (250, 0.10), (300, 0.05), (320, 0.02), (400, 0.05), (500, 0.02), (700, 0.05), (960, 0.03), (990, 0.02)])
+@pytest.mark.parametrize("l,err", [(180, 0.02), (200, 0.05), (250, 0.02), (250, 0.10), (300, 0.05), (320, 0.02), (400, 0.05), (500, 0.02), (700, 0.05), (960, 0.03), (990, 0.02),
+                                   (1000, 0.05), (1200, 0.02), (1450, 0.02), (1500, 0.01), (1900, 0.03), (2000, 0.02)])
 def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
     """dp_group_kernel (READ_SIZE 177 .. 1024: G consecutive lanes own a pair, dp_strip's packed row body with the prefix minimum as ONE wave scan over
     (pair rank, value) keys) against the oracle: every length relation -- plen < / == / > tlen incl. long tails (the aliased boundary cell of every row,
-    the last row's tail cells; nw.c:109-153, swg.c:121-171 over the flat table) --, the pairs it leaves to its to-do list (empty sequences, plen > 2 tlen)
-    through both fallbacks (nw_lane / swg_lane up to READ_SIZE 320, dp_strip in to-do mode above), non-ACGT bytes, other costs (NW: GAP_I != GAP_D),
-    and equality with the kernels it replaced (AIM_NO_DP_GROUP=1)."""
+    the last row's tail cells incl. plen > 2 tlen (round 6); nw.c:109-153, swg.c:121-171 over the flat table) --, the pairs it leaves to its to-do list (empty
+    sequences) through both fallbacks (nw_lane / swg_lane up to READ_SIZE 320, dp_strip in to-do mode above), non-ACGT bytes, other costs (NW: GAP_I != GAP_D),
+    and equality with the kernels it replaced (AIM_NO_DP_GROUP=1). Round 6: score-only READ_SIZE 1025 .. 1536 (20 / 24 registers per lane, two pairs per
+    wavefront), with CIGAR READ_SIZE 1440 .. 2048 (one pair of 45 .. 64 lanes per wavefront); the shapes in between stay on dp_strip_kernel."""
     from aim_amd import engine
     ms, rs = engine.launcher_sizes(algo, l, err)
-    n = 1500 if l <= 400 else 400
+    n = 1500 if l <= 400 else (400 if l <= 1000 else 150)
     req, pat, txt = engine.gen_pairs(8800 + l, 0, n, l, err, rs)
     for i in range(3, n, 17):                                                   # tails of every size
         req["text_len"][i] = max(1, int(req["text_len"][i]) - (i % 61))
@@ -1671,12 +1675,13 @@ def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
         with engine.DeviceSet(1) as s:
             s.configure(params, n)
             s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
-            if rs > 1024:
+            group = rs <= 1024 or (1440 <= rs <= 2048 if bt else rs <= (1536 if algo == "nw" else 1280))
+            if not group:
                 assert s.plan_describe(0).startswith("dp_strip_kernel"), s.plan_describe(0)
                 continue
             assert s.plan_describe(0).startswith("dp_group_kernel"), s.plan_describe(0)
-            out = int(((req["pattern_len"] < 1) | (req["text_len"] < 1) | (req["pattern_len"] > 2 * req["text_len"])).sum())
-            assert s.fallback_pairs(0) == out and out >= 3, (s.fallback_pairs(0), out)
+            out = int(((req["pattern_len"] < 1) | (req["text_len"] < 1)).sum())
+            assert s.fallback_pairs(0) == out and out >= 2, (s.fallback_pairs(0), out)
     params = engine.make_params(algo, ms, rs, backtrace=bt, **costs[0])
     res1, ops1 = engine.align(params, req, pat, txt, check=False)
     monkeypatch.setenv("AIM_NO_DP_GROUP", "1")
@@ -1738,6 +1743,8 @@ def test_nw_asymmetric_gap_costs_on_every_nw_kernel(gpu, monkeypatch, kernel, bt
         monkeypatch.setenv("AIM_NO_NW_REG", "1")
     if kernel == "dp_wave":
         monkeypatch.setenv("AIM_DPW_LEGACY", "1")
+    if kernel == "dp_strip":
+        monkeypatch.setenv("AIM_NO_DP_GROUP", "1")                             # (round 6: score-only READ_SIZE 1064 is dp_group_kernel's, 20 registers per lane)
     req, pat, txt = engine.gen_pairs(9100 + gi, 0, n, l, err, rs)
     for i in range(3, n, 41):                                                  # more tails / short texts than the generator draws
         req["text_len"][i] = max(1, int(req["text_len"][i]) - (i % 9))

@@ -80,6 +80,14 @@ def main():
         summary["kernel"] = disp["kernel"]
         disp["lds_note"] = "rocprofv3's LDS_Block_Size is the STATIC allocation; these kernels use dynamic LDS only -- its size is the `lds=` field of the plan line"
         summary["dispatch"] = disp
+        disp["vgpr_note"] = ("rocprofv3's VGPR_Count is the dispatch record's rounded ARCH count; the kernel's allocation is `code_object` below "
+                             "(.vgpr_count / .agpr_count / .private_segment_fixed_size of the library's metadata notes, tools/codeobj_regs.py)")
+        try:
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import codeobj_regs
+            summary["code_object"] = codeobj_regs.lookup(codeobj_regs.kernel_regs(), disp["kernel"])
+        except Exception as e:   # (no llvm tools: the summary says so instead of guessing)
+            summary["code_object"] = {"error": repr(e)}
         summary["kernel_trace"] = {"launches": len(durs), "avg_us": sum(durs) / len(durs) / 1e3, "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3}
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
         shutil.copy(f, os.path.splitext(a.out)[0].replace("_pmc_summary", "") + "_kernel_stats.csv")
@@ -115,6 +123,10 @@ def main():
                                  % ("yes" if a.fetch_x2 else "no -- access width uncalibrated, raw value kept", a.note))
     if a.alg_bytes:
         summary["algorithmic_bytes_per_launch"] = a.alg_bytes
+        if summary.get("hbm_traffic_bytes_per_launch") and summary["hbm_traffic_bytes_per_launch"] < a.alg_bytes:
+            summary["traffic_note"] = ("the counters' traffic (%.1f MB) is BELOW the bytes this kernel must read and write (%.1f MB algorithmic): the x2 rule for FETCH_SIZE is "
+                                       "calibrated on 16-B-per-lane coalesced streaming reads and under-counts this kernel's loads (narrower or strided accesses are counted at a "
+                                       "different granularity) -- the figure is a lower bound, not a measurement of re-use" % (summary["hbm_traffic_bytes_per_launch"] / 1e6, a.alg_bytes / 1e6))
         if "kernel_trace" in summary:
             summary["algorithmic_GBps"] = a.alg_bytes / (summary["kernel_trace"]["avg_us"] * 1e-6) / 1e9
             summary["roofline_frac_of_8TBps"] = summary["algorithmic_GBps"] / 8000.0
