@@ -3,7 +3,7 @@
 # rocprofv3 kernel stats + PMC summaries for every BASELINE configuration's kernel (tools/pmc_summary.py: stats pass and PMC
 # passes are separate runs), then the kernel timers of every configuration of tools/bench_configs.py.
 # Results go to profiles/<round-dir>/ AND are mirrored under gpurun_out/ (the only directory gpurun copies back).
-R=${1:-r05}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
+R=${1:-r06}; P=profiles/$R; O=gpurun_out/profile_$R; mkdir -p $O $P
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python3 tools/pmc_summary.py --out $P/wfa_lane_pmc_summary.json --kernel wfa_lane_kernel --pairs 4194304 --alg-bytes 905968812 --fetch-x2 --io compact \
    --note "Cross-check: 4194304 pairs x (224 B rows + 8 B request) = 973.1 MB read, x 8 B result = 33.6 MB written." \
@@ -31,7 +31,7 @@ python3 tools/pmc_summary.py --out $P/nw_reg_pmc_summary.json --kernel nw_reg_ke
    --note "NW l=100 e=1% score-only, 1 Mi pairs: the DP row in registers (dp_reg.hpp); per-lane 112-byte rows read as dwords: FETCH_SIZE kept raw." \
    -- python3 tools/bench_configs.py nw_l100_e1_score > $O/pmc_nwreg.log 2>&1; tail -1 $O/pmc_nwreg.log
 python3 tools/pmc_summary.py --out $P/nw_reg_cigar_pmc_summary.json --kernel nw_reg_kernel --pairs 1048576 \
-   --note "NW l=100 e=1% with CIGAR, 1 Mi pairs: two direction bits per cell (8 dwords per row and lane) instead of an int16 table." \
+   --note "NW l=100 e=1% with CIGAR, 1 Mi pairs: two direction bits per cell, round 6: only the band of four dwords around the diagonal is stored (one 16-byte unit per row and lane; 8 dwords before) and the walk fetches eight rows at a time." \
    -- python3 tools/bench_configs.py nw_l100_e1_cigar > $O/pmc_nwregc.log 2>&1; tail -1 $O/pmc_nwregc.log
 python3 tools/pmc_summary.py --out $P/wfa_group_long_pmc_summary.json --kernel wfa_group_kernel --pairs 8192 \
    --note "WFA-adaptive l=10000 e=1% (MAX_SCORE 500, READ_SIZE 10112) score-only, 8192 pairs: wfa_group_kernel G=32 since round 4 (wfa_wave_kernel before)." \
@@ -40,7 +40,7 @@ python3 tools/pmc_summary.py --out $P/swg_reg_pmc_summary.json --kernel swg_reg_
    --note "SWG l=100 e=1% score-only, 1 Mi pairs: M and I rows in registers (dp_reg.hpp, round 5; int8 cells as value * 256 in 16-bit fields)." \
    -- python3 tools/bench_configs.py swg_l100_e1_score > $O/pmc_swgreg.log 2>&1; tail -1 $O/pmc_swgreg.log
 python3 tools/pmc_summary.py --out $P/swg_reg_cigar_pmc_summary.json --kernel swg_reg_kernel --pairs 1048576 \
-   --note "SWG l=100 e=1% with CIGAR, 1 Mi pairs: four direction bits per cell (14 dwords per row and lane, stored as 16)." \
+   --note "SWG l=100 e=1% with CIGAR, 1 Mi pairs: four direction bits per cell, round 6: made and stored for the band of four dwords (32 columns) around the diagonal only (14 dwords per row and lane before), the walk fetches eight rows at a time." \
    -- python3 tools/bench_configs.py swg_l100_e1_cigar > $O/pmc_swgregc.log 2>&1; tail -1 $O/pmc_swgregc.log
 AIM_NO_SWG_REG=1 python3 tools/pmc_summary.py --out $P/swg_lane_pmc_summary.json --kernel swg_lane_kernel --pairs 1048576 \
    --note "swg_lane_kernel alone (AIM_NO_SWG_REG=1: what round 4 ran; now the to-do pass of swg_reg): SWG l=100 e=1% score-only, 1 Mi pairs." \
@@ -57,7 +57,13 @@ python3 tools/pmc_summary.py --out $P/dp_group_pmc_summary.json --kernel dp_grou
 python3 tools/pmc_summary.py --out $P/dp_group_swg_cigar_pmc_summary.json --kernel dp_group_kernel --pairs 99328 \
    --note "SWG (int16 cells) l=250 e=2% with CIGAR, 99 328 pairs: dp_group_kernel, four direction bits per cell + the wavefront's walks." \
    -- python3 tools/bench_configs.py swg_l250_e2_w16_cigar > $O/pmc_dpgc.log 2>&1; tail -1 $O/pmc_dpgc.log
-python3 tools/length_sweep.py $P/length_sweep_after.txt > $O/length_sweep.log 2>&1
+python3 tools/pmc_summary.py --out $P/dp_group_kp20_pmc_summary.json --kernel dp_group_kernel --pairs 16384 \
+   --note "NW l=1200 e=2% score-only, 16 384 pairs: dp_group_kernel with 20 registers (40 columns) per lane, 31 lanes per pair, two pairs per wavefront (round 6; dp_strip_kernel, one wavefront per pair, before)." \
+   -- python3 tools/bench_configs.py nw_l1200_e2_score > $O/pmc_dpg20.log 2>&1; tail -1 $O/pmc_dpg20.log
+python3 tools/pmc_summary.py --out $P/dp_group_l2000_cigar_pmc_summary.json --kernel dp_group_kernel --pairs 1024 \
+   --note "SWG (int16 cells) l=2000 e=2% with CIGAR, 1 024 pairs: dp_group_kernel with ONE pair of 64 lanes per wavefront (round 6; dp_strip_kernel's two-wavefront strips before: 727 GCUPS)." \
+   -- python3 tools/bench_configs.py swg_l2000_e2_w16_cigar > $O/pmc_dpg2000.log 2>&1; tail -1 $O/pmc_dpg2000.log
+python3 tools/length_sweep.py $P/length_sweep.txt > $O/length_sweep.log 2>&1
 python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
 python3 -c "
 import sys, json
