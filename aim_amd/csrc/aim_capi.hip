@@ -130,7 +130,6 @@ aim::Knobs read_knobs()
     k.dbg_flags &= 2;    // they exist in diagnostic builds only (python -m aim_amd.build --variant diag --flags "-DAIM_DIAG_BUILD=1"). Bit 2 changes the route, not the result.
 #endif
     k.nw_reg_per_cu = env_int("AIM_NW_REG_PER_CU", -1);
-    k.reg_phase = env_int("AIM_REG_PHASE", -1);
     k.group_lds_kb = env_int("AIM_GROUP_LDS_KB", -1);
     k.group_g = env_int("AIM_GROUP_G", -1);
     k.group_per_cu = env_int("AIM_GROUP_PER_CU", -1);
@@ -805,7 +804,6 @@ int launch(const Plan &pl, const aim::Knobs &kn, const aim_params_t &p, uint32_t
         uint32_t *todo_d = reinterpret_cast<uint32_t *>((char *)d_scratch + (pl.scratch_total - pl.todo_bytes));
         HIP_TRY(hipMemsetAsync(todo_d, 0, 64, stream));
         ka.todo = todo_d;
-        ka.slot_w = (uint32_t)(kn.reg_phase >= 0 ? kn.reg_phase : p.read_size / 5);   // (dp_reg.hpp: reg_phase_shift)
         if (p.algo == AIM_ALGO_SWG) aim::swg_reg_launch(p, pl.grid, pl.lds, ka, stream);
         else aim::nw_reg_launch(p, pl.grid, pl.lds, ka, stream);
         HIP_TRY(hipGetLastError());

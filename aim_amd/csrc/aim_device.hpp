@@ -108,7 +108,6 @@ struct Knobs {
     bool no_dp_group = false;     // AIM_NO_DP_GROUP=1   NW / SWG medium reads (READ_SIZE 177 .. 1024): nw_lane / swg_lane / dp_strip only, no dp_group_kernel (G lanes per pair) in front
     int dpg_per_cu = -1;          // AIM_DPG_PER_CU=n    dp_group_kernel: wavefronts per CU (default 8; experiments)
     int nw_reg_per_cu = -1;       // AIM_NW_REG_PER_CU   nw_reg: residency sweep
-    int reg_phase = -1;           // AIM_REG_PHASE       nw_reg / swg_reg with CIGAR: sleeps (127 x 64 cycles each) by which a SIMD's odd wavefront starts late; -1 = the plan's rule, 0 = off
     int group_lds_kb = -1;        // AIM_GROUP_LDS_KB    wfa_group: LDS budget for the windows of one wavefront's pairs
     int group_g = -1;             // AIM_GROUP_G         wfa_group: lanes per pair
     int group_per_cu = -1;        // AIM_GROUP_PER_CU    wfa_group: residency sweep

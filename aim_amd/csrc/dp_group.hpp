@@ -43,7 +43,7 @@ __host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt = false)
 }
 // BACKTRACE: a pair's slab of direction bits, dp_strip.hpp's layout with K = 32 -- FLW [READ_SIZE + 3 rows][FS lane words of 16 B], then the boundary cells' bytes [row]
 __host__ __device__ inline int dp_group_fs(int rs) { return dp_group_lanes(rs, true); }   // (exactly the pair's lanes: a row of the slab is one contiguous run of 16-byte words, rows follow each other without gaps)
-__host__ __device__ inline size_t dp_group_slab_bytes(int rs) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs) * 16 + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t dp_group_slab_bytes(int rs, bool swg) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs) * (swg ? 16 : 8) + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }   // (lane words: DpBits<32, SWG>)
 
 inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
 {
@@ -74,10 +74,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int *tl = reinterpret_cast<int *>(rowI + rowcap);
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem + (((size_t)P * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15));   // (BT) the traceback's window
     const int FS = dp_group_fs(rs);
-    const size_t slab = dp_group_slab_bytes(rs);
+    const size_t slab = dp_group_slab_bytes(rs, SWG);
+    constexpr int NQS = DpBits<K, SWG>::NQS, RSH = DpBits<K, SWG>::RSH, RM = DpBits<K, SWG>::RM;   // (BT) dwords per lane word of direction bits
     char *slab0 = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
     uint32_t *FLW = reinterpret_cast<uint32_t *>(slab0 + (size_t)(lane_on ? q : 0) * slab);                 // (BT) this pair's direction bits
-    unsigned char *BF = reinterpret_cast<unsigned char *>(FLW + (size_t)(rs + 3) * FS * 4);
+    unsigned char *BF = reinterpret_cast<unsigned char *>(FLW + (size_t)(rs + 3) * FS * NQS);
     uint32_t *todo = const_cast<uint32_t *>(a.todo);
     const int O = a.p.gap_o, E = a.p.gap_e, OE = O + E, MATCH = a.p.match, MISMATCH = a.p.mismatch;
     const int GD = a.p.gap_d, GI = a.p.gap_i, MAXS = a.p.max_score;
@@ -290,9 +291,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int j = 0; j < KP; ++j) {
                     const uint32_t dA = dps_bits(__builtin_elementwise_sub_sat(A[j], Do[j])), dB = dps_bits(__builtin_elementwise_sub_sat(A[j], Iv[j]));
                     const uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);
-                    fw[j >> 2] |= w1 & (0x01010101u << (j & 3));
+                    fw[j >> RSH] |= w1 & (0x01010101u << (j & RM));
                 }
-                if (act && h <= tlen && nvalid > 0 && !(a.dbg_flags & 4u)) *reinterpret_cast<uint4 *>(FLW + ((size_t)h * FS + g) * 4) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+                if (act && h <= tlen && nvalid > 0 && !(a.dbg_flags & 4u)) {
+                    if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(FLW + ((size_t)h * FS + g) * 4) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+                    else *reinterpret_cast<uint2 *>(FLW + ((size_t)h * FS + g) * 2) = make_uint2(fw[0], fw[1]);
+                }
             }
             // ---- a pair's last row: its regular part into the slot (score; the tail walk reads it)
             if (__ballot(act && h == tlen) != 0ull) {
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 int tw_g = -1, tw_R = -1;         // (BT) lane word being assembled for the tail cells, and its canonical row (dp_strip.hpp: row tlen + v / W, column v mod W)
                 uint32_t tw[4] = {0u, 0u, 0u, 0u};
                 auto tw_flush = [&]() {
-                    if (tw_g >= 0) for (int d = 0; d < 4; ++d) FLW[((size_t)tw_R * FS + tw_g) * 4 + d] = tw[d];
+                    if (tw_g >= 0) for (int d = 0; d < NQS; ++d) FLW[((size_t)tw_R * FS + tw_g) * NQS + d] = tw[d];
                 };
                 int Rt = tlen + 1, C = 0;
                 for (int v = W; v <= plen; ++v, ++C) {
@@ -349,14 +353,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         else {
                             if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left
                                 const int t = (C - 2) - tw_g * K, j = t >> 1;
-                                tw[j >> 2] |= xD << (8 * (t & 1) + 4 + (j & 3));
+                                tw[j >> RSH] |= xD << (8 * (t & 1) + 4 + (j & RM));
                             }
                             const int gg = (C - 1) / K, t = (C - 1) - gg * K, j = t >> 1;
                             if (gg != tw_g || Rt != tw_R) {
                                 tw_flush();
                                 tw_g = gg; tw_R = Rt; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
                             }
-                            tw[j >> 2] |= (nD << (8 * (t & 1) + (j & 3))) | (nI << (8 * (2 + (t & 1)) + (j & 3))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & 3)));
+                            tw[j >> RSH] |= (nD << (8 * (t & 1) + (j & RM))) | (nI << (8 * (2 + (t & 1)) + (j & RM))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & RM)));
                         }
                     }
                     if (v < plen) { rowM[v] = (int16_t)cM; if (SWG) rowI[v] = (int16_t)cI; }   // (plen > 2 tlen: read back W cells on, as the cell "above")
@@ -389,11 +393,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const unsigned char *sP = reinterpret_cast<const unsigned char *>(sslot), *sT = sP + seqcap;
                 const int *stl = reinterpret_cast<const int *>(sslot + 2 * seqcap + 2 * 2 * rowcap);
                 const uint32_t *sFLW = reinterpret_cast<const uint32_t *>(slab0 + (size_t)sq * slab);
-                const unsigned char *sBF = reinterpret_cast<const unsigned char *>(sFLW + (size_t)(rs + 3) * FS * 4);
+                const unsigned char *sBF = reinterpret_cast<const unsigned char *>(sFLW + (size_t)(rs + 3) * FS * NQS);
                 char *ops = a.ops + (uint64_t)s_pair * 2 * rs;
                 int begin_offset = s_plen + s_tlen - 1;
                 if (!(a.dbg_flags & 1u))
-                    dp_traceback_swg_bits<K, SWG>(a.p, s_plen, s_tlen, FS, sFLW, sBF, sP, sT, tile, kDpgTileRows, ops, lane, begin_offset, false, 0, 0);
+                    dp_traceback_swg_bits<K, SWG, true>(a.p, s_plen, s_tlen, FS, sFLW, sBF, sP, sT, tile, kDpgTileRows, ops, lane, begin_offset, false, 0, 0);
                 if (lane == 0) {
                     aim_result_t r;
                     r.max_operations = s_plen + s_tlen;
@@ -415,7 +419,7 @@ inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
     const int G = dp_group_lanes(p.read_size, bt), P = kWave / G;
     *lds = dp_group_lds_bytes(p.read_size, bt);
-    *scratch_per_wg = bt ? (uint64_t)P * dp_group_slab_bytes(p.read_size) : 256;
+    *scratch_per_wg = bt ? (uint64_t)P * dp_group_slab_bytes(p.read_size, p.algo == AIM_ALGO_SWG) : 256;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(kn.dpg_per_cu > 0 ? (size_t)kn.dpg_per_cu : 8, lds_workgroups_per_cu(*lds));
     uint32_t g = resident_grid(kn, per_cu);
     const uint32_t n_units = (n_pairs + (uint32_t)P - 1u) / (uint32_t)P;

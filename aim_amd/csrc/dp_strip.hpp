@@ -101,12 +101,26 @@ __device__ __forceinline__ int strip_wait(lds_msg_p m, int seq)
 // Per row and lane NQS dwords (dword q: registers 4q .. 4q + 3; byte b of it: low nibble bit k = register 4q + k's "M != D" (b = 0, 1: low / high half) or
 // "M != I" (b = 2, 3), high nibble: "next D extended" / "I extended"), row h's words at FLW[(h * FS + lane) * NQS]; boundary cells (column 0) in BF[row]:
 // bits 0 - 3 the cell's own four tests (D extended = its OWN), bit 4 "D of column 1 extended".
-template <int K, bool SWG>
+// The lane word of direction bits: SWG four bits per cell -> a dword per FOUR registers (bit k of the low nibbles = register 4q + k's M-layer tests, high nibbles the
+// two gap tests); NW has the M-layer tests only, so (round 6) a dword holds EIGHT registers -- bit k of every byte, k = 0 .. 7 -- and a lane word is half as long
+// (K = 32: 8 instead of 16 bytes per lane and row; medium reads with CIGAR spent a seventh of their time storing them).
+template <int K, bool SWG> struct DpBits {
+    static constexpr int KP = K / 2;
+    static constexpr int RSH = SWG ? 2 : 3;                       // registers per dword, as a shift ...
+    static constexpr int RM = (1 << RSH) - 1;                     // ... and a mask
+    static constexpr int NQ = (KP + RM) >> RSH;                   // dwords that hold a lane's K cells
+    static constexpr int NQS = NQ == 3 ? 4 : NQ;                  // dwords per lane word as stored (a 12-byte word is stored as 16)
+};
+template <int NQS> struct DpWord { typedef uint4 type; };
+template <> struct DpWord<2> { typedef uint2 type; };
+template <> struct DpWord<1> { typedef uint32_t type; };
+
+template <int K, bool SWG, bool PF = false>   // PF: the next 64-row window is prefetched (dp_group_kernel; costs 12 registers)
 __device__ __forceinline__ bool dp_traceback_swg_bits(const aim_params_t &p, int plen, int tlen, int FS, const uint32_t *FLW, const unsigned char *BF,
                                                       const unsigned char *ldsP, const unsigned char *ldsT, uint32_t *tile, int tile_rows, char *ops, int lane,
                                                       int &begin_offset, bool banded, int band_lo, int band_hi)
 {   // banded: direction bits exist only where C - R lies in [band_lo, band_hi] (the strips around the diagonal, dp_strip_kernel); returns true when the walk left it
-    constexpr int KP = K / 2, NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;
+    constexpr int NQS = DpBits<K, SWG>::NQS, RSH = DpBits<K, SWG>::RSH, RM = DpBits<K, SWG>::RM;
     const int kTR = tile_rows;                                    // rows of the window: 64 or 256 (what the workgroup's LDS admits)
     constexpr int kTW = 3;                                        // lane words per row of the window: a BAND around the diagonal through the cell it was filled at
     const int rs = p.read_size, W = tlen + 1;
@@ -118,22 +132,50 @@ __device__ __forceinline__ bool dp_traceback_swg_bits(const aim_params_t &p, int
     // follows the diagonal through (tR, tC), which is where the walk goes (a gap moves it by one column: ~K columns of slack either side). 256 rows are 12 KB and
     // 12 loads per lane; the rectangular window of 128 rows x 8 words was 16 KB, 16 loads, and was refilled twice as often.
     int tR = -1, tC = 0;
-    auto wbase = [&](int rr) { const int cc = tC - rr; const int g = ((cc > 1 ? cc : 1) - 1) / K; return g > 0 ? g - 1 : 0; };
+    auto wbase_at = [&](int c0, int rr) { const int cc = c0 - rr; const int g = ((cc > 1 ? cc : 1) - 1) / K; return g > 0 ? g - 1 : 0; };
+    auto wbase = [&](int rr) { return wbase_at(tC, rr); };
+    // Round 6: a window of 64 rows is three loads per lane, and the NEXT window -- the 64 rows below, along the same diagonal -- is asked for as soon as the current one
+    // is in LDS: by the time the walk reaches its last row the loads have long landed in registers, and the refill is a wait + three LDS stores instead of a round trip
+    // to HBM every 32 - 64 steps (medium reads: 5 pairs per wavefront walked one after the other, ~10 refills of ~2 us each per pair = a seventh of NW l = 300 with
+    // CIGAR). A walk that gaps its way out of the prefetched band (~K columns either side) falls back to a direct refill around its own position.
+    typedef typename DpWord<NQS>::type word_t;
+    const bool pf_on = PF && kTR == kWave;                        // (the 256-row window of the long-read strips is 12 loads per lane: not prefetched)
+    word_t pf[PF ? kTW : 1];
+    int pfR = -1, pfC = 0;
+    auto prefetch = [&](int R, int C) {
+        pfR = -1;
+        if (!pf_on || R < 1) return;
+        pfR = R; pfC = C;
+#pragma unroll
+        for (int i = 0; i < (PF ? kTW : 0); ++i) {
+            const int q = lane + i * kWave, rr = q / kTW, w = q - rr * kTW, r = R - rr, gg = wbase_at(C, rr) + w;
+            pf[i] = word_t{};
+            if (r >= 0 && gg < FS) pf[i] = *reinterpret_cast<const word_t *>(&FLW[((size_t)r * FS + gg) * NQS]);
+        }
+    };
     auto refill = [&](int R, int C) {
-        tR = R; tC = C;
-        for (int q = lane; q < kTR * kTW; q += kWave) {
-            const int rr = q / kTW, w = q - rr * kTW, r = R - rr, gg = wbase(rr) + w;
-            if (r >= 0 && gg < FS) {
-                if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(&tile[q * 4]) = *reinterpret_cast<const uint4 *>(&FLW[((size_t)r * FS + gg) * 4]);
-                else *reinterpret_cast<uint2 *>(&tile[q * 2]) = *reinterpret_cast<const uint2 *>(&FLW[((size_t)r * FS + gg) * 2]);
+        const int g = (C > 1 ? C - 1 : 0) / K;
+        bool hit = false;
+        if (pf_on && pfR >= 0 && R <= pfR && R > pfR - kTR) { const int w = g - wbase_at(pfC, pfR - R); hit = w >= 0 && w < kTW; }
+        if (hit) {   // the prefetched window holds the cell: wait for it, move it into LDS
+            tR = pfR; tC = pfC;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < (PF ? kTW : 0); ++i) *reinterpret_cast<word_t *>(&tile[(lane + i * kWave) * NQS]) = pf[i];
+        } else {
+            tR = R; tC = C;
+            for (int q = lane; q < kTR * kTW; q += kWave) {
+                const int rr = q / kTW, w = q - rr * kTW, r = R - rr, gg = wbase(rr) + w;
+                if (r >= 0 && gg < FS) *reinterpret_cast<word_t *>(&tile[q * NQS]) = *reinterpret_cast<const word_t *>(&FLW[((size_t)r * FS + gg) * NQS]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        prefetch(tR - kTR, tC - kTR);
     };
     auto in_tile = [&](int R, int g) { if (!(tR >= 0 && R <= tR && R > tR - kTR)) return false; const int w = g - wbase(tR - R); return w >= 0 && w < kTW; };
     auto tilebits = [&](int R, int C, int g) -> uint32_t {        // regular cell (R, C), C >= 1, inside the window: bit 0 M != D, bit 4 next D extended, bit 16 M != I, bit 20 I extended
         const int t = (C - 1) - g * K, j = t >> 1, rr = tR - R;
-        return tile[(rr * kTW + (g - wbase(rr))) * NQS + (j >> 2)] >> (8 * (t & 1) + (j & 3));
+        return tile[(rr * kTW + (g - wbase(rr))) * NQS + (j >> RSH)] >> (8 * (t & 1) + (j & RM));
     };
     auto cellbits = [&](int R, int C) -> uint32_t {               // wave-uniform (R, C)
         const int g = (C - 1) / K;
@@ -152,7 +194,7 @@ __device__ __forceinline__ bool dp_traceback_swg_bits(const aim_params_t &p, int
             // and the run is the leading lanes that pass; each writes its own 'M' / 'X' (the cell's own characters). At e = 1 % a run is ~100 cells:
             // one lane stepping through them (and the window's refills every 31 rows) was 4.6 of config 4's 23.8 ms.
             const int g0 = (C - 1) / K;
-            if (!in_tile(R, g0) || (tR - kTR + 1 > 1 && R - (tR - kTR + 1) < (kTR > 2 * kWave ? kWave : kTR / 2))) refill(R, C);   // (keep 64 rows -- a window of 64: 32 -- above the current one inside the window)
+            if (!in_tile(R, g0) || (!pf_on && tR - kTR + 1 > 1 && R - (tR - kTR + 1) < kWave)) refill(R, C);   // (the 256-row window keeps 64 rows above the current one inside it; the 64-row window is followed by its prefetched successor: a run is cut at its last row and goes on after the switch)
             const int ri = R - lane, ci = C - lane;
             bool ok = lane < h && lane < v && ci >= 1 && ri >= 1;
             const int gi = ok ? (ci - 1) / K : 0;
@@ -234,7 +276,7 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
     // The workgroup's slab holds FOUR DIRECTION BITS per cell (NW: two of them) -- FLW [row][FS lanes][NQS dwords] + the boundary cells' bytes BF [row] -- and no
     // value plane. (Round 5 kept a POOL of int16 tables behind the slabs, taken under a lock, for pairs with plen > 2 tlen, which ONE lane filled literally; round 6
     // computes those pairs' tail cells like everybody else's -- the last row's tail loop below -- and the pool, its lock and the cross-XCD release / acquire it needed are gone.)
-    constexpr int NQ = (KP + 3) / 4, NQS = NQ == 3 ? 4 : NQ;       // dwords of direction bits per lane and row (a 12-byte word is stored as 16)
+    constexpr int NQS = DpBits<K, SWG>::NQS, RSH = DpBits<K, SWG>::RSH, RM = DpBits<K, SWG>::RM;   // dwords of direction bits per lane and row (DpBits)
     int16_t *tb = reinterpret_cast<int16_t *>(a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave);
     const int FS = rs / K + 2;                    // lanes per row that can hold a column
     uint32_t *FLW = reinterpret_cast<uint32_t *>(tb);             // SWG strip path: direction bits
@@ -501,11 +543,12 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                     for (int j = 0; j < KP; ++j) {
                         const uint32_t dA = dps_bits(__builtin_elementwise_sub_sat(A[j], Do[j])), dB = dps_bits(__builtin_elementwise_sub_sat(A[j], Iv[j]));
                         const uint32_t w1 = __builtin_amdgcn_perm(dB, dA, 0x0b0a0908u);
-                        fw[j >> 2] |= w1 & (0x01010101u << (j & 3));
+                        fw[j >> RSH] |= w1 & (0x01010101u << (j & RM));
                     }
                     uint32_t *dst = FLW + ((size_t)h * FS + wv * kWave + lane) * NQS;
                     if constexpr (NQS == 4) *reinterpret_cast<uint4 *>(dst) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
-                    else *reinterpret_cast<uint2 *>(dst) = make_uint2(fw[0], fw[1]);
+                    else if constexpr (NQS == 2) *reinterpret_cast<uint2 *>(dst) = make_uint2(fw[0], fw[1]);
+                    else *dst = fw[0];
                 }
             };
             for (int h = 1; h <= tlen; ++h) {
@@ -577,14 +620,14 @@ __global__ __launch_bounds__(64 * NWMAX) void dp_strip_kernel(KArgs a)
                             else {
                                 if (C >= 2) {   // this cell's "D extended" is kept at the cell on its left (column 1's: BF bit 4, set with column 0)
                                     const int t = (C - 2) - tw_g * K, j = t >> 1;
-                                    tw[j >> 2] |= xD << (8 * (t & 1) + 4 + (j & 3));
+                                    tw[j >> RSH] |= xD << (8 * (t & 1) + 4 + (j & RM));   // (SWG only: xD is 0 for NW)
                                 }
                                 const int g = (C - 1) / K, t = (C - 1) - g * K, j = t >> 1;
                                 if (g != tw_g || Rt != tw_R) {
                                     tw_flush();
                                     tw_g = g; tw_R = Rt; tw[0] = tw[1] = tw[2] = tw[3] = 0u;
                                 }
-                                tw[j >> 2] |= (nD << (8 * (t & 1) + (j & 3))) | (nI << (8 * (2 + (t & 1)) + (j & 3))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & 3)));
+                                tw[j >> RSH] |= (nD << (8 * (t & 1) + (j & RM))) | (nI << (8 * (2 + (t & 1)) + (j & RM))) | (xI << (8 * (2 + (t & 1)) + 4 + (j & RM)));
                             }
                         }
                         if (v < plen && lane == 0) { rowM[v] = (int16_t)cM; if (SWG) rowI[v] = (int16_t)cI; }   // (read back W cells on; same-wave LDS traffic is ordered)
@@ -678,7 +721,7 @@ inline bool dp_strip_plan(const aim_params_t &p, uint32_t n_pairs, uint64_t budg
     if (!dp_strip_shape(p, kn, &sh, n_pairs)) return false;
     *k_out = sh.k;
     // Round 5: four direction bits per cell (NW uses two; NQS dwords per lane and row) + one byte per row.
-    const uint64_t nq = (uint64_t)((sh.k / 2 + 3) / 4), nqs = nq == 3 ? 4 : nq, fs = rs / (uint64_t)sh.k + 2;
+    const uint64_t nq = swg ? (uint64_t)((sh.k / 2 + 3) / 4) : (uint64_t)((sh.k / 2 + 7) / 8), nqs = nq == 3 ? 4 : nq, fs = rs / (uint64_t)sh.k + 2;   // (DpBits)
     uint64_t per = (rs + 3) * fs * nqs * 4 + (rs + 3) + 64;
     if (!(p.flags & AIM_FLAG_BACKTRACE)) per = 256;
     per = (per + 255) & ~255ull;

@@ -155,7 +155,8 @@ def main():
             # every size (plen > tlen: the aliased boundary cells, the last row's tail cells), outliers for the to-do list (empty sequences, plen > 2 tlen) and
             # its two fallbacks (dp_lane kernels up to READ_SIZE 320, dp_strip in to-do mode above), penalties on both sides of dp_strip_exact_ok()
             algo = rng.choice(["nw", "swg"])
-            rs = rng.choice([176, 184, 192, 200, 224, 256, 264, 288, 320, 328, 336, 384, 416, 512, 520, 640, 728, 736, 992, 1000, 1024, 1032])
+            rs = rng.choice([176, 184, 192, 200, 224, 256, 264, 288, 320, 328, 336, 384, 416, 512, 520, 640, 728, 736, 992, 1000, 1024, 1032,
+                             1040, 1232, 1280, 1288, 1432, 1440, 1488, 1536, 1544, 2000, 2048, 2056])   # (round 6: dp_group_rs_ok's ranges and their neighbours)
             l = rng.randint(max(1, rs - rs // 3), rs - 8)
             e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15])
             if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
@@ -187,7 +188,8 @@ def main():
                 if r < 0.4: req["text_len"][i] = rng.randint(0, int(req["text_len"][i]))
                 elif r < 0.7: req["pattern_len"][i] = rng.randint(0, int(req["pattern_len"][i]))
                 elif r < 0.85: req["text_len"][i] = max(1, int(req["pattern_len"][i]) - rng.randint(1, 70))
-                else: req["text_len"][i] = max(1, (int(req["pattern_len"][i]) + 1) // 2 + rng.randint(-1, 1))
+                elif r < 0.93: req["text_len"][i] = max(1, (int(req["pattern_len"][i]) + 1) // 2 + rng.randint(-1, 1))
+                else: req["text_len"][i] = max(1, int(req["pattern_len"][i]) // rng.choice([3, 4, 7, 30, 2000]))   # plen > 2 tlen: the last row's tail wraps the flat table more than once
             if n > 8 and rng.random() < 0.3:                            # unrelated texts: every cell on the gap / mismatch branches
                 for i in range(0, n, rng.choice([2, 7, 50])):
                     k = int(req["text_len"][i])
@@ -358,6 +360,11 @@ def main():
                 txt[i, :len(t_)] = t_
                 req["text_len"][i] = len(t_)
             if rng.random() < 0.5: env["AIM_STRIP_K"] = "20"; os.environ["AIM_STRIP_K"] = "20"
+        if algo != "wfa" and rng.random() < 0.3:                   # length outliers: tails of any size, plen > 2 tlen (the last row's tail wraps the flat table more than once), one-character texts
+            for _ in range(rng.choice([1, 3, 20])):
+                i = rng.randrange(n)
+                pl = int(req["pattern_len"][i])
+                req["text_len"][i] = max(1, rng.choice([pl - rng.randint(1, 70), pl // 2, pl // 3, pl // 7, pl // 40, 1]))
         kn = lib.aim_kernel_name(C.byref(params)).decode()
         case = dict(algo=algo, l=l, e=e, n=n, max_score=ms, read_size=rs, kernel=kn, env=env, **{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
         try:
