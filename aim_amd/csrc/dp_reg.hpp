@@ -88,6 +88,129 @@ __host__ __device__ inline size_t nw_reg_lds_bytes(const aim_params_t &p)   // t
     return ((bt && o > t) ? o : t) + 512;
 }
 
+// nw_traceback over the band of direction bits nw_reg_kernel left for ONE batch of 64 pairs (one pair per lane). (A function of its own since round 6's experiment with
+// the walks as a KERNEL of their own behind the fill -- every batch a slab of its own, four walking wavefronts per SIMD instead of two filling ones: the walk kernel alone took
+// 0.98 ms per 1 Mi pairs against the ~0.4 ms the walks add inside the fill kernel, where the other wavefront of the SIMD fills meanwhile. Refuted and removed; NOTES R6.2.)
+template <int NPK>
+__device__ __forceinline__ void nw_reg_walk(const KArgs &a, char *smem, const int lane, uint32_t *tbw, const bool mine, const uint32_t pair, const int plen, const int tlen,
+                                            const uint32_t idx, const int s0, const int bandc, const uint32_t tailbits, const int score, uint32_t *todo)
+{
+    constexpr int NDQ = (NPK + 7) / 8;
+    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+    const int rs = a.p.read_size, W = tlen + 1;
+    const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
+    const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
+    auto band_q0 = [&](int h) { return min(max((bandc + h - 24) >> 4, 0), NDQ > 4 ? NDQ - 4 : 0); };   // first dword of row h's window (as the fill)
+#define TBU(h) (reinterpret_cast<aim_u32x4 *>(tbw) + ((size_t)(h) * kWave + lane))
+#define TBU2(h) (reinterpret_cast<aim_u32x4 *>(tbw) + ((size_t)((h) + rs + 2) * kWave + lane))
+    {
+        // nw_traceback (nw.c:67-107) over the direction bits (see the header); 'X' / 'M' from the sequences. Ops staged in LDS (the text image is dead by
+        // now), copied out in 16-byte pieces. Round 6: the rows' units are fetched EIGHT ROWS AT A TIME (independent loads, one round trip) and the walk runs
+        // through them row by row -- the walk never returns to a row it has left, so the unrolled row index is static. (Until round 5: one dependent HBM load per
+        // step, ~100 round trips of ~1 us per pair: 0.97 of the kernel's 3.6 ms at l = 100.)
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        bool lost = false;                                     // the walk left the band: the pair goes to the to-do list
+        if (mine && !(a.dbg_flags & 5u)) {
+            int begin_offset = plen + tlen - 1;
+            const int end_offset = plen + tlen;
+            char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+            const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
+            unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem) + lane * reg_ops_stride(rs) + 16;   // this lane's row (reg_ops_stride)
+#define OPS(i) ops_l[(i)]
+            int sentinel = end_offset - 1;
+            int h = tlen, v = plen;
+            // One step of the walk on a cell's code (bit 0 "not D", bit 1 "not I"), WITHOUT branches: the walk is a chain of ~130 dependent steps per pair on all 64
+            // lanes, and as three divergent branches per step it cost as many instructions as a seventh of the fill.
+#define NW_STEP(code_, pch_, tch_) do { const uint32_t cd_ = (code_), pq_ = (pch_), tq_ = (tch_);   /* (the characters are READ whatever the code says: as operands of the */ \
+                const uint32_t xm_ = pq_ != tq_ ? (uint32_t)'X' : (uint32_t)'M';                       /*  selects they would be fetched lazily, i.e. behind branches)          */ \
+                const uint32_t op_ = !(cd_ & 1u) ? (uint32_t)'D' : (!(cd_ & 2u) ? (uint32_t)'I' : xm_);                                            \
+                OPS(sentinel) = (unsigned char)op_;                                                                                               \
+                --sentinel; h -= (int)(cd_ & 1u); v -= (int)(((cd_ >> 1) | ~cd_) & 1u); } while (0)
+            // The walk's characters without a dependent global load per step (two per 'M' / 'X' step until round 6: what was left of the walk's time once the
+            // direction bits came eight rows at a time): the PATTERN row is staged in LDS, in the ops row itself (row byte i at OPS(i)) -- the cursor
+            // never reaches a pattern byte that is still to be read (cursor - (v - 1) = h >= 1 at every step) --, the TEXT characters of a batch's eight rows
+            // come with the batch (row h needs t[h - 1] only).
+            for (int b = 0; 16 * b < rs; ++b) {
+                const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
+                *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            // A pair with tail cells starts in the last row's tail: the cell the reference reads at flat index W h + v with v > W is the tail cell v - W (h == tlen:
+            // its bits are in `tailbits`, its characters its own). Above the last row such an index is cell (h + 1, v - W) of the table: one of the next row's first
+            // eight columns (TBU2).
+            constexpr int NB = 8;                             // rows per batch
+            aim_u32x4 u[NB];                                  // the units of rows h0 .. h0 - NB + 1 ...
+            uint32_t tc[NB];                                  // ... and those rows' text characters
+            int h0 = -1;
+            while (h > 0 && v > 0 && !lost) {
+                while (h > 0 && v > W) {                      // (pairs with tail cells, until the walk is back inside the table's own columns: one dependent load per step)
+                    if (h == tlen) NW_STEP((tailbits >> (2 * (v - W))) & 3u, OPS(v - 1), tbytes[h - 1]);
+                    else {
+                        const int vv = v - W, i = vv + s0;    // cell (h + 1, v - W); its characters are that cell's own
+                        const aim_u32x4 w = __builtin_nontemporal_load(TBU2(h + 1));
+                        const uint32_t word = band_pick(w[0], w[1], w[2], 0u, i >> 4) >> (8 * (i & 1) + ((i >> 1) & 7));
+                        NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(vv - 1), tbytes[h]);
+                    }
+                }
+                if (!(h > 0 && v > 0)) break;
+                if (h != h0) {                                // the first batch: rows h .. h - NB + 1
+                    h0 = h;
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) { u[r] = __builtin_nontemporal_load(TBU(max(h0 - r, 1))); tc[r] = tbytes[max(h0 - r, 1) - 1]; }
+                }
+                aim_u32x4 un[NB];                             // the NEXT batch is asked for before this one is walked: its round trip hides behind the steps
+                uint32_t tn[NB];
+#pragma unroll
+                for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    const int qw = band_q0(h0 - r);           // the row's window (per lane: the lanes' rows differ)
+                    while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= W from here on)
+                        const int i = v + s0, q = i >> 4;
+                        lost = (uint32_t)(q - qw) >= 4u;                 // (outside the window: this step's result is void, the pair goes to the to-do list)
+                        const uint32_t word = band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 7));
+                        NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(v - 1), tc[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < NB; ++r) { u[r] = un[r]; tc[r] = tn[r]; }
+                h0 -= NB;
+            }
+            if (!lost) {
+                while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+                while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
+                begin_offset = sentinel + 1;
+                {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(ops_l);
+                    uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                    for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q];
+                }
+                aim_result_t res;
+                res.max_operations = plen + tlen;
+                res.begin_offset = begin_offset;
+                res.end_offset = end_offset;
+                res.score = score;
+                res.status = AIM_PAIR_OK;
+                res.idx = idx;
+                store_result(a, pair, res);
+            }
+#undef NW_STEP
+#undef OPS
+        }
+        {   // pairs whose walk left the band: nw_lane_kernel aligns them again behind this kernel (one atomic per wavefront that holds one)
+            const unsigned long long lm = __ballot(lost);
+            if (lm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(lm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (lost) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))] = pair;
+            }
+        }
+    }
+#undef TBU
+#undef TBU2
+}
+
 template <int NPK, bool BT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void nw_reg_kernel(KArgs a)   // (two wavefronts per SIMD: vector + accumulation registers <= 256)
 {
@@ -410,108 +533,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             continue;
         }
-        // nw_traceback (nw.c:67-107) over the direction bits (see the header); 'X' / 'M' from the sequences. Ops staged in LDS (the text image is dead by
-        // now), copied out in 16-byte pieces. Round 6: the rows' units are fetched EIGHT ROWS AT A TIME (independent loads, one round trip) and the walk runs
-        // through them row by row -- the walk never returns to a row it has left, so the unrolled row index is static. (Until round 5: one dependent HBM load per
-        // step, ~100 round trips of ~1 us per pair: 0.97 of the kernel's 3.6 ms at l = 100.)
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        bool lost = false;                                     // the walk left the band: the pair goes to the to-do list
-        if (mine && !(a.dbg_flags & 5u)) {
-            int begin_offset = plen + tlen - 1;
-            const int end_offset = plen + tlen;
-            char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
-            const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
-            unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem) + lane * reg_ops_stride(rs) + 16;   // this lane's row (reg_ops_stride)
-#define OPS(i) ops_l[(i)]
-            int sentinel = end_offset - 1;
-            int h = tlen, v = plen;
-            // One step of the walk on a cell's code (bit 0 "not D", bit 1 "not I"), WITHOUT branches: the walk is a chain of ~130 dependent steps per pair on all 64
-            // lanes, and as three divergent branches per step it cost as many instructions as a seventh of the fill.
-#define NW_STEP(code_, pch_, tch_) do { const uint32_t cd_ = (code_); const bool nd_ = (cd_ & 1u) != 0u, ni_ = (cd_ & 2u) != 0u;                  \
-                OPS(sentinel) = !nd_ ? 'D' : (!ni_ ? 'I' : (((pch_) != (tch_)) ? 'X' : 'M'));                                                     \
-                --sentinel; h -= nd_ ? 1 : 0; v -= (nd_ && !ni_) ? 0 : 1; } while (0)
-            // The walk's characters without a dependent global load per step (two per 'M' / 'X' step until round 6: what was left of the walk's time once the
-            // direction bits came eight rows at a time): the PATTERN row is staged in LDS, in the ops row itself (row byte i at OPS(i)) -- the cursor
-            // never reaches a pattern byte that is still to be read (cursor - (v - 1) = h >= 1 at every step) --, the TEXT characters of a batch's eight rows
-            // come with the batch (row h needs t[h - 1] only).
-            for (int b = 0; 16 * b < rs; ++b) {
-                const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
-                *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            // A pair with tail cells starts in the last row's tail: the cell the reference reads at flat index W h + v with v > W is the tail cell v - W (h == tlen:
-            // its bits are in `tailbits`, its characters its own). Above the last row such an index is cell (h + 1, v - W) of the table: one of the next row's first
-            // eight columns (TBU2).
-            constexpr int NB = 8;                             // rows per batch
-            aim_u32x4 u[NB];                                  // the units of rows h0 .. h0 - NB + 1 ...
-            uint32_t tc[NB];                                  // ... and those rows' text characters
-            int h0 = -1;
-            while (h > 0 && v > 0 && !lost) {
-                while (h > 0 && v > W) {                      // (pairs with tail cells, until the walk is back inside the table's own columns: one dependent load per step)
-                    if (h == tlen) NW_STEP((tailbits >> (2 * (v - W))) & 3u, OPS(v - 1), tbytes[h - 1]);
-                    else {
-                        const int vv = v - W, i = vv + s0;    // cell (h + 1, v - W); its characters are that cell's own
-                        const aim_u32x4 w = __builtin_nontemporal_load(TBU2(h + 1));
-                        const uint32_t word = band_pick(w[0], w[1], w[2], 0u, i >> 4) >> (8 * (i & 1) + ((i >> 1) & 7));
-                        NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(vv - 1), tbytes[h]);
-                    }
-                }
-                if (!(h > 0 && v > 0)) break;
-                if (h != h0) {                                // the first batch: rows h .. h - NB + 1
-                    h0 = h;
-#pragma unroll
-                    for (int r = 0; r < NB; ++r) { u[r] = __builtin_nontemporal_load(TBU(max(h0 - r, 1))); tc[r] = tbytes[max(h0 - r, 1) - 1]; }
-                }
-                aim_u32x4 un[NB];                             // the NEXT batch is asked for before this one is walked: its round trip hides behind the steps
-                uint32_t tn[NB];
-#pragma unroll
-                for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
-#pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    const int qw = band_q0(h0 - r);           // the row's window (per lane: the lanes' rows differ)
-                    while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= W from here on)
-                        const int i = v + s0, q = i >> 4;
-                        if ((uint32_t)(q - qw) >= 4u) { lost = true; break; }
-                        const uint32_t word = band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 7));
-                        NW_STEP((word & 1u) | ((word >> 15) & 2u), OPS(v - 1), tc[r]);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < NB; ++r) { u[r] = un[r]; tc[r] = tn[r]; }
-                h0 -= NB;
-            }
-            if (!lost) {
-                while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
-                while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
-                begin_offset = sentinel + 1;
-                {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(ops_l);
-                    uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
-                    for (int q = begin_offset >> 4; q <= (end_offset - 1) >> 4; ++q) dst[q] = src[q];
-                }
-                aim_result_t res;
-                res.max_operations = plen + tlen;
-                res.begin_offset = begin_offset;
-                res.end_offset = end_offset;
-                res.score = score;
-                res.status = AIM_PAIR_OK;
-                res.idx = rq.idx;
-                store_result(a, pair, res);
-            }
-#undef NW_STEP
-#undef OPS
-        }
-        {   // pairs whose walk left the band: nw_lane_kernel aligns them again behind this kernel (one atomic per wavefront that holds one)
-            const unsigned long long lm = __ballot(lost);
-            if (lm) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(lm));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (lost) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(lm & ((1ull << lane) - 1ull))] = pair;
-            }
-        }
+        nw_reg_walk<NPK>(a, smem, lane, tbw, mine, pair, plen, tlen, rq.idx, s0, bandc, tailbits, score, todo);
     }
 #undef TBU
+#undef TBU2
 }
 
 // bytes of one wavefront's table slab (BACKTRACE) and of the workgroup's LDS
@@ -591,6 +616,126 @@ __device__ __forceinline__ uint32_t swg_chain(uint32_t Dprev, uint32_t Aprev, ui
         "v_min_i16_sdwa %0, %5, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0"
         : "=&v"(d), "=&v"(t) : "v"(Dprev), "v"(Aprev), "v"(e2), "v"(aoe));
     return d;
+}
+
+// swg_traceback over the band of direction bits swg_reg_kernel left for ONE batch of 64 pairs (one pair per lane; see nw_reg_walk).
+template <int NPK>
+__device__ __forceinline__ void swg_reg_walk(const KArgs &a, char *smem, const int lane, uint32_t *tbw, const bool mine, const uint32_t pair, const int plen, const int tlen,
+                                             const uint32_t idx, const int bandc, const uint32_t tailbits, const int score, uint32_t *todo)
+{
+    constexpr int NQ = (NPK + 3) / 4;
+    typedef uint32_t aim_u32x4 __attribute__((ext_vector_type(4)));
+    const int rs = a.p.read_size;
+    const uint32_t *gP = reinterpret_cast<const uint32_t *>(a.patterns + (uint64_t)pair * rs);
+    const uint32_t *gT = reinterpret_cast<const uint32_t *>(a.texts + (uint64_t)pair * rs);
+    const unsigned long long mask_below = (1ull << lane) - 1ull;
+    auto band_q0 = [&](int h) { return min(max((bandc + h - 13) >> 3, 0), NQ > 4 ? NQ - 4 : 0); };   // first dword of row h's window (as the fill)
+#define TBU(h) (reinterpret_cast<aim_u32x4 *>(tbw) + ((size_t)(h) * kWave + lane))
+#define TBD0(h) (tbw + ((size_t)(rs + 2) * kWave * 4 + (size_t)(h) * kWave + lane))
+    {
+        int begin_offset = plen + tlen - 1;
+        const int end_offset = plen + tlen;
+        bool lost = false;                                    // the walk left the band: the pair goes to the to-do list
+        {
+            // swg_traceback (swg.c:45-119) over the direction bits; 'X' / 'M' from the sequences. Ops staged in LDS (the text image is dead by now), copied out in
+            // 16-byte pieces. Round 6: the rows' units are fetched eight rows at a time and the walk runs through them row by row (see nw_reg_kernel).
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (mine && !(a.dbg_flags & 5u)) {
+                char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
+                const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
+                unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem) + lane * reg_ops_stride(rs) + 16;   // this lane's row (reg_ops_stride)
+#define OPS(i) ops_l[(i)]
+                int sentinel = end_offset - 1;
+                int h = tlen, v = plen;
+                int layer = 0;                                // 0: M, 1: I, 2: D
+                const int Wc = tlen + 1;
+                // One step of swg_traceback on a cell's bits (bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended), without branches (see nw_reg_kernel):
+                // in layer D / I the step emits the gap and stays or returns to M; in layer M it changes layer (nothing emitted: the byte written at the cursor is
+                // overwritten by the next step) or emits 'M' / 'X'.
+#define SWG_STEP(bits_, pch_, tch_) do { const uint32_t bq_ = (bits_), pq_ = (pch_), tq_ = (tch_);   /* (the characters are read whatever the layer: see NW_STEP) */ \
+                    const bool inD_ = layer == 2, inI_ = layer == 1, inM_ = layer == 0;                                                       \
+                    const bool toD_ = inM_ && !(bq_ & 1u), toI_ = inM_ && (bq_ & 1u) && !(bq_ & 0x10000u), dg_ = inM_ && (bq_ & 1u) && (bq_ & 0x10000u); \
+                    const uint32_t xm_ = pq_ != tq_ ? (uint32_t)'X' : (uint32_t)'M';                                                          \
+                    OPS(sentinel) = (unsigned char)(inD_ ? (uint32_t)'D' : (inI_ ? (uint32_t)'I' : xm_));                                     \
+                    sentinel -= (inD_ || inI_ || dg_) ? 1 : 0; v -= (inD_ || dg_) ? 1 : 0; h -= (inI_ || dg_) ? 1 : 0;                        \
+                    layer = inD_ ? ((bq_ & 0x10u) ? 2 : 0) : inI_ ? ((bq_ & 0x100000u) ? 1 : 0) : toD_ ? 2 : toI_ ? 1 : 0; } while (0)
+                // the pattern row staged in LDS in the ops area's own layout, the text characters of a batch's rows with the batch (see nw_reg_kernel)
+                for (int b = 0; 16 * b < rs; ++b) {
+                    const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
+                    *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                // A pair with tail cells starts in the last row's tail: flat index W h + v with v > W is the tail cell v - W (h == tlen: its bits are in `tailbits`,
+                // its characters its own); above the last row it is cell (h + 1, v - W) of the table -- the row's first columns, far outside the band: to-do list.
+                constexpr int NB = 8;                         // rows per batch
+                aim_u32x4 u[NB];                              // the units of rows h0 .. h0 - NB + 1 ...
+                uint32_t tc[NB];                              // ... and those rows' text characters
+                int h0 = -1;
+                while (h > 0 && v > 0 && !lost) {
+                    while (h > 0 && v > Wc) {                 // (pairs with tail cells, until the walk is back inside the table's own columns: one dependent load per step)
+                        if (h == tlen) {
+                            const uint32_t nb = tailbits >> (4 * ((v - Wc) & 7));
+                            SWG_STEP((nb & 1u) | ((nb & 2u) << 15) | ((nb & 4u) << 2) | ((nb & 8u) << 17), OPS(v - 1), tbytes[h - 1]);
+                        } else {
+                            const int vv = v - Wc, i = vv - 1;  // cell (h + 1, v - W), columns 1 .. 8: dword 0; its characters are that cell's own
+                            SWG_STEP(__builtin_nontemporal_load(TBD0(h + 1)) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(vv - 1), tbytes[h]);
+                        }
+                    }
+                    if (!(h > 0 && v > 0)) break;
+                    if (h != h0) {                            // the first batch: rows h .. h - NB + 1
+                        h0 = h;
+#pragma unroll
+                        for (int r = 0; r < NB; ++r) { u[r] = __builtin_nontemporal_load(TBU(max(h0 - r, 1))); tc[r] = tbytes[max(h0 - r, 1) - 1]; }
+                    }
+                    aim_u32x4 un[NB];                         // the NEXT batch is asked for before this one is walked
+                    uint32_t tn[NB];
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) {
+                        const int qw = band_q0(h0 - r);       // the row's window (per lane: the lanes' rows differ)
+                        while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= Wc from here on)
+                            const int i = v - 1, q = i >> 3;
+                            lost = (uint32_t)(q - qw) >= 4u;         // (outside the window: this step's result is void, the pair goes to the to-do list)
+                            SWG_STEP(band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(v - 1), tc[r]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < NB; ++r) { u[r] = un[r]; tc[r] = tn[r]; }
+                    h0 -= NB;
+                }
+                if (!lost) {
+                    while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
+                    while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
+                    begin_offset = sentinel + 1;
+                    const uint4 *src = reinterpret_cast<const uint4 *>(ops_l);
+                    uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
+                    for (int qq = begin_offset >> 4; qq <= (end_offset - 1) >> 4; ++qq) dst[qq] = src[qq];
+                }
+#undef SWG_STEP
+#undef OPS
+            }
+            const unsigned long long lm = __ballot(lost);
+            if (lm) {   // pairs whose walk left the band: swg_lane_kernel aligns them again behind this kernel
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(lm));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (lost) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(lm & mask_below)] = pair;
+            }
+        }
+        if (mine && !lost) {
+            aim_result_t res;
+            res.max_operations = plen + tlen;
+            res.begin_offset = begin_offset;
+            res.end_offset = end_offset;
+            res.score = score;
+            res.status = AIM_PAIR_OK;
+            res.idx = idx;
+            store_result(a, pair, res);
+        }
+    }
+#undef TBU
+#undef TBD0
 }
 
 template <int NPK, bool BT, bool C8>
@@ -866,105 +1011,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if (bad) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(badm & mask_below)] = pair;
         }
-        int begin_offset = plen + tlen - 1;
-        const int end_offset = plen + tlen;
-        bool lost = false;                                    // the walk left the band: the pair goes to the to-do list
-        if (BT) {
-            // swg_traceback (swg.c:45-119) over the direction bits; 'X' / 'M' from the sequences. Ops staged in LDS (the text image is dead by now), copied out in
-            // 16-byte pieces. Round 6: the rows' units are fetched eight rows at a time and the walk runs through them row by row (see nw_reg_kernel).
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (mine && !bad && !(a.dbg_flags & 5u)) {
-                char *ops_g = a.ops + (uint64_t)pair * 2 * rs;
-                const unsigned char *pb = reinterpret_cast<const unsigned char *>(gP), *tbytes = reinterpret_cast<const unsigned char *>(gT);
-                unsigned char *ops_l = reinterpret_cast<unsigned char *>(smem) + lane * reg_ops_stride(rs) + 16;   // this lane's row (reg_ops_stride)
-#define OPS(i) ops_l[(i)]
-                int sentinel = end_offset - 1;
-                int h = tlen, v = plen;
-                int layer = 0;                                // 0: M, 1: I, 2: D
-                const int Wc = tlen + 1;
-                // One step of swg_traceback on a cell's bits (bit 0: M != D, bit 4: D extended, bit 16: M != I, bit 20: I extended), without branches (see nw_reg_kernel):
-                // in layer D / I the step emits the gap and stays or returns to M; in layer M it changes layer (nothing emitted: the byte written at the cursor is
-                // overwritten by the next step) or emits 'M' / 'X'.
-#define SWG_STEP(bits_, pch_, tch_) do { const uint32_t bq_ = (bits_);                                                                      \
-                    const bool inD_ = layer == 2, inI_ = layer == 1, inM_ = layer == 0;                                                       \
-                    const bool toD_ = inM_ && !(bq_ & 1u), toI_ = inM_ && (bq_ & 1u) && !(bq_ & 0x10000u), dg_ = inM_ && (bq_ & 1u) && (bq_ & 0x10000u); \
-                    OPS(sentinel) = inD_ ? 'D' : (inI_ ? 'I' : (((pch_) != (tch_)) ? 'X' : 'M'));                                             \
-                    sentinel -= (inD_ || inI_ || dg_) ? 1 : 0; v -= (inD_ || dg_) ? 1 : 0; h -= (inI_ || dg_) ? 1 : 0;                        \
-                    layer = inD_ ? ((bq_ & 0x10u) ? 2 : 0) : inI_ ? ((bq_ & 0x100000u) ? 1 : 0) : toD_ ? 2 : toI_ ? 1 : 0; } while (0)
-                // the pattern row staged in LDS in the ops area's own layout, the text characters of a batch's rows with the batch (see nw_reg_kernel)
-                for (int b = 0; 16 * b < rs; ++b) {
-                    const aim_u32x4_u w = __builtin_nontemporal_load(reinterpret_cast<const aim_u32x4_u *>(pb) + b);
-                    *reinterpret_cast<uint4 *>(&OPS(16 * b)) = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-                // A pair with tail cells starts in the last row's tail: flat index W h + v with v > W is the tail cell v - W (h == tlen: its bits are in `tailbits`,
-                // its characters its own); above the last row it is cell (h + 1, v - W) of the table -- the row's first columns, far outside the band: to-do list.
-                constexpr int NB = 8;                         // rows per batch
-                aim_u32x4 u[NB];                              // the units of rows h0 .. h0 - NB + 1 ...
-                uint32_t tc[NB];                              // ... and those rows' text characters
-                int h0 = -1;
-                while (h > 0 && v > 0 && !lost) {
-                    while (h > 0 && v > Wc) {                 // (pairs with tail cells, until the walk is back inside the table's own columns: one dependent load per step)
-                        if (h == tlen) {
-                            const uint32_t nb = tailbits >> (4 * ((v - Wc) & 7));
-                            SWG_STEP((nb & 1u) | ((nb & 2u) << 15) | ((nb & 4u) << 2) | ((nb & 8u) << 17), OPS(v - 1), tbytes[h - 1]);
-                        } else {
-                            const int vv = v - Wc, i = vv - 1;  // cell (h + 1, v - W), columns 1 .. 8: dword 0; its characters are that cell's own
-                            SWG_STEP(__builtin_nontemporal_load(TBD0(h + 1)) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(vv - 1), tbytes[h]);
-                        }
-                    }
-                    if (!(h > 0 && v > 0)) break;
-                    if (h != h0) {                            // the first batch: rows h .. h - NB + 1
-                        h0 = h;
-#pragma unroll
-                        for (int r = 0; r < NB; ++r) { u[r] = __builtin_nontemporal_load(TBU(max(h0 - r, 1))); tc[r] = tbytes[max(h0 - r, 1) - 1]; }
-                    }
-                    aim_u32x4 un[NB];                         // the NEXT batch is asked for before this one is walked
-                    uint32_t tn[NB];
-#pragma unroll
-                    for (int r = 0; r < NB; ++r) { un[r] = __builtin_nontemporal_load(TBU(max(h0 - NB - r, 1))); tn[r] = tbytes[max(h0 - NB - r, 1) - 1]; }
-#pragma unroll
-                    for (int r = 0; r < NB; ++r) {
-                        const int qw = band_q0(h0 - r);       // the row's window (per lane: the lanes' rows differ)
-                        while (h == h0 - r && h > 0 && v > 0 && !lost) {     // (v <= Wc from here on)
-                            const int i = v - 1, q = i >> 3;
-                            if ((uint32_t)(q - qw) >= 4u) { lost = true; break; }
-                            SWG_STEP(band_pick(u[r][0], u[r][1], u[r][2], u[r][3], q) >> (8 * (i & 1) + ((i >> 1) & 3)), OPS(v - 1), tc[r]);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < NB; ++r) { u[r] = un[r]; tc[r] = tn[r]; }
-                    h0 -= NB;
-                }
-                if (!lost) {
-                    while (h > 0) { OPS(sentinel) = 'I'; --sentinel; --h; }
-                    while (v > 0) { OPS(sentinel) = 'D'; --sentinel; --v; }
-                    begin_offset = sentinel + 1;
-                    const uint4 *src = reinterpret_cast<const uint4 *>(ops_l);
-                    uint4 *dst = reinterpret_cast<uint4 *>(ops_g);
-                    for (int qq = begin_offset >> 4; qq <= (end_offset - 1) >> 4; ++qq) dst[qq] = src[qq];
-                }
-#undef SWG_STEP
-#undef OPS
+        if (!BT) {
+            if (mine && !bad) {
+                aim_result_t res;
+                res.max_operations = plen + tlen;
+                res.begin_offset = plen + tlen - 1;
+                res.end_offset = plen + tlen;
+                res.score = score;
+                res.status = AIM_PAIR_OK;
+                res.idx = rq.idx;
+                store_result(a, pair, res);
             }
-            const unsigned long long lm = __ballot(lost);
-            if (lm) {   // pairs whose walk left the band: swg_lane_kernel aligns them again behind this kernel
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&todo[LANE_TODO_COUNT], (uint32_t)__builtin_popcountll(lm));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (lost) todo[LANE_TODO_LIST + base + (uint32_t)__builtin_popcountll(lm & mask_below)] = pair;
-            }
-        }
-        if (mine && !bad && !lost) {
-            aim_result_t res;
-            res.max_operations = plen + tlen;
-            res.begin_offset = begin_offset;
-            res.end_offset = end_offset;
-            res.score = score;
-            res.status = AIM_PAIR_OK;
-            res.idx = rq.idx;
-            store_result(a, pair, res);
-        }
+        } else
+            swg_reg_walk<NPK>(a, smem, lane, tbw, mine && !bad, pair, plen, tlen, rq.idx, bandc, tailbits, score, todo);
     };
 
     for (;;) {
