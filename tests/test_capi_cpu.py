@@ -96,7 +96,15 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 160, backtrace=True))) == b"nw_reg_kernel"         # (l = 150: the pattern row in LDS, 12 dwords of direction bits)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184))) == b"dp_group_kernel"                         # round 5: medium reads, G lanes per pair (READ_SIZE 177 .. 1024)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1024, backtrace=True))) == b"dp_group_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032))) == b"dp_strip_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032))) == b"dp_group_kernel"                       # round 6: score-only to READ_SIZE 1536 (NW; 20 / 24 registers per lane) ...
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1536))) == b"dp_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1544))) == b"dp_strip_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1280))) == b"dp_group_kernel"                     # ... / 1280 (SWG)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1288))) == b"dp_strip_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032, backtrace=True))) == b"dp_strip_kernel"       # ... with CIGAR READ_SIZE 1025 .. 1439 stay on the strips,
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1440, backtrace=True))) == b"dp_group_kernel"       #     1440 .. 2048 are one pair of 45 .. 64 lanes per wavefront
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 2048, backtrace=True))) == b"dp_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 2056, backtrace=True))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 336, backtrace=True))) == b"dp_group_kernel"      # (int16 cells by MAX_SCORE)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336, swg_w16=True))) == b"dp_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_strip_kernel" or lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_wave_kernel"   # (int8 cells wrap by design: the literal kernels)
@@ -153,7 +161,7 @@ def test_group_plan_prefers_a_wavefront_per_pair_when_lds_starves_residency(buil
 
 
 def test_dp_group_plan_scratch_and_lds(built):
-    """dp_group_kernel's plan (dp_group.hpp, round 5): with CIGAR every pair of a wavefront owns a slab of [READ_SIZE + 3][G] 16-byte lane words + a byte per boundary cell;
+    """dp_group_kernel's plan (dp_group.hpp, round 5): with CIGAR every pair of a wavefront owns a slab of [READ_SIZE + 3][G] lane words (SWG 16 bytes, NW 8) + a byte per boundary cell;
     the to-do region sits behind the larger of (slabs, the fallback kernel's scratch); LDS = the pairs' slots + the traceback's 3-KB window."""
     import ctypes as C
     from aim_amd import capi, engine
@@ -174,7 +182,7 @@ def test_dp_group_plan_scratch_and_lds(built):
                 assert lds == ((P * slot + 15) & ~15) + (64 * 3 * 16 if bt else 0) + 64, (rs, bt, lds)
                 assert grid == min(2048, ((((1 << 16) + P - 1) // P + 7) // 8) * 8)
                 total = lib.aim_scratch_bytes(C.byref(p), 1 << 16)
-                slab = (((rs + 3) * G * 16 + (rs + 3) + 64) + 255) & ~255
+                slab = (((rs + 3) * G * 8 + (rs + 3) + 64) + 255) & ~255      # (NW: 8-byte lane words since round 6 -- eight registers per dword; SWG: 16)
                 todo = ((16 + (1 << 16)) * 4 + 255) & ~255
                 assert total >= (grid * P * slab if bt else 0) + todo and total < (1 << 33), (rs, bt, total)
     finally:
@@ -197,8 +205,7 @@ def test_scratch_bound_default_and_override(built):
         assert r.returncode == 0, r.stderr
         return tuple(int(x) for x in r.stdout.split())
     # round 5: a resident SWG pair's slab is FOUR DIRECTION BITS per cell (K = 20 cells per lane: 16 bytes per lane and row) + a byte per row -- 82 MB instead of
-    # the 614 MB of three int16 planes; the planes survive as a pool of 1 .. 8 tables for the literal path behind the slabs
-    table = 3 * ((rs4 + 20 + 16) & ~7) * (rs4 + 3) * 2
+    # the 614 MB of three int16 planes; round 6: nothing else (round 5's pool of int16 tables for the literal path is gone with that path)
     per_pair = (((rs4 + 3) * (rs4 // 20 + 2) * 16 + rs4 + 3 + 64) + 255) & ~255
     c4_default, c2_default = q()
     c4_16, c2_16 = q(AIM_SCRATCH_GB="16")
@@ -206,10 +213,10 @@ def test_scratch_bound_default_and_override(built):
     c4_8, _ = q(AIM_SCRATCH_GB="8")
     assert c4_default == c4_16                               # no GPU here: 16 GB fallback
     assert c2_default == c2_16 == c2_100                     # need-capped plan
-    assert c4_16 == 128 * per_pair + 256 + 8 * table and c4_16 <= 16 << 30     # one round of 128 pairs (round 4: five) and the whole pool
+    assert c4_16 == 128 * per_pair and c4_16 <= 16 << 30     # one round of 128 pairs (round 4: five)
     assert c4_100 == c4_16                                   # need-capped too
-    assert c4_8 <= 8 << 30 and c4_8 < c4_16                   # a smaller bound trims the grid / the pool: g slabs + t tables, g a multiple of 8
-    assert any((c4_8 - 256 - t * table) % per_pair == 0 and ((c4_8 - 256 - t * table) // per_pair) % 8 == 0 for t in range(1, 9))
+    assert c4_8 <= 8 << 30 and c4_8 < c4_16                   # a smaller bound trims the grid: g slabs, g a multiple of 8
+    assert c4_8 % per_pair == 0 and (c4_8 // per_pair) % 8 == 0
 
 
 def test_plans_follow_the_device_compute_unit_count(built):
