@@ -558,7 +558,7 @@ int describe_plan(const Plan &pl, const aim_params_t &p, uint32_t n_pairs, uint6
     else if (pl.kid == K_WFA_WAVE) snprintf(extra, sizeof extra, " pool_cap=%u ring=%ux%u seq_lds=%d", pl.pool_cap, pl.ring_slots, pl.slot_w, (int)pl.seq_lds);
     else if (pl.kid == K_DP_LANE) snprintf(extra, sizeof extra, " seq_lds=%d", (int)pl.seq_lds);
     else if (pl.kid == K_DP_REG) snprintf(extra, sizeof extra, " fb_grid=%u fb_lds=%zu", pl.fb_grid, pl.fb_lds);
-    else if (pl.kid == K_DP_GROUP) snprintf(extra, sizeof extra, " lanes_per_pair=%d fb_grid=%u fb_block=%u fb_lds=%zu", aim::dp_group_lanes(p.read_size, (p.flags & AIM_FLAG_BACKTRACE) != 0), pl.fb_grid, pl.fb_block, pl.fb_lds);
+    else if (pl.kid == K_DP_GROUP) snprintf(extra, sizeof extra, " lanes_per_pair=%d fb_grid=%u fb_block=%u fb_lds=%zu", aim::dp_group_lanes(p.read_size, (p.flags & AIM_FLAG_BACKTRACE) != 0, p.algo == AIM_ALGO_SWG), pl.fb_grid, pl.fb_block, pl.fb_lds);
     return snprintf(out, cap, "%s n=%u grid=%u block=%u lds=%zu scratch=%zu budget=%llu%s", kernel_name(pl, p), n_pairs, pl.grid,
                     pl.block, pl.lds, pl.scratch_total, (unsigned long long)budget, extra);
 }

@@ -25,32 +25,57 @@ constexpr int kDpgMinRs = 177;
 // dp_traceback_swg_bits' 16-byte layout for 32 columns); round 6: score-only READ_SIZE 1025 .. 1280 / .. 1536 with 20 / 24 registers -- two pairs of <= 32 lanes per
 // wavefront where dp_strip ran one wavefront per pair (NW l = 1000: 1 980 GCUPS) -- and with CIGAR READ_SIZE 1440 .. 2048 with ONE pair of 45 .. 64 lanes per wavefront
 // (dp_strip's two-wavefront strips with the walk on one of them: 900 / 730 GCUPS at l = 2000).
-__host__ __device__ inline int dp_group_kp(int read_size, bool bt) { return (bt || read_size <= 1024) ? 16 : (read_size <= 1280 ? 20 : 24); }
-__host__ __device__ inline bool dp_group_rs_ok(int read_size, bool bt)
-{
-    if (read_size < kDpgMinRs) return false;
-    return bt ? (read_size <= 1024 || (read_size >= 1440 && read_size <= 2048)) : read_size <= 1536;
-}
-
-__host__ __device__ inline int dp_group_lanes(int read_size, bool bt) { const int k = 2 * dp_group_kp(read_size, bt); return (read_size + k - 1) / k; }   // G: lanes per pair (6 .. 64)
-
+// Registers per lane and row (KP; 2 KP columns per lane): 16, 20 or 24. A wavefront holds P = floor(64 / G) pairs of G = ceil(READ_SIZE / 2 KP) lanes and a row costs ~KP, so the
+// cells per unit of time go as P / KP: READ_SIZE 728 is two pairs of 23 lanes at 16 registers (46 of 64 lanes), three of 19 at 20, FOUR of 16 at 24 -- the dips of round 5's
+// length sweep at l = 320 / 700 were idle lanes. The shape with the largest P / KP among those the configuration has registers for: NW score-only 16 / 20 / 24 (156 / 184 / 213
+// VGPRs), SWG score-only and NW with CIGAR 16 / 20 (SWG spills inside the row at 24; with CIGAR the lane words are 16 bytes for 40 columns of NW, 251 VGPRs), SWG with CIGAR 16.
+// (... times the wavefronts per CU the pairs' LDS slots leave, up to the eight the registers admit: READ_SIZE 192 as sixteen pairs of four lanes is 23 KB per wavefront = six per CU,
+//  and measured 10 % SLOWER than ten pairs of six.)
 // LDS of one pair slot: pattern | text | the last row's M, I (int16) | 16 B {M, D of cell W - 1, M of the cell above it}
 __host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
-constexpr int kDpgTileRows = 64;                 // the traceback's window (dp_traceback_swg_bits): 64 rows x 3 lane words x 16 B = 3 KB (128 rows measured slower: 3.53 -> 3.65 ms at NW l = 300, LDS residency at READ_SIZE 192)
-__host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt = false)
+__host__ __device__ inline int dp_group_kp(int read_size, bool bt, bool swg)
 {
-    return (((size_t)(kWave / dp_group_lanes(rs, bt)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
+    const int kmax = bt ? (swg ? 16 : 20) : (swg ? 20 : 24);
+    int best = 16;
+    long best_num = 0, best_den = 1;
+    for (int kp = 16; kp <= kmax; kp += 4) {
+        const int g = (read_size + 2 * kp - 1) / (2 * kp);
+        if (g > kWave) continue;
+        const int p = kWave / g;
+        const long lds = (((long)p * dp_group_slot_bytes(read_size) + 15) & ~15L) + (bt ? 64 * 3 * 16 : 0) + 64;
+        const long gran = (lds + 1279) / 1280 * 1280;          // (LDS is handed out in 1 280-byte granules: lds_workgroups_per_cu)
+        long waves = 160L * 1024 / gran;
+        waves = waves > 8 ? 8 : (waves < 1 ? 1 : waves);
+        const long num = (long)p * waves, den = kp;
+        if (num * best_den > best_num * den) { best = kp; best_num = num; best_den = den; }   // p waves / kp > best
+    }
+    return best;
 }
-// BACKTRACE: a pair's slab of direction bits, dp_strip.hpp's layout with K = 32 -- FLW [READ_SIZE + 3 rows][FS lane words of 16 B], then the boundary cells' bytes [row]
-__host__ __device__ inline int dp_group_fs(int rs) { return dp_group_lanes(rs, true); }   // (exactly the pair's lanes: a row of the slab is one contiguous run of 16-byte words, rows follow each other without gaps)
-__host__ __device__ inline size_t dp_group_slab_bytes(int rs, bool swg) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs) * (swg ? 16 : 8) + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }   // (lane words: DpBits<32, SWG>)
+__host__ __device__ inline bool dp_group_rs_ok(int read_size, bool bt, bool swg)
+{
+    if (read_size < kDpgMinRs) return false;
+    if (!bt) return read_size <= (swg ? 1280 : 1536);         // (SWG with 24 registers per lane spills inside the row: dp_strip_kernel)
+    return read_size <= 1024 || (!swg && read_size <= 1280) || (read_size >= 1440 && read_size <= 2048);
+}
+
+__host__ __device__ inline int dp_group_lanes(int read_size, bool bt, bool swg) { const int k = 2 * dp_group_kp(read_size, bt, swg); return (read_size + k - 1) / k; }   // G: lanes per pair (6 .. 64)
+
+constexpr int kDpgTileRows = 64;                 // the traceback's window (dp_traceback_swg_bits): 64 rows x 3 lane words x 16 B = 3 KB (128 rows measured slower: 3.53 -> 3.65 ms at NW l = 300, LDS residency at READ_SIZE 192)
+__host__ __device__ inline size_t dp_group_lds_bytes(int rs, bool bt, bool swg)
+{
+    return (((size_t)(kWave / dp_group_lanes(rs, bt, swg)) * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15) + (bt ? (size_t)kDpgTileRows * 3 * 16 : 0) + 64;
+}
+// BACKTRACE: a pair's slab of direction bits, dp_strip.hpp's layout -- FLW [READ_SIZE + 3 rows][FS lane words], then the boundary cells' bytes [row]. Lane words (DpBits): SWG 16 bytes
+// (32 columns x 4 bits), NW 8 bytes at 32 columns, 16 at 40.
+__host__ __device__ inline int dp_group_fs(int rs, bool swg) { return dp_group_lanes(rs, true, swg); }   // (exactly the pair's lanes: a row of the slab is one contiguous run of lane words, rows follow each other without gaps)
+__host__ __device__ inline int dp_group_word_bytes(int rs, bool swg) { return (swg || dp_group_kp(rs, true, swg) > 16) ? 16 : 8; }
+__host__ __device__ inline size_t dp_group_slab_bytes(int rs, bool swg) { return (((size_t)(rs + 3) * (size_t)dp_group_fs(rs, swg) * (size_t)dp_group_word_bytes(rs, swg) + (size_t)(rs + 3) + 64) + 255) & ~(size_t)255; }
 
 inline bool dp_group_supported(const aim_params_t &p, const Knobs &kn)
 {
     if (kn.no_dp_group || kn.force_dpwave || kn.dpw_legacy || kn.strip_k > 0 || kn.dpw_nw > 0) return false;   // (the long-read kernels' own knobs ask for those kernels)
     if (p.algo != AIM_ALGO_NW && p.algo != AIM_ALGO_SWG) return false;
-    if (!dp_group_rs_ok(p.read_size, (p.flags & AIM_FLAG_BACKTRACE) != 0)) return false;
-    if (p.algo == AIM_ALGO_SWG && !(p.flags & AIM_FLAG_BACKTRACE) && p.read_size > 1280) return false;   // (SWG with 24 registers per lane spills inside the row: dp_strip_kernel)
+    if (!dp_group_rs_ok(p.read_size, (p.flags & AIM_FLAG_BACKTRACE) != 0, p.algo == AIM_ALGO_SWG)) return false;
     if (p.algo == AIM_ALGO_SWG && swg_cell_bytes(p) == 1) return false;   // int8 cells wrap by design: the literal kernels
     return dp_strip_exact_ok(p, false);
 }
@@ -73,7 +98,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int16_t *rowM = reinterpret_cast<int16_t *>(ldsT + seqcap), *rowI = rowM + rowcap;
     int *tl = reinterpret_cast<int *>(rowI + rowcap);
     uint32_t *tile = reinterpret_cast<uint32_t *>(smem + (((size_t)P * (size_t)dp_group_slot_bytes(rs) + 15) & ~(size_t)15));   // (BT) the traceback's window
-    const int FS = dp_group_fs(rs);
+    const int FS = dp_group_fs(rs, SWG);
     const size_t slab = dp_group_slab_bytes(rs, SWG);
     constexpr int NQS = DpBits<K, SWG>::NQS, RSH = DpBits<K, SWG>::RSH, RM = DpBits<K, SWG>::RM;   // (BT) dwords per lane word of direction bits
     char *slab0 = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
@@ -417,8 +442,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &kn, uint32_t *grid, size_t *lds, uint64_t *scratch_per_wg)
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    const int G = dp_group_lanes(p.read_size, bt), P = kWave / G;
-    *lds = dp_group_lds_bytes(p.read_size, bt);
+    const bool swg = p.algo == AIM_ALGO_SWG;
+    const int G = dp_group_lanes(p.read_size, bt, swg), P = kWave / G;
+    *lds = dp_group_lds_bytes(p.read_size, bt, swg);
     *scratch_per_wg = bt ? (uint64_t)P * dp_group_slab_bytes(p.read_size, p.algo == AIM_ALGO_SWG) : 256;
     const uint32_t per_cu = (uint32_t)std::min<size_t>(kn.dpg_per_cu > 0 ? (size_t)kn.dpg_per_cu : 8, lds_workgroups_per_cu(*lds));
     uint32_t g = resident_grid(kn, per_cu);
@@ -433,10 +459,11 @@ inline bool dp_group_plan(const aim_params_t &p, uint32_t n_pairs, const Knobs &
 void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KArgs &ka, hipStream_t s)
 {
     const bool bt = (p.flags & AIM_FLAG_BACKTRACE) != 0;
-    const int G = dp_group_lanes(p.read_size, bt), kp = dp_group_kp(p.read_size, bt);
+    const int G = dp_group_lanes(p.read_size, bt, p.algo == AIM_ALGO_SWG), kp = dp_group_kp(p.read_size, bt, p.algo == AIM_ALGO_SWG);
 #define AIM_DPG(ALGO, BT_, KP_) hipLaunchKernelGGL((dp_group_kernel<ALGO, BT_, KP_>), dim3(grid), dim3(kWave), lds, s, ka, G)
     if (p.algo == AIM_ALGO_NW) {
-        if (bt) AIM_DPG(AIM_ALGO_NW, true, 16);
+        if (bt && kp == 16) AIM_DPG(AIM_ALGO_NW, true, 16);
+        else if (bt) AIM_DPG(AIM_ALGO_NW, true, 20);
         else if (kp == 16) AIM_DPG(AIM_ALGO_NW, false, 16);
         else if (kp == 20) AIM_DPG(AIM_ALGO_NW, false, 20);
         else AIM_DPG(AIM_ALGO_NW, false, 24);

@@ -101,7 +101,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1544))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1280))) == b"dp_group_kernel"                     # ... / 1280 (SWG)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1288))) == b"dp_strip_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032, backtrace=True))) == b"dp_strip_kernel"       # ... with CIGAR READ_SIZE 1025 .. 1439 stay on the strips,
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032, backtrace=True))) == b"dp_group_kernel"       # ... with CIGAR NW to READ_SIZE 1280 (20 registers per lane, 16-byte lane words),
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1288, backtrace=True))) == b"dp_strip_kernel"       #     READ_SIZE 1281 .. 1439 (SWG: 1025 .. 1439) stay on the strips,
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1032, backtrace=True))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1440, backtrace=True))) == b"dp_group_kernel"       #     1440 .. 2048 are one pair of 45 .. 64 lanes per wavefront
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 2048, backtrace=True))) == b"dp_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 2056, backtrace=True))) == b"dp_strip_kernel"
@@ -168,11 +170,20 @@ def test_dp_group_plan_scratch_and_lds(built):
     lib = capi.load()
     env = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("AIM_") and k != "AIM_LIB"}
     try:
-        for rs in (192, 336, 736, 1024):
-            G = (rs + 31) // 32
-            P = 64 // G
+        def shape(rs, bt):   # dp_group_kp (round 6): the registers per lane (16 / 20 / 24; NW with CIGAR 16 / 20) with the most pairs x resident wavefronts per register
             slot = 2 * ((rs + 79) & ~15) + 4 * ((rs + 47) & ~7) + 16
+            best = None
+            for kp in range(16, (20 if bt else 24) + 1, 4):
+                g = (rs + 2 * kp - 1) // (2 * kp)
+                p = 64 // g
+                lds = ((p * slot + 15) & ~15) + (64 * 3 * 16 if bt else 0) + 64
+                waves = min(8, max(1, 160 * 1024 // ((lds + 1279) // 1280 * 1280)))
+                if best is None or p * waves * best[0] > best[1] * kp:
+                    best = (kp, p * waves, g, p)
+            return best[0], best[2], best[3], slot
+        for rs in (192, 336, 736, 1024):
             for bt in (False, True):
+                kp, G, P, slot = shape(rs, bt)
                 p = engine.make_params("nw", 40, rs, backtrace=bt)
                 buf = C.create_string_buffer(1024)
                 assert lib.aim_plan_describe(C.byref(p), 1 << 16, buf, 1024) == 0
@@ -182,7 +193,8 @@ def test_dp_group_plan_scratch_and_lds(built):
                 assert lds == ((P * slot + 15) & ~15) + (64 * 3 * 16 if bt else 0) + 64, (rs, bt, lds)
                 assert grid == min(2048, ((((1 << 16) + P - 1) // P + 7) // 8) * 8)
                 total = lib.aim_scratch_bytes(C.byref(p), 1 << 16)
-                slab = (((rs + 3) * G * 8 + (rs + 3) + 64) + 255) & ~255      # (NW: 8-byte lane words since round 6 -- eight registers per dword; SWG: 16)
+                Gbt = shape(rs, True)[1]
+                slab = (((rs + 3) * Gbt * (8 if shape(rs, True)[0] == 16 else 16) + (rs + 3) + 64) + 255) & ~255      # (NW: 8-byte lane words at 32 columns since round 6 -- eight registers per dword --, 16 at 40; SWG: 16)
                 todo = ((16 + (1 << 16)) * 4 + 255) & ~255
                 assert total >= (grid * P * slab if bt else 0) + todo and total < (1 << 33), (rs, bt, total)
     finally:

@@ -414,7 +414,8 @@ def _dp_kernel_name(env, params):
     from aim_amd import capi
     int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
     bt = bool(params.flags & capi.FLAG_BACKTRACE)
-    rs_ok = 177 <= params.read_size <= 1024 or (1440 <= params.read_size <= 2048 if bt else params.read_size <= (1536 if params.algo == capi.ALGO_NW else 1280))
+    nw = params.algo == capi.ALGO_NW
+    rs_ok = 177 <= params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= 2048 if bt else params.read_size <= (1536 if nw else 1280))
     if not env and not int8 and rs_ok:
         return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave); round 6: dp_group_rs_ok's ranges
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
@@ -1576,7 +1577,8 @@ def test_long_pattern_tails_wrap_the_flat_table_more_than_once(gpu, algo, l, n):
     """Round 6: plen > 2 tlen -- the last row's tail cells v = W .. plen reach back W cells into the tail itself (flat index W tlen + v - W), and
     the walk passes canonical rows beyond tlen + 1. dp_strip_kernel computes them in its tail loop (they join the row's LDS image; their direction bits sit at row
     tlen + v / W, column v mod W) instead of handing the pair to one lane and a pooled table. Texts cut to a third, a fifth, a fiftieth of the pattern and to one
-    character, next to ordinary pairs; READ_SIZE 1064 / 2576 reach dp_strip directly, READ_SIZE 424 through dp_group's to-do list. Scores and CIGARs against the oracle."""
+    character, next to ordinary pairs; READ_SIZE 2576 and SWG with CIGAR at READ_SIZE 1040 reach dp_strip_kernel, READ_SIZE 416 and the other READ_SIZE-1040 shapes
+    dp_group_kernel, whose tail walk is the same code. Scores and CIGARs against the oracle."""
     from aim_amd import engine
     ms, rs = engine.launcher_sizes(algo, l, 0.03)
     req, pat, txt = engine.gen_pairs(6600 + l, 0, n, l, 0.03, rs)
@@ -1650,7 +1652,7 @@ def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
     the last row's tail cells incl. plen > 2 tlen (round 6); nw.c:109-153, swg.c:121-171 over the flat table) --, the pairs it leaves to its to-do list (empty
     sequences) through both fallbacks (nw_lane / swg_lane up to READ_SIZE 320, dp_strip in to-do mode above), non-ACGT bytes, other costs (NW: GAP_I != GAP_D),
     and equality with the kernels it replaced (AIM_NO_DP_GROUP=1). Round 6: score-only READ_SIZE 1025 .. 1536 (20 / 24 registers per lane, two pairs per
-    wavefront), with CIGAR READ_SIZE 1440 .. 2048 (one pair of 45 .. 64 lanes per wavefront); the shapes in between stay on dp_strip_kernel."""
+    wavefront), with CIGAR NW to READ_SIZE 1280 (20 registers) and READ_SIZE 1440 .. 2048 (one pair of 45 .. 64 lanes per wavefront); the shapes in between stay on dp_strip_kernel."""
     from aim_amd import engine
     ms, rs = engine.launcher_sizes(algo, l, err)
     n = 1500 if l <= 400 else (400 if l <= 1000 else 150)
@@ -1675,7 +1677,7 @@ def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
         with engine.DeviceSet(1) as s:
             s.configure(params, n)
             s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
-            group = rs <= 1024 or (1440 <= rs <= 2048 if bt else rs <= (1536 if algo == "nw" else 1280))
+            group = rs <= 1024 or ((algo == "nw" and rs <= 1280) or 1440 <= rs <= 2048 if bt else rs <= (1536 if algo == "nw" else 1280))
             if not group:
                 assert s.plan_describe(0).startswith("dp_strip_kernel"), s.plan_describe(0)
                 continue
