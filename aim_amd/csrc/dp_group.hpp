@@ -35,7 +35,7 @@ constexpr int kDpgMinRs = 177;
 __host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
 __host__ __device__ inline int dp_group_kp(int read_size, bool bt, bool swg)
 {
-    const int kmax = bt ? (swg ? 16 : 20) : (swg ? 20 : 24);
+    const int kmax = bt ? (swg ? 16 : 20) : (swg ? 20 : 28);
     int best = 16;
     long best_num = 0, best_den = 1;
     for (int kp = 16; kp <= kmax; kp += 4) {
@@ -54,7 +54,7 @@ __host__ __device__ inline int dp_group_kp(int read_size, bool bt, bool swg)
 __host__ __device__ inline bool dp_group_rs_ok(int read_size, bool bt, bool swg)
 {
     if (read_size < kDpgMinRs) return false;
-    if (!bt) return read_size <= (swg ? 1280 : 1536);         // (SWG with 24 registers per lane spills inside the row: dp_strip_kernel)
+    if (!bt) return read_size <= (swg ? 1280 : 1792);         // (two pairs of <= 32 lanes at 20 / 24 / 28 registers; SWG with 24 registers per lane spills inside the row: dp_strip_kernel)
     return read_size <= 1024 || (!swg && read_size <= 1280) || (read_size >= 1440 && read_size <= 2048);
 }
 
@@ -466,7 +466,8 @@ void dp_group_launch(const aim_params_t &p, uint32_t grid, size_t lds, const KAr
         else if (bt) AIM_DPG(AIM_ALGO_NW, true, 20);
         else if (kp == 16) AIM_DPG(AIM_ALGO_NW, false, 16);
         else if (kp == 20) AIM_DPG(AIM_ALGO_NW, false, 20);
-        else AIM_DPG(AIM_ALGO_NW, false, 24);
+        else if (kp == 24) AIM_DPG(AIM_ALGO_NW, false, 24);
+        else AIM_DPG(AIM_ALGO_NW, false, 28);
     } else {
         if (bt) AIM_DPG(AIM_ALGO_SWG, true, 16);
         else if (kp == 16) AIM_DPG(AIM_ALGO_SWG, false, 16);

@@ -96,9 +96,9 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 160, backtrace=True))) == b"nw_reg_kernel"         # (l = 150: the pattern row in LDS, 12 dwords of direction bits)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184))) == b"dp_group_kernel"                         # round 5: medium reads, G lanes per pair (READ_SIZE 177 .. 1024)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1024, backtrace=True))) == b"dp_group_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032))) == b"dp_group_kernel"                       # round 6: score-only to READ_SIZE 1536 (NW; 20 / 24 registers per lane) ...
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1536))) == b"dp_group_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1544))) == b"dp_strip_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032))) == b"dp_group_kernel"                       # round 6: score-only to READ_SIZE 1792 (NW; 20 / 24 / 28 registers per lane) ...
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1792))) == b"dp_group_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1800))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1280))) == b"dp_group_kernel"                     # ... / 1280 (SWG)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1288))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032, backtrace=True))) == b"dp_group_kernel"       # ... with CIGAR NW to READ_SIZE 1280 (20 registers per lane, 16-byte lane words),
@@ -170,10 +170,10 @@ def test_dp_group_plan_scratch_and_lds(built):
     lib = capi.load()
     env = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith("AIM_") and k != "AIM_LIB"}
     try:
-        def shape(rs, bt):   # dp_group_kp (round 6): the registers per lane (16 / 20 / 24; NW with CIGAR 16 / 20) with the most pairs x resident wavefronts per register
+        def shape(rs, bt):   # dp_group_kp (round 6): the registers per lane (NW: 16 / 20 / 24 / 28; with CIGAR 16 / 20) with the most pairs x resident wavefronts per register
             slot = 2 * ((rs + 79) & ~15) + 4 * ((rs + 47) & ~7) + 16
             best = None
-            for kp in range(16, (20 if bt else 24) + 1, 4):
+            for kp in range(16, (20 if bt else 28) + 1, 4):
                 g = (rs + 2 * kp - 1) // (2 * kp)
                 p = 64 // g
                 lds = ((p * slot + 15) & ~15) + (64 * 3 * 16 if bt else 0) + 64

@@ -156,7 +156,7 @@ def main():
             # its two fallbacks (dp_lane kernels up to READ_SIZE 320, dp_strip in to-do mode above), penalties on both sides of dp_strip_exact_ok()
             algo = rng.choice(["nw", "swg"])
             rs = rng.choice([176, 184, 192, 200, 224, 256, 264, 288, 320, 328, 336, 384, 416, 512, 520, 640, 728, 736, 992, 1000, 1024, 1032,
-                             1040, 1232, 1280, 1288, 1432, 1440, 1488, 1536, 1544, 2000, 2048, 2056])   # (round 6: dp_group_rs_ok's ranges and their neighbours)
+                             1040, 1232, 1280, 1288, 1432, 1440, 1488, 1536, 1544, 1736, 1792, 1800, 2000, 2048, 2056])   # (round 6: dp_group_rs_ok's ranges and their neighbours)
             l = rng.randint(max(1, rs - rs // 3), rs - 8)
             e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15])
             if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0

@@ -9,7 +9,7 @@ out = open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/length_sweep.txt", 
 import io, contextlib
 for algo in ("nw", "swg"):
     for bt in (False, True):
-        for l in (150, 180, 200, 250, 300, 320, 400, 500, 700, 1000, 1200, 1450, 1500, 2000):
+        for l in (150, 180, 200, 250, 300, 320, 400, 500, 700, 1000, 1200, 1450, 1500, 1700, 2000):
             n = max(1024, int(2.5e10 / (l * l) / (4 if bt else 1)) // 1024 * 1024)
             n = min(n, 1 << 20)
             kw = dict(backtrace=True) if bt else {}
