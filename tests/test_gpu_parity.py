@@ -415,7 +415,7 @@ def _dp_kernel_name(env, params):
     int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
     bt = bool(params.flags & capi.FLAG_BACKTRACE)
     nw = params.algo == capi.ALGO_NW
-    rs_ok = 177 <= params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= 2048 if bt else params.read_size <= (1792 if nw else 1280))
+    rs_ok = params.read_size >= 177 and (params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= 2048 if bt else params.read_size <= (1792 if nw else 1280)))
     if not env and not int8 and rs_ok:
         return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave); round 6: dp_group_rs_ok's ranges
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
@@ -715,7 +715,7 @@ def test_dp_wave_every_wavefront_count_agrees_with_oracle(gpu, monkeypatch):
     for algo, l, e in (("nw", 1000, 0.05), ("swg", 1000, 0.05), ("nw", 2500, 0.02)):
         ms, rs = engine.launcher_sizes(algo, l, e)
         params = engine.make_params(algo, ms, rs, backtrace=True)
-        assert lib.aim_kernel_name(C.byref(params)) == b"dp_strip_kernel"
+        assert lib.aim_kernel_name(C.byref(params)) == (b"dp_group_kernel" if (algo, l) == ("nw", 1000) else b"dp_strip_kernel")   # (round 6: NW with CIGAR at READ_SIZE <= 1280 is dp_group_kernel's; AIM_DPW_NW below asks for the strips)
         req, pat, txt = engine.gen_pairs(4321 + l, 0, 96, l, e, rs)
         d = req["pattern_len"].astype(int) - req["text_len"].astype(int)
         assert (d > 0).any() and (d < 0).any()

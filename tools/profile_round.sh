@@ -52,10 +52,10 @@ python3 tools/pmc_summary.py --out $P/nw_reg_e5_pmc_summary.json --kernel nw_reg
    --note "NW l=100 e=5% score-only, 1 Mi pairs: the last row's tail cells in the kernel (round 5: no to-do pass)." \
    -- python3 tools/bench_configs.py nw_l100_e5_score > $O/pmc_nwreg5.log 2>&1; tail -1 $O/pmc_nwreg5.log
 python3 tools/pmc_summary.py --out $P/dp_group_pmc_summary.json --kernel dp_group_kernel --pairs 399360 \
-   --note "NW l=250 e=2% score-only, 399 360 pairs: dp_group_kernel (9 lanes per pair, 7 pairs per wavefront, 32 cells per lane in registers)." \
+   --note "NW l=250 e=2% score-only, 399 360 pairs: dp_group_kernel (round 6: 20 registers = 40 cells per lane, 7 lanes per pair, 9 pairs per wavefront: the shape with the most pairs x resident wavefronts per register)." \
    -- python3 tools/bench_configs.py nw_l250_e2_score > $O/pmc_dpg.log 2>&1; tail -1 $O/pmc_dpg.log
 python3 tools/pmc_summary.py --out $P/dp_group_swg_cigar_pmc_summary.json --kernel dp_group_kernel --pairs 99328 \
-   --note "SWG (int16 cells) l=250 e=2% with CIGAR, 99 328 pairs: dp_group_kernel, four direction bits per cell + the wavefront's walks." \
+   --note "SWG (int16 cells) l=250 e=2% with CIGAR, 99 328 pairs: dp_group_kernel (16 registers per lane: 9 lanes per pair, 7 pairs per wavefront), four direction bits per cell + the wavefront's walks (the walker prefetches its next window)." \
    -- python3 tools/bench_configs.py swg_l250_e2_w16_cigar > $O/pmc_dpgc.log 2>&1; tail -1 $O/pmc_dpgc.log
 python3 tools/pmc_summary.py --out $P/dp_group_kp20_pmc_summary.json --kernel dp_group_kernel --pairs 16384 \
    --note "NW l=1200 e=2% score-only, 16 384 pairs: dp_group_kernel with 20 registers (40 columns) per lane, 31 lanes per pair, two pairs per wavefront (round 6; dp_strip_kernel, one wavefront per pair, before)." \
