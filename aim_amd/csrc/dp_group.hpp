@@ -28,14 +28,15 @@ constexpr int kDpgMinRs = 177;
 // Registers per lane and row (KP; 2 KP columns per lane): 16, 20 or 24. A wavefront holds P = floor(64 / G) pairs of G = ceil(READ_SIZE / 2 KP) lanes and a row costs ~KP, so the
 // cells per unit of time go as P / KP: READ_SIZE 728 is two pairs of 23 lanes at 16 registers (46 of 64 lanes), three of 19 at 20, FOUR of 16 at 24 -- the dips of round 5's
 // length sweep at l = 320 / 700 were idle lanes. The shape with the largest P / KP among those the configuration has registers for: NW score-only 16 / 20 / 24 (156 / 184 / 213
-// VGPRs), SWG score-only and NW with CIGAR 16 / 20 (SWG spills inside the row at 24; with CIGAR the lane words are 16 bytes for 40 columns of NW, 251 VGPRs), SWG with CIGAR 16.
+// VGPRs; 28: 241), SWG score-only 16 / 20 / 24 (256 VGPRs and twenty spill instructions inside the row at 24 -- still 2 806 GCUPS at l = 1450 against dp_strip's 2 394), NW with CIGAR 16 / 20
+// (the lane words are 16 bytes for 40 columns of NW, 251 VGPRs), SWG with CIGAR 16.
 // (... times the wavefronts per CU the pairs' LDS slots leave, up to the eight the registers admit: READ_SIZE 192 as sixteen pairs of four lanes is 23 KB per wavefront = six per CU,
 //  and measured 10 % SLOWER than ten pairs of six.)
 // LDS of one pair slot: pattern | text | the last row's M, I (int16) | 16 B {M, D of cell W - 1, M of the cell above it}
 __host__ __device__ inline int dp_group_slot_bytes(int rs) { return 2 * ((rs + 79) & ~15) + 2 * 2 * ((rs + 47) & ~7) + 16; }
 __host__ __device__ inline int dp_group_kp(int read_size, bool bt, bool swg)
 {
-    const int kmax = bt ? (swg ? 16 : 20) : (swg ? 20 : 28);
+    const int kmax = bt ? (swg ? 16 : 20) : (swg ? 24 : 28);
     int best = 16;
     long best_num = 0, best_den = 1;
     for (int kp = 16; kp <= kmax; kp += 4) {
@@ -54,7 +55,7 @@ __host__ __device__ inline int dp_group_kp(int read_size, bool bt, bool swg)
 __host__ __device__ inline bool dp_group_rs_ok(int read_size, bool bt, bool swg)
 {
     if (read_size < kDpgMinRs) return false;
-    if (!bt) return read_size <= (swg ? 1280 : 1792);         // (two pairs of <= 32 lanes at 20 / 24 / 28 registers; SWG with 24 registers per lane spills inside the row: dp_strip_kernel)
+    if (!bt) return read_size <= (swg ? 1536 : 1792);         // (two pairs of <= 32 lanes at 20 / 24 / 28 registers; SWG stops at 24)
     return read_size <= 1024 || (!swg && read_size <= 1280) || (read_size >= 1440 && read_size <= 2048);
 }
 

@@ -99,8 +99,8 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032))) == b"dp_group_kernel"                       # round 6: score-only to READ_SIZE 1792 (NW; 20 / 24 / 28 registers per lane) ...
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1792))) == b"dp_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1800))) == b"dp_strip_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1280))) == b"dp_group_kernel"                     # ... / 1280 (SWG)
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1288))) == b"dp_strip_kernel"
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1536))) == b"dp_group_kernel"                     # ... / 1536 (SWG: 16 / 20 / 24 registers)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1544))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1032, backtrace=True))) == b"dp_group_kernel"       # ... with CIGAR NW to READ_SIZE 1280 (20 registers per lane, 16-byte lane words),
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 40, 1288, backtrace=True))) == b"dp_strip_kernel"       #     READ_SIZE 1281 .. 1439 (SWG: 1025 .. 1439) stay on the strips,
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 1032, backtrace=True))) == b"dp_strip_kernel"

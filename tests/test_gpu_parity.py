@@ -415,7 +415,7 @@ def _dp_kernel_name(env, params):
     int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
     bt = bool(params.flags & capi.FLAG_BACKTRACE)
     nw = params.algo == capi.ALGO_NW
-    rs_ok = params.read_size >= 177 and (params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= 2048 if bt else params.read_size <= (1792 if nw else 1280)))
+    rs_ok = params.read_size >= 177 and (params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= 2048 if bt else params.read_size <= (1792 if nw else 1536)))
     if not env and not int8 and rs_ok:
         return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave); round 6: dp_group_rs_ok's ranges
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
@@ -1651,7 +1651,7 @@ def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
     (pair rank, value) keys) against the oracle: every length relation -- plen < / == / > tlen incl. long tails (the aliased boundary cell of every row,
     the last row's tail cells incl. plen > 2 tlen (round 6); nw.c:109-153, swg.c:121-171 over the flat table) --, the pairs it leaves to its to-do list (empty
     sequences) through both fallbacks (nw_lane / swg_lane up to READ_SIZE 320, dp_strip in to-do mode above), non-ACGT bytes, other costs (NW: GAP_I != GAP_D),
-    and equality with the kernels it replaced (AIM_NO_DP_GROUP=1). Round 6: score-only READ_SIZE 1025 .. 1792 (NW; SWG .. 1280: 20 / 24 / 28 registers per lane, two pairs per
+    and equality with the kernels it replaced (AIM_NO_DP_GROUP=1). Round 6: score-only READ_SIZE 1025 .. 1792 (NW; SWG .. 1536: 20 / 24 / 28 registers per lane, two pairs per
     wavefront; the registers per lane follow lane use x residency at every READ_SIZE), with CIGAR NW to READ_SIZE 1280 (20 registers) and READ_SIZE 1440 .. 2048 (one pair of 45 .. 64 lanes per wavefront); the shapes in between stay on dp_strip_kernel."""
     from aim_amd import engine
     ms, rs = engine.launcher_sizes(algo, l, err)
@@ -1677,7 +1677,7 @@ def test_dp_group_kernel_medium_reads(gpu, monkeypatch, algo, bt, l, err):
         with engine.DeviceSet(1) as s:
             s.configure(params, n)
             s.push(0, req, pat, txt); s.launch(); s.pull(0, check=False)
-            group = rs <= 1024 or ((algo == "nw" and rs <= 1280) or 1440 <= rs <= 2048 if bt else rs <= (1792 if algo == "nw" else 1280))
+            group = rs <= 1024 or ((algo == "nw" and rs <= 1280) or 1440 <= rs <= 2048 if bt else rs <= (1792 if algo == "nw" else 1536))
             if not group:
                 assert s.plan_describe(0).startswith("dp_strip_kernel"), s.plan_describe(0)
                 continue
