@@ -56,7 +56,7 @@ __host__ __device__ inline bool dp_group_rs_ok(int read_size, bool bt, bool swg)
 {
     if (read_size < kDpgMinRs) return false;
     if (!bt) return read_size <= (swg ? 1536 : 1792);         // (two pairs of <= 32 lanes at 20 / 24 / 28 registers; SWG stops at 24)
-    return read_size <= 1024 || (!swg && read_size <= 1280) || (read_size >= 1440 && read_size <= 2048);
+    return read_size <= 1024 || (!swg && read_size <= 1280) || (read_size >= 1440 && read_size <= (swg ? 2048 : 2560));   // (NW at 20 registers: 40 columns per lane)
 }
 
 __host__ __device__ inline int dp_group_lanes(int read_size, bool bt, bool swg) { const int k = 2 * dp_group_kp(read_size, bt, swg); return (read_size + k - 1) / k; }   // G: lanes per pair (6 .. 64)

@@ -689,14 +689,21 @@ inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *s
 {
     const int rs = p.read_size;
     int best_k = 0, best_nw = 0;
-    long best_cost = 0;
+    double best_cost = 0;
     for (int k : {16, 20, 24, 32}) {
         if (kn.strip_k > 0 && kn.strip_k != k) continue;
         const int nw = (rs + kWave * k - 1) / (kWave * k);
         if (nw > (k == 16 ? 12 : 8)) continue;
-        // few pairs (about one per CU, config 4): the busiest SIMD's wavefronts set the time; many pairs: the total work does
-        long cost = (n_pairs > 4u * kn.cus ? (long)nw : (long)((nw + 3) / 4)) * (110 + 10L * k);
-        if (k >= 24 && p.algo == AIM_ALGO_SWG && (p.flags & AIM_FLAG_BACKTRACE)) cost += cost / 4;   // (round 5: with the direction bits these instantiations spill 15 - 51 registers)
+        // The busiest SIMD's wavefronts set a row's time: pe resident pairs of nw wavefronts put ceil(pe nw / 4) on it, and pe pairs leave per such time -- pe is what the
+        // registers admit (dp_strip_plan: 16 wavefronts per CU at K = 16, 12 for SWG with CIGAR, 8 from K = 20 on), or the pairs per CU the batch has (config 4: one).
+        // Until round 6 the rule knew "few" (<= four pairs per CU: ceil(nw / 4)) and "many" (nw), and added a quarter to K >= 24 for SWG with CIGAR (its spills): 1 024 pairs
+        // at READ_SIZE 2 049 .. 4 096 took three or four wavefronts of 16 cells per lane where two of 20 / 24 / 32 run 1.5 - 2.5x faster (profiles/r06/strip_shape_sweep.txt;
+        // SWG with CIGAR at READ_SIZE 2 952: 1 304 GCUPS at K = 24 x 2 against 518 at 16 x 3).
+        const bool heavy = p.algo == AIM_ALGO_SWG && (p.flags & AIM_FLAG_BACKTRACE);
+        const long cus = kn.cus > 0 ? (long)kn.cus : 256L;
+        const long per_cu = std::max<long>(1, (k >= 20 ? 8 : (heavy ? 12 : 16)) / nw);
+        const long pe = n_pairs == 0 ? per_cu : std::min<long>(per_cu, std::max<long>(1, ((long)n_pairs + cus - 1) / cus));
+        const double cost = (double)((pe * nw + 3) / 4) * (110 + 10.0 * k) / (double)pe;
         if (!best_k || cost < best_cost) { best_k = k; best_nw = nw; best_cost = cost; }
     }
     if (!best_k) return false;

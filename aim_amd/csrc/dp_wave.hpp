@@ -62,7 +62,18 @@ __host__ __device__ inline bool dp_wave_exact_ok(const aim_params_t &p, bool swg
     const long rs = p.read_size;
     if (p.algo == AIM_ALGO_NW) {
         const long g = p.gap_i > p.gap_d ? p.gap_i : p.gap_d;
-        return (2 * rs + 4) * g + 2 * p.mismatch < 32000;
+        if (p.gap_i < 0 || p.gap_d < 0 || p.mismatch < 0) return (2 * rs + 4) * g + 2 * p.mismatch < 32000 && g >= 0 && p.mismatch >= 0;
+        // Round 6. With costs >= 0 every stored cell is a minimum of (neighbour + cost) and so at most the cost of ANY path of the recurrence's own moves that ends in it:
+        //   * a regular cell (h, v), v >= 1: diagonal steps from (0, 0) = 0 to (m, m), m = min(h, v), then |h - v| gap steps along row h / column v -- all of them cells of
+        //     columns >= 1 that hold their own row's values when they are read (the flat table's aliasing only ever replaces column 0 and cells of LATER rows):
+        //     <= m min(x, gi + gd) + |h - v| g <= READ_SIZE * M, M = max(min(x, gi + gd), gi, gd);
+        //   * the aliased boundary cell B(h + 1) = tail cell (h, W) <= cell (h, W - 1) + gd; a tail cell (h, v >= W) <= its "up" (h, v - W) + gi, so by induction
+        //     <= cell (h, v mod W) + floor(v / W) gi <= tlen M + (READ_SIZE / (tlen + 1)) g <= READ_SIZE * M + g;
+        // and the reference's int16 casts of the three candidates see at most that + max(x, g). (Until round 6 the bound was the gap-only path, (2 READ_SIZE + 4) g: at the
+        // launchers' costs every NW pair from READ_SIZE 3 998 on took the literal one-lane path -- 4 GCUPS, tools/strip_shape_sweep.py -- where nothing can wrap before 7 990.)
+        const long x2 = p.mismatch < p.gap_i + p.gap_d ? p.mismatch : p.gap_i + p.gap_d;
+        const long m = x2 > g ? x2 : g;
+        return (rs + 4) * m + 2L * p.mismatch + 2 * g < 32000;
     }
     const long hi = 3L * p.gap_o + (2 * rs + 4) * p.gap_e + 2L * p.mismatch + (p.max_score > 0 ? p.max_score : 0);
     const long lo = (long)p.match * rs;   // match <= 0

@@ -110,7 +110,10 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 336, backtrace=True))) == b"dp_group_kernel"      # (int16 cells by MAX_SCORE)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336, swg_w16=True))) == b"dp_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_strip_kernel" or lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_wave_kernel"   # (int8 cells wrap by design: the literal kernels)
-    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184, gap=90))) == b"nw_lane_kernel"                  # (dp_strip_exact_ok: an int16 store could wrap)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184, gap=180))) == b"nw_lane_kernel"                 # (dp_strip_exact_ok: an int16 store could wrap)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184, gap=90))) == b"dp_group_kernel"                 # (round 6: READ_SIZE x gap bounds a cell, not twice that)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 300, 7904))) == b"dp_strip_kernel"                      # (until round 6 the literal one-lane path from READ_SIZE 3 998 on)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 300, 8000))) == b"dp_wave_kernel"                       # (cells of unrelated sequences can wrap: literal)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 4, 112))) == b"swg_reg_kernel"                          # round 5: M and I rows in registers up to READ_SIZE 128
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 112, backtrace=True))) == b"swg_reg_kernel"       # (int16 cells too)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 160, swg_w16=True))) == b"swg_reg_kernel"            # (l = 150, int16 cells: the pattern row in LDS, M and I in 154 registers)
@@ -281,7 +284,13 @@ def test_round4_plan_shapes(built):
         l = plan(engine.make_params("swg", 250, 1064, backtrace=True), 65536)
         assert "cells_per_lane=20" in l and "wavefronts_per_pair=1" in l
         l = plan(engine.make_params("swg", 150, 3064, backtrace=True), 1024)
-        assert "cells_per_lane=16" in l and "wavefronts_per_pair=3" in l
+        assert "cells_per_lane=24" in l and "wavefronts_per_pair=2" in l                                      # (round 6: until then 16 x 3 -- 518 against 1 304 GCUPS at READ_SIZE 2 952, profiles/r06/strip_shape_sweep.txt)
+        l = plan(engine.make_params("nw", 400, 2112), 1024)
+        assert "cells_per_lane=20" in l and "wavefronts_per_pair=2" in l
+        l = plan(engine.make_params("nw", 400, 2112, backtrace=True), 1024)
+        assert l.startswith("dp_group_kernel") and "lanes_per_pair=53" in l, l                                # (NW with CIGAR: 40 columns per lane to READ_SIZE 2 560)
+        l = plan(engine.make_params("nw", 700, 3688, backtrace=True), 4096)
+        assert "cells_per_lane=32" in l and "wavefronts_per_pair=2" in l
         for rs, n, grid in ((110008, 4096, 4096), (110008, 1 << 20, 24 * 256), (120, 1 << 18, 24 * 256)):
             l = plan(engine.make_params("genasm", 0, rs, backtrace=True), n)
             assert l.startswith("genasm_wave_kernel") and "grid=%d " % grid in l and "lds=4160" in l, l

@@ -415,7 +415,7 @@ def _dp_kernel_name(env, params):
     int8 = params.algo == capi.ALGO_SWG and params.max_score < 127 and not (params.flags & capi.FLAG_SWG_W16)
     bt = bool(params.flags & capi.FLAG_BACKTRACE)
     nw = params.algo == capi.ALGO_NW
-    rs_ok = params.read_size >= 177 and (params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= 2048 if bt else params.read_size <= (1792 if nw else 1536)))
+    rs_ok = params.read_size >= 177 and (params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= (2560 if nw else 2048) if bt else params.read_size <= (1792 if nw else 1536)))
     if not env and not int8 and rs_ok:
         return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave); round 6: dp_group_rs_ok's ranges
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
@@ -715,7 +715,7 @@ def test_dp_wave_every_wavefront_count_agrees_with_oracle(gpu, monkeypatch):
     for algo, l, e in (("nw", 1000, 0.05), ("swg", 1000, 0.05), ("nw", 2500, 0.02)):
         ms, rs = engine.launcher_sizes(algo, l, e)
         params = engine.make_params(algo, ms, rs, backtrace=True)
-        assert lib.aim_kernel_name(C.byref(params)) == (b"dp_group_kernel" if (algo, l) == ("nw", 1000) else b"dp_strip_kernel")   # (round 6: NW with CIGAR at READ_SIZE <= 1280 is dp_group_kernel's; AIM_DPW_NW below asks for the strips)
+        assert lib.aim_kernel_name(C.byref(params)) == (b"dp_group_kernel" if algo == "nw" else b"dp_strip_kernel")   # (round 6: NW with CIGAR at READ_SIZE <= 1280 and 1440 .. 2560 is dp_group_kernel's; AIM_DPW_NW below asks for the strips)
         req, pat, txt = engine.gen_pairs(4321 + l, 0, 96, l, e, rs)
         d = req["pattern_len"].astype(int) - req["text_len"].astype(int)
         assert (d > 0).any() and (d < 0).any()
@@ -1592,6 +1592,37 @@ def test_long_pattern_tails_wrap_the_flat_table_more_than_once(gpu, algo, l, n):
         _compare(algo, params, req, pat, txt)
     params = engine.make_params(algo, ms, rs, backtrace=True, mismatch=2, **(dict(gap_i=5, gap_d=1) if algo == "nw" else dict(gap_o=1, gap_e=2, swg_w16=True)))
     _compare(algo, params, req, pat, txt)
+
+
+@pytest.mark.parametrize("rs,l,costs", [(7904, 7800, {}), (4560, 4500, dict(mismatch=7, gap_i=5, gap_d=3)), (4096, 4000, {})])
+def test_nw_long_reads_below_the_int16_bound_leave_the_literal_path(gpu, rs, l, costs):
+    """Round 6: dp_wave_exact_ok bounded an NW cell by the gap-only path, (2 READ_SIZE + 4) g, and at the launchers' costs sent every pair from READ_SIZE 3 998 on to
+    the literal one-lane path (4 GCUPS). A cell is at most READ_SIZE x max(min(x, gi + gd), gi, gd) + g (dp_wave.hpp), so nothing wraps before READ_SIZE 7 990: these
+    run on dp_strip_kernel now. Pairs chosen to reach the bound -- unrelated sequences, all-mismatch diagonals, one-character and half-length texts (the flat table's
+    aliasing over many rows), a one-character pattern -- next to related ones; READ_SIZE 7 904 is 96 below the first size at which the new bound refuses. Against the
+    oracle's int16 table (oracle/aim_oracle.c nw_pair: every store through the reference's casts)."""
+    import ctypes as C
+    from aim_amd import capi, engine
+    n = 10
+    req, pat, txt = engine.gen_pairs(9100 + rs, 0, n, l, 0.03, rs)
+    rng = np.random.default_rng(rs)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    full = rs - 8
+    def put(i, p, t):
+        pat[i, :] = 0; txt[i, :] = 0
+        pat[i, :len(p)] = p; txt[i, :len(t)] = t
+        req["pattern_len"][i] = len(p); req["text_len"][i] = len(t)
+    put(0, acgt[rng.integers(0, 4, full)], acgt[rng.integers(0, 4, full)])                    # unrelated, full length
+    put(1, np.full(full, ord("A"), np.uint8), np.full(full, ord("C"), np.uint8))              # every diagonal step a mismatch
+    put(2, acgt[rng.integers(0, 4, full)], acgt[rng.integers(0, 4, 1)])                       # W = 2: the pattern's row wraps the flat table thousands of times
+    put(3, acgt[rng.integers(0, 4, 1)], acgt[rng.integers(0, 4, full)])
+    put(4, acgt[rng.integers(0, 4, full)], acgt[rng.integers(0, 4, full // 2)])               # plen = 2 tlen
+    put(5, np.full(full, ord("A"), np.uint8), np.concatenate([np.full(full // 3, ord("A"), np.uint8), np.full(full // 4, ord("G"), np.uint8)]))
+    put(6, np.full(full // 5, ord("T"), np.uint8), np.full(full, ord("G"), np.uint8))         # plen << tlen, nothing matches
+    for bt in (False, True):
+        params = engine.make_params("nw", 4, rs, backtrace=bt, **costs)
+        assert capi.load().aim_kernel_name(C.byref(params)) == b"dp_strip_kernel"
+        _compare("nw", params, req, pat, txt)
 
 
 def test_dp_strip_batches_with_long_pattern_tails_are_stable_launch_to_launch(gpu):

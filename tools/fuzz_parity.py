@@ -156,7 +156,7 @@ def main():
             # its two fallbacks (dp_lane kernels up to READ_SIZE 320, dp_strip in to-do mode above), penalties on both sides of dp_strip_exact_ok()
             algo = rng.choice(["nw", "swg"])
             rs = rng.choice([176, 184, 192, 200, 224, 256, 264, 288, 320, 328, 336, 384, 416, 512, 520, 640, 728, 736, 992, 1000, 1024, 1032,
-                             1040, 1232, 1280, 1288, 1432, 1440, 1488, 1536, 1544, 1736, 1792, 1800, 2000, 2048, 2056])   # (round 6: dp_group_rs_ok's ranges and their neighbours)
+                             1040, 1232, 1280, 1288, 1432, 1440, 1488, 1536, 1544, 1736, 1792, 1800, 2000, 2048, 2056, 2112, 2424, 2560, 2568])   # (round 6: dp_group_rs_ok's ranges and their neighbours)
             l = rng.randint(max(1, rs - rs // 3), rs - 8)
             e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15])
             if l + int(np.ceil(l * e)) + 1 > rs: e = 0.0
@@ -303,7 +303,7 @@ def main():
                 return 1
             continue
         algo = "wfa" if a.focus == "wfa" else (rng.choice(["nw", "swg"]) if a.focus == "dp" else rng.choice(["wfa", "wfa", "wfa", "nw", "swg"]))
-        l = rng.choice([330, 400, 700, 1000, 1500, 2500, 3500, 5000]) if a.focus == "dp" else rng.choice([3, 8, 20, 33, 64, 100, 100, 150, 250, 300, 400, 700, 1000, 1500, 2500, 3500])
+        l = rng.choice([330, 400, 700, 1000, 1500, 2500, 2800, 3500, 5000, 6000, 7500]) if a.focus == "dp" else rng.choice([3, 8, 20, 33, 64, 100, 100, 150, 250, 300, 400, 700, 1000, 1500, 2500, 3500])
         e = rng.choice([0.0, 0.01, 0.02, 0.05, 0.10, 0.15, 0.25])
         cost = {}
         if rng.random() < 0.5:
