@@ -1604,7 +1604,7 @@ def test_nw_long_reads_below_the_int16_bound_leave_the_literal_path(gpu, rs, l, 
     import ctypes as C
     from aim_amd import capi, engine
     n = 10
-    req, pat, txt = engine.gen_pairs(9100 + rs, 0, n, l, 0.03, rs)
+    req, pat, txt = engine.gen_pairs(9100 + rs, 0, n, l, 0.01, rs)
     rng = np.random.default_rng(rs)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     full = rs - 8

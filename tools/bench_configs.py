@@ -62,6 +62,11 @@ CONFIGS = {
     "nw_l1200_e2_score": dict(algo="nw", l=1200, e=0.02, n=16384, kw=dict()),
     "swg_l2000_e2_w16_cigar": dict(algo="swg", l=2000, e=0.02, n=1024, kw=dict(backtrace=True, swg_w16=True)),
     "nw_l2000_e2_cigar": dict(algo="nw", l=2000, e=0.02, n=1024, kw=dict(backtrace=True)),
+    # round 6: beyond READ_SIZE 2048 (two-wavefront strips of 20 / 24 / 32 cells per lane), and NW long reads below the int16 bound (READ_SIZE < 7 990: dp_strip, not the literal path)
+    "nw_l2800_e5_cigar": dict(algo="nw", l=2800, e=0.05, n=1024, kw=dict(backtrace=True)),
+    "swg_l2800_e5_w16_cigar": dict(algo="swg", l=2800, e=0.05, n=1024, kw=dict(backtrace=True, swg_w16=True)),
+    "nw_l5000_e5_score": dict(algo="nw", l=5000, e=0.05, n=1024, kw=dict()),
+    "nw_l5000_e5_cigar": dict(algo="nw", l=5000, e=0.05, n=1024, kw=dict(backtrace=True)),
     "swg_l500_e5_w16_cigar": dict(algo="swg", l=500, e=0.05, n=24576, kw=dict(backtrace=True, swg_w16=True)),   # (MAX_SCORE 125: int8 cells wrap by design here, S3 -- a pair then stops with AIM_PAIR_SWG_NO_OP)
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
