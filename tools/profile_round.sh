@@ -63,6 +63,9 @@ python3 tools/pmc_summary.py --out $P/dp_group_kp20_pmc_summary.json --kernel dp
 python3 tools/pmc_summary.py --out $P/dp_group_l2000_cigar_pmc_summary.json --kernel dp_group_kernel --pairs 1024 \
    --note "SWG (int16 cells) l=2000 e=2% with CIGAR, 1 024 pairs: dp_group_kernel with ONE pair of 64 lanes per wavefront (round 6; dp_strip_kernel's two-wavefront strips before: 727 GCUPS)." \
    -- python3 tools/bench_configs.py swg_l2000_e2_w16_cigar > $O/pmc_dpg2000.log 2>&1; tail -1 $O/pmc_dpg2000.log
+python3 tools/pmc_summary.py --out $P/dp_strip_nw_l5000_pmc_summary.json --kernel dp_strip_kernel --pairs 1024 \
+   --note "NW l=5000 e=5% score-only (READ_SIZE 5264), 1 024 pairs: dp_strip_kernel, four wavefronts of 24 cells per lane per pair (round 6: until then the literal one-lane path behind an int16 bound that was loose by 2x: 4 GCUPS; NOTES R6.7)." \
+   -- python3 tools/bench_configs.py nw_l5000_e5_score > $O/pmc_strip5000.log 2>&1; tail -1 $O/pmc_strip5000.log
 python3 tools/length_sweep.py $P/length_sweep.txt > $O/length_sweep.log 2>&1
 python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
 python3 -c "
