@@ -703,7 +703,10 @@ inline bool dp_strip_shape(const aim_params_t &p, const Knobs &kn, StripShape *s
         const long cus = kn.cus > 0 ? (long)kn.cus : 256L;
         const long per_cu = std::max<long>(1, (k >= 20 ? 8 : (heavy ? 12 : 16)) / nw);
         const long pe = n_pairs == 0 ? per_cu : std::min<long>(per_cu, std::max<long>(1, ((long)n_pairs + cus - 1) / cus));
-        const double cost = (double)((pe * nw + 3) / 4) * (110 + 10.0 * k) / (double)pe;
+        double cost = (double)((pe * nw + 3) / 4) * (110 + 10.0 * k) / (double)pe;
+        // (K = 16 with at most two wavefronts per SIMD: its rows take 1.5x those of K = 20 with the SAME wavefront count -- 256 pairs at READ_SIZE 2 952: 448 against 674 GCUPS, 3 688:
+        //  564 against 846, strip_shape_sweep_few.txt; with four and more pairs per CU its higher residency makes up for it)
+        if (k == 16 && pe * nw <= 8) cost *= 1.5;
         if (!best_k || cost < best_cost) { best_k = k; best_nw = nw; best_cost = cost; }
     }
     if (!best_k) return false;
