@@ -442,7 +442,12 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
         }
     }
     // NW / SWG long reads: one pair per workgroup of 1-12 wavefronts, row-scan, canonical table in per-workgroup HBM scratch
-    if (p.read_size > 320 || kn.force_dpwave) {
+    // (SWG with int8 cells -- the launchers' MAX_SCORE < 127 -- wraps by design and is nobody's but the literal kernels': swg_lane_kernel, one pair per LANE with its M and I rows
+    //  in LDS, takes it as far as 64 lanes' rows fit a CU's LDS (READ_SIZE <= 1 199; round 6: until then dp_wave_kernel's literal path, one lane per WORKGROUP, from READ_SIZE 321 on:
+    //  6 - 13 GCUPS, profiles/r06/cliff_scan.txt))
+    const bool cell8_lane = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1 && !kn.force_dpwave && !kn.dpw_legacy && kn.dpw_nw < 0 && kn.strip_k <= 0 &&
+                            (size_t)2 * (p.read_size + 1) * 64 <= 150 * 1024;
+    if ((p.read_size > 320 && !cell8_lane) || kn.force_dpwave) {
         const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
         if (!kn.dpw_legacy && kn.dpw_nw < 0 && aim::dp_strip_supported(p, cell8, kn)) {
             // column-strip pipeline (dp_strip.hpp): previous row in registers, packed int16 arithmetic, mailboxes instead of barriers

@@ -89,7 +89,8 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 250, 1064, backtrace=True, reduce=True))) == b"wfa_group_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("wfa", 2000, 8000))) == b"wfa_wave_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 500, 10112, backtrace=True))) == b"dp_strip_kernel"    # round 3: column-strip pipeline
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 100, 1064, backtrace=True))) == b"dp_wave_kernel"      # int8 cells (MAX_SCORE < 127): row-scan kernel's literal path
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 100, 1064, backtrace=True))) == b"swg_lane_kernel"     # int8 cells (MAX_SCORE < 127): the literal kernels -- one pair per lane while 64 lanes' rows fit LDS (round 6) ...
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 100, 1200, backtrace=True))) == b"dp_wave_kernel"      # ... beyond READ_SIZE 1199 the row-scan kernel's literal path
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 400, 20000))) == b"dp_wave_kernel"                      # beyond 16 384 columns
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 112))) == b"nw_reg_kernel"                           # round 4: rows in registers up to READ_SIZE 128 (112 with CIGAR)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 120, backtrace=True))) == b"nw_reg_kernel"          # round 5: READ_SIZE 120 / 128 with CIGAR too (l = 100, e = 10 %)
@@ -109,7 +110,7 @@ def test_scratch_planning_is_pure(built):
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 2056, backtrace=True))) == b"dp_strip_kernel"
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 200, 336, backtrace=True))) == b"dp_group_kernel"      # (int16 cells by MAX_SCORE)
     assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336, swg_w16=True))) == b"dp_group_kernel"
-    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_strip_kernel" or lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"dp_wave_kernel"   # (int8 cells wrap by design: the literal kernels)
+    assert lib.aim_kernel_name(C.byref(engine.make_params("swg", 8, 336))) == b"swg_lane_kernel"                        # (int8 cells wrap by design: the literal kernels)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184, gap=180))) == b"nw_lane_kernel"                 # (dp_strip_exact_ok: an int16 store could wrap)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 4, 184, gap=90))) == b"dp_group_kernel"                 # (round 6: READ_SIZE x gap bounds a cell, not twice that)
     assert lib.aim_kernel_name(C.byref(engine.make_params("nw", 300, 7904))) == b"dp_strip_kernel"                      # (until round 6 the literal one-lane path from READ_SIZE 3 998 on)

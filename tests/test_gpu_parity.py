@@ -418,6 +418,8 @@ def _dp_kernel_name(env, params):
     rs_ok = params.read_size >= 177 and (params.read_size <= 1024 or ((nw and params.read_size <= 1280) or 1440 <= params.read_size <= (2560 if nw else 2048) if bt else params.read_size <= (1792 if nw else 1536)))
     if not env and not int8 and rs_ok:
         return b"dp_group_kernel"            # round 5: medium reads (the long-read kernels' knobs keep them on dp_strip / dp_wave); round 6: dp_group_rs_ok's ranges
+    if int8 and not env and params.read_size <= 1199 and not os.environ.get("AIM_FORCE_DPWAVE"):
+        return b"swg_lane_kernel"            # round 6: int8 cells on one pair per lane while 64 lanes' rows fit LDS
     return b"dp_wave_kernel" if (env.get("AIM_DPW_LEGACY") or int8) else b"dp_strip_kernel"
 
 

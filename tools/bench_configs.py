@@ -67,6 +67,9 @@ CONFIGS = {
     "swg_l2800_e5_w16_cigar": dict(algo="swg", l=2800, e=0.05, n=1024, kw=dict(backtrace=True, swg_w16=True)),
     "nw_l5000_e5_score": dict(algo="nw", l=5000, e=0.05, n=1024, kw=dict()),
     "nw_l5000_e5_cigar": dict(algo="nw", l=5000, e=0.05, n=1024, kw=dict(backtrace=True)),
+    # round 6: SWG with the launchers' int8 cells (MAX_SCORE < 127: they wrap by design) beyond READ_SIZE 320: swg_lane_kernel while 64 lanes' rows fit LDS (dp_wave's one-lane literal path before)
+    "swg_l500_e1_int8_score": dict(algo="swg", l=500, e=0.01, n=16384, kw=dict()),
+    "swg_l1000_e1_int8_score": dict(algo="swg", l=1000, e=0.01, n=4096, kw=dict()),
     "swg_l500_e5_w16_cigar": dict(algo="swg", l=500, e=0.05, n=24576, kw=dict(backtrace=True, swg_w16=True)),   # (MAX_SCORE 125: int8 cells wrap by design here, S3 -- a pair then stops with AIM_PAIR_SWG_NO_OP)
     "swg_l1000_e5_cigar": dict(algo="swg", l=1000, e=0.05, n=1 << 12, kw=dict(backtrace=True)),
     "swg_l10000_e1_cigar": dict(algo="swg", l=10000, e=0.01, n=128, kw=dict(backtrace=True)),
