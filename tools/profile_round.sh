@@ -66,6 +66,9 @@ python3 tools/pmc_summary.py --out $P/dp_group_l2000_cigar_pmc_summary.json --ke
 python3 tools/pmc_summary.py --out $P/dp_strip_nw_l5000_pmc_summary.json --kernel dp_strip_kernel --pairs 1024 \
    --note "NW l=5000 e=5% score-only (READ_SIZE 5264), 1 024 pairs: dp_strip_kernel, four wavefronts of 24 cells per lane per pair (round 6: until then the literal one-lane path behind an int16 bound that was loose by 2x: 4 GCUPS; NOTES R6.7)." \
    -- python3 tools/bench_configs.py nw_l5000_e5_score > $O/pmc_strip5000.log 2>&1; tail -1 $O/pmc_strip5000.log
+SWEEP_NS=1024 SWEEP_LENGTHS=2000,2800,3500,5000,6200 python3 tools/strip_shape_sweep.py $P/strip_shape_sweep.txt > $O/strip_shape_sweep.log 2>&1        # (tests/test_strip_shape_cpu.py reads these two)
+SWEEP_NS=256,512 SWEEP_LENGTHS=1000,2000,2800,3500,5000 python3 tools/strip_shape_sweep.py $P/strip_shape_sweep_few.txt > $O/strip_shape_sweep_few.log 2>&1
+# (tools/cliff_scan.py -> $P/cliff_scan.txt takes ~11 minutes, most of it on the literal paths' rows: run it on its own)
 python3 tools/length_sweep.py $P/length_sweep.txt > $O/length_sweep.log 2>&1
 python3 tools/bench_configs.py > $P/all_configs_kernel_timers.jsonl 2> $O/configs.err
 python3 -c "
