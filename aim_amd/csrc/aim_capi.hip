@@ -445,8 +445,13 @@ int make_plan_inner(const aim_params_t &p, uint32_t n_pairs, const aim::Knobs &k
     // (SWG with int8 cells -- the launchers' MAX_SCORE < 127 -- wraps by design and is nobody's but the literal kernels': swg_lane_kernel, one pair per LANE with its M and I rows
     //  in LDS, takes it as far as 64 lanes' rows fit a CU's LDS (READ_SIZE <= 1 199; round 6: until then dp_wave_kernel's literal path, one lane per WORKGROUP, from READ_SIZE 321 on:
     //  6 - 13 GCUPS, profiles/r06/cliff_scan.txt))
-    const bool cell8_lane = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1 && !kn.force_dpwave && !kn.dpw_legacy && kn.dpw_nw < 0 && kn.strip_k <= 0 &&
-                            (size_t)2 * (p.read_size + 1) * 64 <= 150 * 1024;
+    bool cell8_lane = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1 && !kn.force_dpwave && !kn.dpw_legacy && kn.dpw_nw < 0 && kn.strip_k <= 0 &&
+                      (size_t)2 * (p.read_size + 1) * 64 <= 150 * 1024;
+    if (cell8_lane && p.read_size > 320) {   // (with CIGAR a lane's table is READ_SIZE^2 x 4 bytes x 64 lanes per workgroup: a budget that does not hold eight of them keeps the one-table-per-workgroup path)
+        Plan t;
+        memset(&t, 0, sizeof t);
+        cell8_lane = aim::dp_lane_plan(p, n_pairs, budget, kn, &t.grid, &t.block, &t.lds, &t.scratch_per_wg, &t.scratch_total, &t.seq_lds);
+    }
     if ((p.read_size > 320 && !cell8_lane) || kn.force_dpwave) {
         const bool cell8 = p.algo == AIM_ALGO_SWG && aim::swg_cell_bytes(p) == 1;
         if (!kn.dpw_legacy && kn.dpw_nw < 0 && aim::dp_strip_supported(p, cell8, kn)) {

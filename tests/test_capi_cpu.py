@@ -310,3 +310,22 @@ def test_round4_plan_shapes(built):
         assert plan(engine.make_params("nw", 4, 112, gap=60), 1 << 20).startswith("nw_lane_kernel")     # costs too large for INF = 16 000 to stay out of reach
     finally:
         os.environ.update(env)
+
+
+def test_int8_swg_medium_reads_keep_a_plan_under_a_small_scratch_bound(monkeypatch):
+    """Round 6: SWG with int8 cells at READ_SIZE 321 .. 1199 runs on swg_lane_kernel (one pair per lane). With CIGAR a workgroup's 64 tables are READ_SIZE^2 x 256 bytes;
+    a scratch bound that cannot hold the smallest grid of them must fall back to dp_wave_kernel's one table per workgroup, not fail (ADVICE r05 on dp_group, same rule)."""
+    from aim_amd import capi, engine
+    lib = capi.load()
+    def plan(p, n):
+        buf = C.create_string_buffer(1024)
+        assert lib.aim_plan_describe(C.byref(p), n, buf, 1024) == 0, lib.aim_last_error()
+        return buf.value.decode()
+    for k in list(os.environ):
+        if k.startswith("AIM_") and k != "AIM_LIB":
+            monkeypatch.delenv(k)
+    assert plan(engine.make_params("swg", 100, 1064, backtrace=True), 4096).startswith("swg_lane_kernel")
+    monkeypatch.setenv("AIM_SCRATCH_GB", "1")
+    assert plan(engine.make_params("swg", 100, 1064, backtrace=True), 4096).startswith("dp_wave_kernel")
+    assert plan(engine.make_params("swg", 100, 1064), 4096).startswith("swg_lane_kernel")            # score-only: no table at all
+    assert plan(engine.make_params("swg", 100, 536, backtrace=True), 4096).startswith("swg_lane_kernel")
